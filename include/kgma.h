@@ -1,0 +1,199 @@
+/*
+ * kgma.h -- C ABI of libkgma: the MI355X (gfx950) implementation of KmerGMA.jl's
+ * sliding-window k-mer-distance genome scan.
+ *
+ * Drop-in boundary.  The reference (Julia, no FFI of its own) exposes the scan as two
+ * keyword-only engine functions that API.jl and the tests call directly:
+ *
+ *   ac_gma_testing!(; genome_path, refVec, consensus_refseq, k, windowsize, thr, buff, mask,
+ *                     Nt_bits, ScaleFactor, do_align, ..., resultVec)       src/GenomeMiner.jl:4-23
+ *   Omn_KmerGMA!(;    genome_path, refVecs, windowsizes, consensus_seqs, resultVec, k, ScaleFactor,
+ *                     mask, thr_vec, buff, ..., dist_vec_vec)               src/OmnGenomeMiner.jl:7-30
+ *
+ * A Julia shim with those signatures `ccall`s the entry points below (INTEGRATION.md shows the
+ * binding); the per-record body of both engines (src/GenomeMiner.jl:32-107,
+ * src/OmnGenomeMiner.jl:55-160) is what this library replaces.  FASTA parsing, reference
+ * preparation, BioAlignments re-alignment and FASTA-record construction stay on the host.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary: every call returns a KGMA_* status (0 = OK);
+ *     kgma_last_error() gives the message for the last failing call on that context.
+ *   - all sequence coordinates are 1-BASED and inclusive, exactly as in the reference.
+ *   - the caller owns every buffer it passes in; the library copies what it keeps.
+ *   - a context is bound to one GPU and is not thread-safe; use one context per host thread/task.
+ *   - there is NO CPU fallback: kgma_create fails with KGMA_E_NODEVICE when no gfx950 device
+ *     (or no HIP runtime) is available.
+ */
+#ifndef KGMA_H
+#define KGMA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KGMA_VERSION_MAJOR 0
+#define KGMA_VERSION_MINOR 1
+
+/* status codes */
+enum {
+    KGMA_OK = 0,
+    KGMA_E_ARG = 1,         /* invalid argument (also k >= windowsize: error() at src/API.jl:70,177) */
+    KGMA_E_NODEVICE = 2,    /* no usable HIP device / runtime                                      */
+    KGMA_E_HIP = 3,         /* a HIP runtime call failed                                           */
+    KGMA_E_BADBASE = 4,     /* residue outside A/C/G/T/N (either case): KeyError, src/Consts.jl:22-28 */
+    KGMA_E_BOUNDS = 5,      /* record shorter than k-1 in the cluster engine: BoundsError, src/OmnGenomeMiner.jl:84-86 */
+    KGMA_E_UNSUPPORTED = 6, /* parameters outside what the device path implements                  */
+    KGMA_E_OVERFLOW = 7,    /* a device-side record buffer overflowed even after regrowth           */
+    KGMA_E_NOMEM = 8,
+    KGMA_E_STATE = 9        /* call sequence error (e.g. scan before set_refs)                      */
+};
+
+/* engine selector for kgma_scan */
+enum {
+    KGMA_MODE_SINGLE = 0,   /* ac_gma_testing!  src/GenomeMiner.jl:4-109   (uses KFV 1 only)          */
+    KGMA_MODE_OMN = 1       /* Omn_KmerGMA!     src/OmnGenomeMiner.jl:7-162 (all KFVs, lock-step)     */
+};
+
+/* flags for kgma_scan */
+enum {
+    KGMA_F_RETURN_DISTS = 1u << 0   /* do_return_dists: keep the per-window distances on the device
+                                       for kgma_get_dists (8 B per window per KFV)                   */
+};
+
+/* flags in kgma_hit.flags / kgma_dip.flags */
+enum {
+    KGMA_HIT_TIE = 1u << 0,        /* the dip's minimum is attained at >=2 positions that are not one
+                                      contiguous plateau: exact arithmetic reports the FIRST; the
+                                      reference's choice there depends on Float64 rounding noise     */
+    KGMA_HIT_AT_THRESHOLD = 1u << 1 /* some window of the dip (or its exit) has D == T exactly        */
+};
+
+typedef struct kgma_ctx kgma_ctx;
+typedef struct kgma_genome kgma_genome;
+
+/* One accepted hit, in the reference's emission order.
+ * single engine: cmi = CMI after `CMI += 1` (GenomeMiner.jl:92) = best window start + k - 1;
+ * cluster engine: cmi = CMIs[ind] (OmnGenomeMiner.jl:117,123) = best window start - 1.
+ * lo:hi = seq_UnitRange (after the align callback if one was given). */
+typedef struct {
+    int32_t contig;      /* 0-based index of the record in the genome                          */
+    int32_t kfv;         /* 1-based KFV index (cluster engine); 0 for the single engine        */
+    int64_t cmi;
+    int64_t lo, hi;
+    int64_t genome_pos;  /* GenomeMiner.jl:25,106 / OmnGenomeMiner.jl:25,159                   */
+    double dist;         /* currminim = D / (2 k N^2)                                          */
+    int64_t D;           /* exact integer squared distance sum_x (S[x] - N c[x])^2             */
+    uint32_t flags;
+    uint32_t reserved;
+} kgma_hit;
+
+/* One dip (maximal run of tested windows with d < thr) as found by the device, before the
+ * host-side hit state machine.  Window starts are 1-based. */
+typedef struct {
+    int32_t contig;
+    int32_t kfv;          /* 1-based */
+    int64_t start, end;   /* first / last window start of the run                               */
+    int64_t argmin;       /* first window start attaining the minimum                           */
+    int64_t D_min;
+    int64_t exit_pos;     /* end + 1 if that window was tested (dip closed), else 0 (open at contig end) */
+    int64_t D_exit;       /* D of the exit window (valid if exit_pos != 0)                      */
+    uint32_t flags;
+    uint32_t reserved;
+} kgma_dip;
+
+typedef struct {
+    int64_t bases_scanned;     /* sum of contig lengths handed to the last scan                 */
+    int64_t windows_scanned;   /* windows evaluated (all KFVs)                                  */
+    int64_t n_dips, n_hits, n_tie_flagged, n_at_threshold;
+    double pack_ms, scan_ms;   /* device time of the last pack / scan kernels (hipEvents)       */
+    double replay_ms;          /* host time of the hit state machine                            */
+    int64_t device_bytes;      /* device memory held by the context + current genome            */
+    int32_t n_tiles, n_launches;
+} kgma_stats;
+
+/* Host-side stand-in for `pairalign` + `cigar_to_UnitRange` (src/Alignment.jl:33-52,
+ * src/OmnGenomeMiner.jl:130-136): given a candidate range lo:hi (1-based) on `contig` for KFV
+ * `kfv` (0 for the single engine) it must write the aligned range.  Called on the calling
+ * thread, in reference order, interleaved with the hit state machine (the cluster engine feeds
+ * the result back into its overlap checks, OmnGenomeMiner.jl:126,139,152). NULL = no alignment. */
+typedef void (*kgma_align_fn)(void *user, int32_t contig, int32_t kfv, int64_t lo, int64_t hi,
+                              int64_t seq_len, int64_t *out_lo, int64_t *out_hi);
+
+int kgma_version(void);
+const char *kgma_status_string(int status);
+const char *kgma_last_error(const kgma_ctx *ctx);
+
+/* Create a context on HIP device `device_ordinal`. */
+int kgma_create(int device_ordinal, kgma_ctx **out);
+void kgma_destroy(kgma_ctx *ctx);
+
+/* Upload the reference KFV(s).  ref: m x 4^k row-major Float64 (refVec / refVecs, natural k-mer
+ * index order: first base most significant, src/Kmers.jl:37-43).  windowsizes[m], thr[m].
+ * n_refs[m]: number of reference sequences averaged into each KFV (KFV = S/N, S integer); the
+ * device computes in exact integers with S = round(ref*N).  n_refs == NULL: N is inferred
+ * (smallest N <= 2^20 making ref*N integral to 1e-9); KGMA_E_UNSUPPORTED if none exists.
+ * Requires 1 <= k <= 7 (LDS-resident tables), k < min(windowsizes) (src/API.jl:70,177). */
+int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const int64_t *windowsizes,
+                  const double *thr, const int64_t *n_refs);
+
+/* Change thresholds only (thr[m]). */
+int kgma_set_thresholds(kgma_ctx *ctx, const double *thr);
+
+/* Build a device-resident genome from host ASCII records (raw FASTA residue bytes, either case;
+ * line breaks already removed).  The bytes are copied to the device and packed there to two
+ * bit-planes (A0 C1 G2 T3 N->3, src/Consts.jl:22-28).  Residues outside A/C/G/T/N are recorded
+ * per record; kgma_scan raises KGMA_E_BADBASE for those the reference would have looked up. */
+int kgma_genome_from_host(kgma_ctx *ctx, const uint8_t *const *contig_ascii, const int64_t *contig_len,
+                          int64_t n_contigs, kgma_genome **out);
+
+/* Build a synthetic genome on the device (benchmarks; no PCIe traffic): n_contigs records of the
+ * given lengths, base i of record c = splitmix64(seed + c, i) >> 62 written as ASCII 'A','C','G','T',
+ * then `n_plants` copies of `plant` (ASCII, length plant_len) written at the given (contig,
+ * 1-based position) pairs, then packed like kgma_genome_from_host. */
+int kgma_genome_synthetic(kgma_ctx *ctx, const int64_t *contig_len, int64_t n_contigs, uint64_t seed,
+                          const uint8_t *plant, int64_t plant_len, const int64_t *plant_contig,
+                          const int64_t *plant_pos, int64_t n_plants, kgma_genome **out);
+
+/* Copy `len` ASCII bases of record `contig` starting at 1-based `pos` back to the host
+ * (used to build the FASTA body of a hit: view(seq, seq_UnitRange)). */
+int kgma_genome_fetch(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int64_t pos, int64_t len,
+                      uint8_t *out);
+int64_t kgma_genome_num_contigs(const kgma_genome *g);
+int64_t kgma_genome_contig_len(const kgma_genome *g, int64_t contig);
+int64_t kgma_genome_total_bases(const kgma_genome *g);
+void kgma_genome_free(kgma_ctx *ctx, kgma_genome *g);
+
+/* Re-run only the ASCII -> bit-plane pack kernel of a resident genome (benchmarks). */
+int kgma_genome_repack(kgma_ctx *ctx, kgma_genome *g);
+
+/* Scan every record of `g`.  mode: KGMA_MODE_*.  buff: `buff`.  genome_pos0: the cluster
+ * engine's `genome_pos` keyword (OmnGenomeMiner.jl:25); ignored (0) by the single engine.
+ * Results are kept in the context until the next scan. */
+int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, int64_t genome_pos0,
+              uint32_t flags, kgma_align_fn align, void *align_user);
+
+/* Device part of kgma_scan only (kernels + record download, no hit state machine); used by
+ * benchmarks and by callers that replay dips themselves. */
+int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, uint32_t flags);
+
+/* Results of the last scan.  Two-call pattern: out == NULL or cap too small -> *n is set to the
+ * required count (status KGMA_OK when out == NULL, KGMA_E_ARG when cap is too small). */
+int kgma_get_hits(kgma_ctx *ctx, kgma_hit *out, int64_t cap, int64_t *n);
+int kgma_get_dips(kgma_ctx *ctx, kgma_dip *out, int64_t cap, int64_t *n);
+/* D of the first window of every record for KFV `kfv` (1-based): out[n_contigs], -1 = record skipped. */
+int kgma_get_first_window(kgma_ctx *ctx, int32_t kfv, int64_t *out, int64_t cap, int64_t *n);
+/* Per-window distances of KFV `kfv` (1-based) in the order the reference push!es them
+ * (GenomeMiner.jl:79 / OmnGenomeMiner.jl:111); needs KGMA_F_RETURN_DISTS. */
+int kgma_get_dists(kgma_ctx *ctx, int32_t kfv, double *out, int64_t cap, int64_t *n);
+
+int kgma_get_stats(kgma_ctx *ctx, kgma_stats *out);
+
+/* Host stream handle (hipStream_t) the context launches on, for callers that time with hipEvents. */
+void *kgma_stream(kgma_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KGMA_H */

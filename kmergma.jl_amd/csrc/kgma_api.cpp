@@ -1,0 +1,995 @@
+// kgma_api.cpp -- host side of libkgma: the C ABI declared in include/kgma.h.
+//
+// Owns device memory, launches the gfx950 kernels of kgma_kernels.hip, stitches the per-lane dip
+// fragments the scan kernel emits into dips, and replays the reference's hit state machine over
+// them (src/GenomeMiner.jl:82-104, src/OmnGenomeMiner.jl:113-156) -- O(#dips) host work, with the
+// optional alignment callback interleaved exactly where the reference calls BioAlignments.
+//
+// There is no CPU fallback for the scan itself: without a HIP device kgma_create fails.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/kgma.h"
+#include "kgma_device.h"
+
+namespace kgma {
+struct ScanArgs {
+    const uint32_t *planes;
+    const TileDesc *tiles;
+    const int32_t *Stab;
+    int64_t *D0out;
+    DevRecord *recs;
+    unsigned int *rec_count;
+    unsigned int rec_cap;
+    int32_t n_tiles;
+    double *dist[KGMA_MAX_GROUP];
+    unsigned long long *n_att;
+};
+size_t scan_lds_bytes(int k, int nk, int n_kfv);
+hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc *cd, int n_contigs,
+                       int64_t total_words, unsigned long long *first_bad, hipStream_t st);
+hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int64_t total_words,
+                        uint64_t seed, hipStream_t st);
+hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
+}  // namespace kgma
+
+using namespace kgma;
+
+namespace {
+
+constexpr int64_t CONTIG_PAD_WORDS = 32;
+constexpr int64_t TAIL_PAD_WORDS = KGMA_TILE_WORDS + 64;
+constexpr unsigned long long NO_BAD = ~0ull;
+
+struct KfvInfo {
+    int64_t W = 0;
+    int64_t N = 0;
+    double thr = 0;
+    int64_t T = 0;
+    int64_t sumS2 = 0;
+    std::vector<int64_t> S;   // natural k-mer order
+};
+
+struct Group {
+    int64_t W;
+    std::vector<int> kfvs;    // 0-based KFV indices
+};
+
+}  // namespace
+
+struct kgma_genome {
+    int64_t n_contigs = 0;
+    int64_t total_bases = 0;
+    int64_t total_words = 0;      // plane words incl. padding
+    int64_t ascii_bytes = 0;
+    std::vector<ContigDesc> cd;
+    std::vector<unsigned long long> first_bad;
+    uint8_t *d_ascii = nullptr;
+    uint32_t *d_planes = nullptr;
+    ContigDesc *d_cd = nullptr;
+    unsigned long long *d_first_bad = nullptr;
+    int64_t device_bytes = 0;
+};
+
+struct kgma_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    // references
+    int k = 0, m = 0;
+    std::vector<KfvInfo> kfv;
+    int32_t *d_Stab = nullptr;        // m x 4^k, plane-index order
+    // scan scratch
+    TileDesc *d_tiles = nullptr; int64_t tiles_cap = 0;
+    int64_t *d_D0 = nullptr; int64_t d0_cap = 0;
+    DevRecord *d_recs = nullptr; unsigned int rec_cap = 0;
+    unsigned int *d_rec_count = nullptr;
+    unsigned long long *d_n_att = nullptr;
+    std::vector<double *> d_dist;     // per KFV
+    std::vector<int64_t> dist_cap;
+    // results of the last scan
+    int last_mode = -1;
+    std::vector<TileDesc> tiles;
+    std::vector<int64_t> contig_tile_base;   // per contig: index of its first tile or -1
+    std::vector<int64_t> contig_nwin;        // evaluated windows per contig (0 = skipped)
+    std::vector<int64_t> D0;                 // [m][n_tiles] (slot = kfv index)
+    std::vector<kgma_dip> dips;
+    std::vector<kgma_hit> hits;
+    std::vector<int64_t> contig_len;
+    int64_t n_dists_per_kfv = 0;
+    bool have_dists = false;
+    kgma_stats stats{};
+    int64_t device_bytes = 0;
+};
+
+namespace {
+
+int fail(kgma_ctx *ctx, int code, const char *fmt, ...)
+{
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail((ctx), KGMA_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e__));  \
+    } while (0)
+
+template <class T>
+int dev_reserve(kgma_ctx *ctx, T *&ptr, int64_t &cap, int64_t need)
+{
+    if (need <= cap && ptr) return KGMA_OK;
+    if (ptr) { (void)hipFree(ptr); ctx->device_bytes -= cap * (int64_t)sizeof(T); ptr = nullptr; cap = 0; }
+    int64_t n = std::max<int64_t>(need, 16);
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ptr), (size_t)n * sizeof(T)));
+    cap = n;
+    ctx->device_bytes += n * (int64_t)sizeof(T);
+    return KGMA_OK;
+}
+
+// natural k-mer value (first base most significant, 2 bits per base, Kmers.jl:37-43) ->
+// plane-order index used on the device: bit j = hi bit of base j, bit k+j = lo bit of base j.
+uint32_t plane_index_of(uint32_t v, int k)
+{
+    uint32_t idx = 0;
+    for (int j = 0; j < k; j++) {
+        const uint32_t code = (v >> (2 * (k - 1 - j))) & 3u;
+        idx |= (code >> 1) << j;
+        idx |= (code & 1u) << (k + j);
+    }
+    return idx;
+}
+
+// smallest integer T with (D < T) <=> (D / (2 k N^2) < thr) in exact arithmetic
+int64_t int_threshold(double thr, int k, int64_t N)
+{
+    if (!(thr > 0.0)) return 0;
+    if (thr >= 4.0e18) return INT64_MAX;
+    int e;
+    const double fr = std::frexp(thr, &e);
+    const int64_t mant = (int64_t)std::ldexp(fr, 53);
+    e -= 53;
+    const __int128 scale = (__int128)2 * k * N * N;
+    const __int128 prod = (__int128)mant * scale;
+    if (e >= 0) {
+        if (e > 60) return INT64_MAX;
+        const __int128 v = prod << e;
+        return v > (__int128)INT64_MAX ? INT64_MAX : (int64_t)v;
+    }
+    const int sh = -e;
+    if (sh >= 126) return 1;
+    __int128 q = prod >> sh;
+    if (prod - (q << sh) != 0) q += 1;
+    return q > (__int128)INT64_MAX ? INT64_MAX : (int64_t)q;
+}
+
+std::vector<Group> make_groups(const kgma_ctx *ctx, int mode)
+{
+    std::vector<Group> gs;
+    if (mode == KGMA_MODE_SINGLE) {
+        gs.push_back(Group{ctx->kfv[0].W, {0}});
+        return gs;
+    }
+    for (int j = 0; j < ctx->m; j++) {
+        bool placed = false;
+        for (auto &g : gs)
+            if (g.W == ctx->kfv[j].W && (int)g.kfvs.size() < KGMA_MAX_GROUP) { g.kfvs.push_back(j); placed = true; break; }
+        if (!placed) gs.push_back(Group{ctx->kfv[j].W, {j}});
+    }
+    return gs;
+}
+
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" {
+
+int kgma_version(void) { return KGMA_VERSION_MAJOR * 1000 + KGMA_VERSION_MINOR; }
+
+const char *kgma_status_string(int s)
+{
+    switch (s) {
+    case KGMA_OK: return "ok";
+    case KGMA_E_ARG: return "invalid argument";
+    case KGMA_E_NODEVICE: return "no HIP device";
+    case KGMA_E_HIP: return "HIP runtime error";
+    case KGMA_E_BADBASE: return "residue outside A/C/G/T/N (KeyError in the reference)";
+    case KGMA_E_BOUNDS: return "record shorter than k-1 (BoundsError in the reference)";
+    case KGMA_E_UNSUPPORTED: return "unsupported parameters";
+    case KGMA_E_OVERFLOW: return "device record buffer overflow";
+    case KGMA_E_NOMEM: return "out of memory";
+    case KGMA_E_STATE: return "invalid call sequence";
+    default: return "unknown status";
+    }
+}
+
+const char *kgma_last_error(const kgma_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int kgma_create(int device_ordinal, kgma_ctx **out)
+{
+    if (!out) return KGMA_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return KGMA_E_NODEVICE;
+    if (device_ordinal < 0 || device_ordinal >= n) return KGMA_E_ARG;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return KGMA_E_NODEVICE;
+    kgma_ctx *ctx = new (std::nothrow) kgma_ctx();
+    if (!ctx) return KGMA_E_NOMEM;
+    ctx->device = device_ordinal;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&ctx->d_rec_count), sizeof(unsigned int)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&ctx->d_n_att), sizeof(unsigned long long)) != hipSuccess) {
+        kgma_destroy(ctx);
+        return KGMA_E_HIP;
+    }
+    *out = ctx;
+    return KGMA_OK;
+}
+
+void kgma_destroy(kgma_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (double *p : ctx->d_dist) if (p) (void)hipFree(p);
+    if (ctx->d_Stab) (void)hipFree(ctx->d_Stab);
+    if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
+    if (ctx->d_D0) (void)hipFree(ctx->d_D0);
+    if (ctx->d_recs) (void)hipFree(ctx->d_recs);
+    if (ctx->d_rec_count) (void)hipFree(ctx->d_rec_count);
+    if (ctx->d_n_att) (void)hipFree(ctx->d_n_att);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void *kgma_stream(kgma_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int kgma_set_thresholds(kgma_ctx *ctx, const double *thr)
+{
+    if (!ctx) return KGMA_E_ARG;
+    if (!thr) return fail(ctx, KGMA_E_ARG, "thr is NULL");
+    if (ctx->m == 0) return fail(ctx, KGMA_E_STATE, "kgma_set_refs has not been called");
+    for (int j = 0; j < ctx->m; j++) {
+        ctx->kfv[j].thr = thr[j];
+        ctx->kfv[j].T = int_threshold(thr[j], ctx->k, ctx->kfv[j].N);
+    }
+    return KGMA_OK;
+}
+
+int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const int64_t *windowsizes,
+                  const double *thr, const int64_t *n_refs)
+{
+    if (!ctx) return KGMA_E_ARG;
+    if (!ref || !windowsizes || !thr || m < 1) return fail(ctx, KGMA_E_ARG, "null argument or m < 1");
+    if (k < 2 || k > 7) return fail(ctx, KGMA_E_UNSUPPORTED, "k = %d: the device path supports 2 <= k <= 7", k);
+    (void)hipSetDevice(ctx->device);
+    const int64_t NB = (int64_t)1 << (2 * k);
+    std::vector<KfvInfo> kv((size_t)m);
+    for (int j = 0; j < m; j++) {
+        KfvInfo &f = kv[(size_t)j];
+        f.W = windowsizes[j];
+        if (k >= f.W)   // src/API.jl:70,177
+            return fail(ctx, KGMA_E_ARG, "the average reference sequence length %lld exceeds/is equal to the chosen kmer length %d. please reduce k.",
+                        (long long)f.W, k);
+        const int64_t nk = f.W - k + 1;
+        if (nk > KGMA_MAX_NK)
+            return fail(ctx, KGMA_E_UNSUPPORTED, "window size %lld: at most %d k-mers per window are supported", (long long)f.W, KGMA_MAX_NK);
+        const double *r = ref + (size_t)j * (size_t)NB;
+        int64_t N = 0;
+        if (n_refs) {
+            N = n_refs[j];
+            if (N < 1) return fail(ctx, KGMA_E_ARG, "n_refs[%d] = %lld", j, (long long)N);
+        } else {
+            for (int64_t cand = 1; cand <= (1 << 20) && N == 0; cand++) {
+                bool ok = true;
+                for (int64_t x = 0; x < NB && ok; x++) {
+                    const double v = r[x] * (double)cand;
+                    ok = std::fabs(v - std::nearbyint(v)) <= 1e-9 * std::max(1.0, std::fabs(v));
+                }
+                if (ok) N = cand;
+            }
+            if (N == 0) return fail(ctx, KGMA_E_UNSUPPORTED, "KFV %d is not of the form S/N with integer S and N <= 2^20", j + 1);
+        }
+        f.N = N;
+        f.S.resize((size_t)NB);
+        __int128 s2 = 0;
+        for (int64_t x = 0; x < NB; x++) {
+            const double v = r[x] * (double)N;
+            const double rv = std::nearbyint(v);
+            if (!(std::fabs(v - rv) <= 1e-6 * std::max(1.0, std::fabs(v))) || rv < 0 || rv > 2.0e9)
+                return fail(ctx, KGMA_E_UNSUPPORTED, "KFV %d entry %lld (%.17g) times N=%lld is not a non-negative integer", j + 1,
+                            (long long)x, r[x], (long long)N);
+            f.S[(size_t)x] = (int64_t)rv;
+            s2 += (__int128)f.S[(size_t)x] * f.S[(size_t)x];
+        }
+        // the device keeps E = (D - D0)/(2N) and N*diff in int32
+        const __int128 dmax = s2 + (__int128)N * N * nk * nk;
+        if (dmax / (2 * N) >= ((__int128)1 << 29) || (__int128)N * nk >= ((__int128)1 << 30))
+            return fail(ctx, KGMA_E_UNSUPPORTED, "KFV %d: N = %lld with %lld k-mers per window exceeds the int32 range of the device path", j + 1,
+                        (long long)N, (long long)nk);
+        f.sumS2 = (int64_t)s2;
+        f.thr = thr[j];
+        f.T = int_threshold(thr[j], k, N);
+    }
+    // upload the plane-index permuted tables
+    std::vector<int32_t> tab((size_t)m * (size_t)NB);
+    for (int j = 0; j < m; j++)
+        for (int64_t v = 0; v < NB; v++)
+            tab[(size_t)j * (size_t)NB + plane_index_of((uint32_t)v, k)] = (int32_t)kv[(size_t)j].S[(size_t)v];
+    if (ctx->d_Stab) { (void)hipFree(ctx->d_Stab); ctx->d_Stab = nullptr; }
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_Stab), tab.size() * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_Stab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    ctx->k = k;
+    ctx->m = m;
+    ctx->kfv.swap(kv);
+    for (double *p : ctx->d_dist) if (p) (void)hipFree(p);
+    ctx->d_dist.assign((size_t)m, nullptr);
+    ctx->dist_cap.assign((size_t)m, 0);
+    ctx->last_mode = -1;
+    return KGMA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// genomes
+// ------------------------------------------------------------------------------------------
+static int genome_layout(kgma_ctx *ctx, kgma_genome *g, const int64_t *contig_len, int64_t n_contigs)
+{
+    g->n_contigs = n_contigs;
+    g->cd.resize((size_t)n_contigs);
+    int64_t aoff = 0, woff = 0, total = 0;
+    for (int64_t c = 0; c < n_contigs; c++) {
+        const int64_t L = contig_len[c];
+        if (L < 0) return fail(ctx, KGMA_E_ARG, "contig_len[%lld] < 0", (long long)c);
+        g->cd[(size_t)c] = ContigDesc{aoff, woff, L};
+        aoff += ((L + 31) & ~31ll) + 32;
+        woff += (L + 31) / 32 + CONTIG_PAD_WORDS;
+        total += L;
+    }
+    g->ascii_bytes = aoff + 64;
+    g->total_words = woff + TAIL_PAD_WORDS;
+    g->total_bases = total;
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_ascii), (size_t)g->ascii_bytes));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_planes), (size_t)g->total_words * 8));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_cd), std::max<size_t>(1, (size_t)n_contigs) * sizeof(ContigDesc)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_first_bad), std::max<size_t>(1, (size_t)n_contigs) * sizeof(unsigned long long)));
+    g->device_bytes = g->ascii_bytes + g->total_words * 8 + n_contigs * (int64_t)(sizeof(ContigDesc) + 8);
+    if (n_contigs > 0)
+        HIP_TRY(ctx, hipMemcpy(g->d_cd, g->cd.data(), (size_t)n_contigs * sizeof(ContigDesc), hipMemcpyHostToDevice));
+    return KGMA_OK;
+}
+
+int kgma_genome_repack(kgma_ctx *ctx, kgma_genome *g)
+{
+    if (!ctx || !g) return KGMA_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    g->first_bad.assign((size_t)std::max<int64_t>(1, g->n_contigs), NO_BAD);
+    HIP_TRY(ctx, hipMemsetAsync(g->d_first_bad, 0xFF, std::max<size_t>(1, (size_t)g->n_contigs) * 8, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (g->n_contigs > 0)
+        HIP_TRY(ctx, launch_pack(g->d_ascii, g->d_planes, g->d_cd, (int)g->n_contigs, g->total_words, g->d_first_bad, ctx->stream));
+    else
+        HIP_TRY(ctx, hipMemsetAsync(g->d_planes, 0, (size_t)g->total_words * 8, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    if (g->n_contigs > 0)
+        HIP_TRY(ctx, hipMemcpyAsync(g->first_bad.data(), g->d_first_bad, (size_t)g->n_contigs * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->stats.pack_ms = ms;
+    return KGMA_OK;
+}
+
+int kgma_genome_from_host(kgma_ctx *ctx, const uint8_t *const *contig_ascii, const int64_t *contig_len,
+                          int64_t n_contigs, kgma_genome **out)
+{
+    if (!ctx) return KGMA_E_ARG;
+    if (!out || n_contigs < 0 || (n_contigs > 0 && (!contig_ascii || !contig_len)))
+        return fail(ctx, KGMA_E_ARG, "null argument");
+    if (n_contigs > 0x7FFFFFF0ll) return fail(ctx, KGMA_E_UNSUPPORTED, "too many records");
+    *out = nullptr;
+    kgma_genome *g = new (std::nothrow) kgma_genome();
+    if (!g) return fail(ctx, KGMA_E_NOMEM, "out of host memory");
+    int rc = genome_layout(ctx, g, contig_len, n_contigs);
+    if (rc != KGMA_OK) { kgma_genome_free(ctx, g); return rc; }
+    // stream the records through a pinned staging buffer
+    const size_t stage_cap = (size_t)64 << 20;
+    uint8_t *stage = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void **>(&stage), stage_cap, hipHostMallocDefault) != hipSuccess) {
+        kgma_genome_free(ctx, g);
+        return fail(ctx, KGMA_E_NOMEM, "cannot allocate the pinned staging buffer");
+    }
+    int64_t win_base = 0;   // device offset of stage[0]
+    size_t fill = 0;        // bytes of the window in use
+    auto flush = [&]() -> hipError_t {
+        if (fill == 0) return hipSuccess;
+        hipError_t e = hipMemcpy(g->d_ascii + win_base, stage, fill, hipMemcpyHostToDevice);
+        win_base += (int64_t)fill;
+        fill = 0;
+        return e;
+    };
+    hipError_t he = hipSuccess;
+    for (int64_t c = 0; c < n_contigs && he == hipSuccess; c++) {
+        const ContigDesc &d = g->cd[(size_t)c];
+        const int64_t region = ((d.len + 31) & ~31ll) + 32;
+        int64_t done = 0;   // bytes of this record's region already staged
+        while (done < region && he == hipSuccess) {
+            if (fill == stage_cap) { he = flush(); if (he != hipSuccess) break; }
+            const size_t room = stage_cap - fill;
+            const size_t take = (size_t)std::min<int64_t>((int64_t)room, region - done);
+            // part of [done, done+take) that is residue data
+            const int64_t data_hi = std::min<int64_t>(d.len, done + (int64_t)take);
+            size_t ndata = data_hi > done ? (size_t)(data_hi - done) : 0;
+            if (ndata) memcpy(stage + fill, contig_ascii[c] + done, ndata);
+            if (take > ndata) memset(stage + fill + ndata, 0, take - ndata);
+            fill += take;
+            done += (int64_t)take;
+        }
+    }
+    if (he == hipSuccess) he = flush();
+    (void)hipHostFree(stage);
+    if (he != hipSuccess) {
+        kgma_genome_free(ctx, g);
+        return fail(ctx, KGMA_E_HIP, "host-to-device copy failed: %s", hipGetErrorString(he));
+    }
+    rc = kgma_genome_repack(ctx, g);
+    if (rc != KGMA_OK) { kgma_genome_free(ctx, g); return rc; }
+    *out = g;
+    return KGMA_OK;
+}
+
+int kgma_genome_synthetic(kgma_ctx *ctx, const int64_t *contig_len, int64_t n_contigs, uint64_t seed,
+                          const uint8_t *plant, int64_t plant_len, const int64_t *plant_contig,
+                          const int64_t *plant_pos, int64_t n_plants, kgma_genome **out)
+{
+    if (!ctx) return KGMA_E_ARG;
+    if (!out || !contig_len || n_contigs < 1) return fail(ctx, KGMA_E_ARG, "null argument");
+    if (n_plants > 0 && (!plant || !plant_contig || !plant_pos || plant_len < 1)) return fail(ctx, KGMA_E_ARG, "bad plant arguments");
+    *out = nullptr;
+    kgma_genome *g = new (std::nothrow) kgma_genome();
+    if (!g) return fail(ctx, KGMA_E_NOMEM, "out of host memory");
+    int rc = genome_layout(ctx, g, contig_len, n_contigs);
+    if (rc != KGMA_OK) { kgma_genome_free(ctx, g); return rc; }
+    hipError_t he = launch_synth(g->d_ascii, g->d_cd, (int)n_contigs, g->total_words, seed, ctx->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+    for (int64_t i = 0; i < n_plants && he == hipSuccess; i++) {
+        const int64_t c = plant_contig[i], pos = plant_pos[i];
+        if (c < 0 || c >= n_contigs || pos < 1 || pos + plant_len - 1 > contig_len[c]) {
+            kgma_genome_free(ctx, g);
+            return fail(ctx, KGMA_E_ARG, "plant %lld does not fit its record", (long long)i);
+        }
+        he = hipMemcpy(g->d_ascii + g->cd[(size_t)c].ascii_off + (pos - 1), plant, (size_t)plant_len, hipMemcpyHostToDevice);
+    }
+    if (he != hipSuccess) {
+        kgma_genome_free(ctx, g);
+        return fail(ctx, KGMA_E_HIP, "synthetic genome generation failed: %s", hipGetErrorString(he));
+    }
+    rc = kgma_genome_repack(ctx, g);
+    if (rc != KGMA_OK) { kgma_genome_free(ctx, g); return rc; }
+    *out = g;
+    return KGMA_OK;
+}
+
+int kgma_genome_fetch(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int64_t pos, int64_t len, uint8_t *outp)
+{
+    if (!ctx || !g) return KGMA_E_ARG;
+    if (contig < 0 || contig >= g->n_contigs || pos < 1 || len < 0 || pos + len - 1 > g->cd[(size_t)contig].len || (!outp && len > 0))
+        return fail(ctx, KGMA_E_ARG, "kgma_genome_fetch: range outside the record");
+    if (len == 0) return KGMA_OK;
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipMemcpy(outp, g->d_ascii + g->cd[(size_t)contig].ascii_off + (pos - 1), (size_t)len, hipMemcpyDeviceToHost));
+    return KGMA_OK;
+}
+
+int64_t kgma_genome_num_contigs(const kgma_genome *g) { return g ? g->n_contigs : 0; }
+int64_t kgma_genome_contig_len(const kgma_genome *g, int64_t c)
+{
+    return (g && c >= 0 && c < g->n_contigs) ? g->cd[(size_t)c].len : -1;
+}
+int64_t kgma_genome_total_bases(const kgma_genome *g) { return g ? g->total_bases : 0; }
+
+void kgma_genome_free(kgma_ctx *ctx, kgma_genome *g)
+{
+    if (!g) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (g->d_ascii) (void)hipFree(g->d_ascii);
+    if (g->d_planes) (void)hipFree(g->d_planes);
+    if (g->d_cd) (void)hipFree(g->d_cd);
+    if (g->d_first_bad) (void)hipFree(g->d_first_bad);
+    delete g;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// scan: device part
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct Frag {             // one device record in global coordinates
+    int32_t contig, kfv;  // kfv 0-based
+    int32_t kind;
+    int64_t start, end;   // 1-based window starts
+    int64_t minD, exitD;
+    int64_t argf, argl;
+    int64_t nmin;
+    bool has_exit;
+};
+
+int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
+{
+    const int64_t n_tiles = (int64_t)ctx->tiles.size();
+    const int64_t P = KGMA_TILE_WINDOWS;
+    std::vector<Frag> fr;
+    fr.reserve(recs.size());
+    for (const DevRecord &r : recs) {
+        if (r.tile < 0 || r.tile >= n_tiles) return fail(ctx, KGMA_E_HIP, "corrupt device record (tile %d)", r.tile);
+        const TileDesc &td = ctx->tiles[(size_t)r.tile];
+        const int kfv = (r.kind_kfv >> 8) - 1;
+        if (kfv < 0 || kfv >= ctx->m) return fail(ctx, KGMA_E_HIP, "corrupt device record (kfv %d)", kfv + 1);
+        const int64_t D0 = ctx->D0[(size_t)kfv * (size_t)n_tiles + (size_t)r.tile];
+        const int64_t twoN = 2 * ctx->kfv[(size_t)kfv].N;
+        Frag f;
+        f.contig = td.contig; f.kfv = kfv; f.kind = r.kind_kfv & 0xFF;
+        f.start = td.win0 + r.start; f.end = td.win0 + r.end;
+        f.minD = D0 + twoN * (int64_t)r.minE;
+        f.exitD = D0 + twoN * (int64_t)r.exitE;
+        f.argf = td.win0 + r.argf; f.argl = td.win0 + r.argl;
+        f.nmin = r.nmin; f.has_exit = r.has_exit != 0;
+        fr.push_back(f);
+    }
+    std::sort(fr.begin(), fr.end(), [](const Frag &a, const Frag &b) {
+        if (a.contig != b.contig) return a.contig < b.contig;
+        if (a.kfv != b.kfv) return a.kfv < b.kfv;
+        if (a.start != b.start) return a.start < b.start;
+        return a.kind < b.kind;
+    });
+    ctx->dips.clear();
+    int64_t n_tie = 0;
+    size_t i = 0;
+    const size_t n = fr.size();
+    // positions (contig,kfv) -> set of ATT positions for flagging
+    auto att_at = [&](int32_t contig, int32_t kfv, int64_t pos) -> bool {
+        Frag key; key.contig = contig; key.kfv = kfv; key.start = pos; key.kind = REC_ATT;
+        auto it = std::lower_bound(fr.begin(), fr.end(), key, [](const Frag &a, const Frag &b) {
+            if (a.contig != b.contig) return a.contig < b.contig;
+            if (a.kfv != b.kfv) return a.kfv < b.kfv;
+            if (a.start != b.start) return a.start < b.start;
+            return a.kind < b.kind;
+        });
+        return it != fr.end() && it->contig == contig && it->kfv == kfv && it->start == pos && it->kind == REC_ATT;
+    };
+    while (i < n) {
+        if (fr[i].kind != REC_RUN) { i++; continue; }
+        Frag cur = fr[i];
+        size_t jx = i + 1;
+        // merge fragments that continue the run (skipping EXIT/ATT records in between is not
+        // needed: a continuing RUN starts exactly at cur.end + 1)
+        while (true) {
+            size_t nx = jx;
+            while (nx < n && fr[nx].contig == cur.contig && fr[nx].kfv == cur.kfv && fr[nx].kind != REC_RUN && fr[nx].start <= cur.end + 1) nx++;
+            if (!cur.has_exit && nx < n && fr[nx].kind == REC_RUN && fr[nx].contig == cur.contig && fr[nx].kfv == cur.kfv &&
+                fr[nx].start == cur.end + 1) {
+                const Frag &b = fr[nx];
+                if (b.minD < cur.minD) { cur.minD = b.minD; cur.argf = b.argf; cur.argl = b.argl; cur.nmin = b.nmin; }
+                else if (b.minD == cur.minD) { cur.argl = b.argl; cur.nmin += b.nmin; }
+                cur.end = b.end; cur.has_exit = b.has_exit; cur.exitD = b.exitD;
+                jx = nx + 1;
+            } else break;
+        }
+        kgma_dip d;
+        memset(&d, 0, sizeof d);
+        d.contig = cur.contig; d.kfv = cur.kfv + 1;
+        d.start = cur.start; d.end = cur.end; d.argmin = cur.argf; d.D_min = cur.minD;
+        const int64_t nwin = ctx->contig_nwin[(size_t)cur.contig];
+        if (cur.has_exit) { d.exit_pos = cur.end + 1; d.D_exit = cur.exitD; }
+        else if (cur.end + 1 <= nwin) {
+            // exit window lies in another lane / tile: an EXIT record, or the next tile's D0
+            const int64_t e = cur.end + 1;
+            bool found = false;
+            for (size_t u = i; u < n && fr[u].contig == cur.contig && fr[u].kfv == cur.kfv && fr[u].start <= e; u++)
+                if (fr[u].kind == REC_EXIT && fr[u].start == e) { d.exit_pos = e; d.D_exit = fr[u].exitD; found = true; break; }
+            if (!found) {
+                if ((e - 1) % P != 0) return fail(ctx, KGMA_E_HIP, "internal: dip exit at window %lld of record %d not found", (long long)e, cur.contig);
+                const int64_t t = ctx->contig_tile_base[(size_t)cur.contig] + (e - 1) / P;
+                d.exit_pos = e;
+                d.D_exit = ctx->D0[(size_t)cur.kfv * (size_t)n_tiles + (size_t)t];
+            }
+        }
+        if (cur.nmin != cur.argl - cur.argf + 1) { d.flags |= KGMA_HIT_TIE; n_tie++; }
+        if ((d.exit_pos && d.D_exit == ctx->kfv[(size_t)cur.kfv].T) || att_at(cur.contig, cur.kfv, cur.start - 1))
+            d.flags |= KGMA_HIT_AT_THRESHOLD;
+        ctx->dips.push_back(d);
+        i = jx > i ? jx : i + 1;
+    }
+    ctx->stats.n_dips = (int64_t)ctx->dips.size();
+    ctx->stats.n_tie_flagged = n_tie;
+    return KGMA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, uint32_t flags)
+{
+    if (!ctx || !g) return KGMA_E_ARG;
+    if (ctx->m == 0) return fail(ctx, KGMA_E_STATE, "kgma_set_refs has not been called");
+    if (mode != KGMA_MODE_SINGLE && mode != KGMA_MODE_OMN) return fail(ctx, KGMA_E_ARG, "unknown mode %d", mode);
+    (void)hipSetDevice(ctx->device);
+    const int k = ctx->k, m_used = mode == KGMA_MODE_SINGLE ? 1 : ctx->m;
+    const int64_t P = KGMA_TILE_WINDOWS;
+    int64_t maxws = 0;
+    for (int j = 0; j < m_used; j++) maxws = std::max(maxws, ctx->kfv[(size_t)j].W);
+
+    // ---- which windows each record evaluates, and the residues the reference would look up ---
+    const int64_t nc = g->n_contigs;
+    ctx->contig_len.resize((size_t)nc);
+    ctx->contig_nwin.assign((size_t)nc, 0);
+    ctx->contig_tile_base.assign((size_t)nc, -1);
+    ctx->tiles.clear();
+    ctx->dips.clear();
+    ctx->hits.clear();
+    ctx->have_dists = false;
+    ctx->last_mode = -1;
+    int64_t dist_total = 0, bases = 0, windows = 0;
+    for (int64_t c = 0; c < nc; c++) {
+        const int64_t L = g->cd[(size_t)c].len;
+        ctx->contig_len[(size_t)c] = L;
+        bases += L;
+        int64_t nwin = 0, looked = 0;
+        if (mode == KGMA_MODE_SINGLE) {
+            const int64_t W = ctx->kfv[0].W;
+            if (L >= W) { nwin = L - W + 1; looked = L; }   // GenomeMiner.jl:37-39,60
+        } else {
+            if (L < k - 1)
+                return fail(ctx, KGMA_E_BOUNDS, "record %lld has %lld residues, fewer than k-1 (BoundsError, OmnGenomeMiner.jl:84-86)",
+                            (long long)c, (long long)L);
+            looked = k - 1;                                                    // :84-86
+            for (int j = 0; j < m_used; j++)
+                if (L >= ctx->kfv[(size_t)j].W) looked = std::max(looked, ctx->kfv[(size_t)j].W);   // :61-82
+            const int64_t n_iter = L - maxws - k + 2;                          // :89
+            if (n_iter >= 1) { nwin = n_iter + 1; looked = std::max(looked, L - k + 2); }   // seq[i+ws], :97
+        }
+        const unsigned long long fb = g->first_bad[(size_t)c];
+        if (fb != NO_BAD && (int64_t)fb <= looked)
+            return fail(ctx, KGMA_E_BADBASE, "record %lld position %llu: residue is not one of A/C/G/T/N (KeyError, Consts.jl:22-28)",
+                        (long long)c, fb);
+        ctx->contig_nwin[(size_t)c] = nwin;
+        if (nwin > 0) {
+            ctx->contig_tile_base[(size_t)c] = (int64_t)ctx->tiles.size();
+            const int64_t nt = (nwin + P - 1) / P;
+            for (int64_t t = 0; t < nt; t++) {
+                TileDesc td;
+                td.word_base = g->cd[(size_t)c].word_off + t * KGMA_TILE_WORDS;
+                td.win0 = t * P + 1;
+                td.dist_base = dist_total + t * P - 1;
+                td.n_valid = (int32_t)std::min<int64_t>(P, nwin - t * P);
+                td.first_test = t == 0 ? 1 : 0;
+                td.contig = (int32_t)c;
+                td.pad = 0;
+                ctx->tiles.push_back(td);
+            }
+            dist_total += nwin - 1;
+            windows += nwin * m_used;
+        }
+    }
+    const int64_t n_tiles = (int64_t)ctx->tiles.size();
+    if (n_tiles > 0x7FFFFFF0ll) return fail(ctx, KGMA_E_UNSUPPORTED, "too many tiles");
+    ctx->n_dists_per_kfv = dist_total;
+    ctx->stats.bases_scanned = bases;
+    ctx->stats.windows_scanned = windows;
+    ctx->stats.n_tiles = (int32_t)n_tiles;
+    ctx->stats.n_launches = 0;
+    ctx->stats.scan_ms = 0;
+    ctx->stats.n_at_threshold = 0;
+    ctx->stats.n_dips = ctx->stats.n_hits = ctx->stats.n_tie_flagged = 0;
+    ctx->D0.assign((size_t)ctx->m * (size_t)std::max<int64_t>(1, n_tiles), -1);
+    if (n_tiles == 0) { ctx->last_mode = mode; ctx->have_dists = (flags & KGMA_F_RETURN_DISTS) != 0; return KGMA_OK; }
+
+    int rc = dev_reserve(ctx, ctx->d_tiles, ctx->tiles_cap, n_tiles);
+    if (rc) return rc;
+    rc = dev_reserve(ctx, ctx->d_D0, ctx->d0_cap, n_tiles * ctx->m);
+    if (rc) return rc;
+    if (ctx->rec_cap == 0) {
+        int64_t cap = 0;
+        rc = dev_reserve(ctx, ctx->d_recs, cap, 1 << 16);
+        if (rc) return rc;
+        ctx->rec_cap = (unsigned int)cap;
+    }
+    const bool want_dists = (flags & KGMA_F_RETURN_DISTS) != 0;
+    if (want_dists)
+        for (int j = 0; j < m_used; j++) {
+            rc = dev_reserve(ctx, ctx->d_dist[(size_t)j], ctx->dist_cap[(size_t)j], std::max<int64_t>(1, dist_total));
+            if (rc) return rc;
+        }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tiles, ctx->tiles.data(), (size_t)n_tiles * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
+
+    const std::vector<Group> groups = make_groups(ctx, mode);
+    const int64_t NB = (int64_t)1 << (2 * k);
+    unsigned int n_recs = 0;
+    for (int attempt = 0;; attempt++) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_rec_count, 0, sizeof(unsigned int), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_n_att, 0, sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        ctx->stats.n_launches = 0;
+        for (const Group &gr : groups) {
+            // the KFVs of one launch must be contiguous rows of the S table
+            size_t i = 0;
+            while (i < gr.kfvs.size()) {
+                size_t jn = i + 1;
+                while (jn < gr.kfvs.size() && gr.kfvs[jn] == gr.kfvs[jn - 1] + 1) jn++;
+                GroupParams gp;
+                memset(&gp, 0, sizeof gp);
+                ScanArgs a;
+                memset(&a, 0, sizeof a);
+                gp.n_kfv = (int32_t)(jn - i);
+                gp.k = k;
+                gp.nk = (int32_t)(gr.W - k + 1);
+                gp.nblocks = (gp.nk + 15) / 16;
+                for (size_t u = i; u < jn; u++) {
+                    const int j = gr.kfvs[u];
+                    const KfvInfo &f = ctx->kfv[(size_t)j];
+                    gp.kfv_id[u - i] = j + 1;
+                    gp.N[u - i] = (int32_t)f.N;
+                    gp.T[u - i] = f.T;
+                    gp.sumS2[u - i] = f.sumS2;
+                    gp.inv_scale[u - i] = 2.0 * (double)k * (double)f.N * (double)f.N;
+                    a.dist[u - i] = want_dists ? ctx->d_dist[(size_t)j] : nullptr;
+                }
+                const int j0 = gr.kfvs[i];
+                a.planes = g->d_planes;
+                a.tiles = ctx->d_tiles;
+                a.Stab = ctx->d_Stab + (size_t)j0 * (size_t)NB;
+                a.D0out = ctx->d_D0 + (size_t)j0 * (size_t)n_tiles;
+                a.recs = ctx->d_recs;
+                a.rec_count = ctx->d_rec_count;
+                a.rec_cap = ctx->rec_cap;
+                a.n_tiles = (int32_t)n_tiles;
+                a.n_att = ctx->d_n_att;
+                HIP_TRY(ctx, launch_scan(a, gp, ctx->stream));
+                ctx->stats.n_launches++;
+                i = jn;
+            }
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&n_recs, ctx->d_rec_count, sizeof n_recs, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (n_recs <= ctx->rec_cap) break;
+        if (attempt >= 4) return fail(ctx, KGMA_E_OVERFLOW, "record buffer overflow (%u records)", n_recs);
+        int64_t cap = ctx->rec_cap;
+        rc = dev_reserve(ctx, ctx->d_recs, cap, (int64_t)n_recs + (n_recs >> 2) + 1024);
+        if (rc) return rc;
+        ctx->rec_cap = (unsigned int)cap;
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->stats.scan_ms = ms;
+
+    std::vector<DevRecord> recs((size_t)n_recs);
+    unsigned long long n_att = 0;
+    if (n_recs) HIP_TRY(ctx, hipMemcpy(recs.data(), ctx->d_recs, (size_t)n_recs * sizeof(DevRecord), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&n_att, ctx->d_n_att, sizeof n_att, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(ctx->D0.data(), ctx->d_D0, (size_t)n_tiles * (size_t)ctx->m * sizeof(int64_t), hipMemcpyDeviceToHost));
+    ctx->stats.n_at_threshold = (int64_t)n_att;
+    ctx->have_dists = want_dists;
+    rc = stitch_dips(ctx, recs);
+    if (rc) return rc;
+    ctx->last_mode = mode;
+    ctx->stats.device_bytes = ctx->device_bytes + g->device_bytes;
+    return KGMA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// scan: host replay of the hit state machine over the dips
+// ------------------------------------------------------------------------------------------
+int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, int64_t genome_pos0,
+              uint32_t flags, kgma_align_fn align, void *align_user)
+{
+    int rc = kgma_scan_device(ctx, g, mode, flags);
+    if (rc) return rc;
+    if (buff < 0) return fail(ctx, KGMA_E_ARG, "buff < 0");
+    const double t0 = now_ms();
+    const int k = ctx->k;
+    const int64_t n_tiles = (int64_t)ctx->tiles.size();
+    ctx->hits.clear();
+    const int64_t nc = (int64_t)ctx->contig_len.size();
+    size_t di = 0;   // dips are sorted by (contig, kfv, start)
+    if (mode == KGMA_MODE_SINGLE) {
+        const KfvInfo &f = ctx->kfv[0];
+        const int64_t W = f.W;
+        const double scale = 2.0 * (double)k * (double)f.N * (double)f.N;
+        int64_t genome_pos = 0;                                         // GenomeMiner.jl:25
+        for (int64_t c = 0; c < nc; c++) {
+            const int64_t L = ctx->contig_len[(size_t)c];
+            if (ctx->contig_nwin[(size_t)c] == 0) continue;            // L < W: :37-39
+            const int64_t D1 = ctx->D0[(size_t)ctx->contig_tile_base[(size_t)c]];
+            int64_t CMI = 2, goal_ind = 0, currmin = D1;               // :57
+            bool stop = true;
+            uint32_t cur_flags = 0;
+            while (di < ctx->dips.size() && ctx->dips[di].contig < c) di++;
+            for (; di < ctx->dips.size() && ctx->dips[di].contig == c; di++) {
+                const kgma_dip &d = ctx->dips[di];
+                if (d.D_min < currmin) {                               // :83-87 (strict running minimum)
+                    currmin = d.D_min;
+                    CMI = d.argmin + k - 2;                            // i_left of the best window
+                    stop = false;
+                    cur_flags = d.flags;
+                }
+                if (d.exit_pos == 0) continue;                         // dip still open at the record end
+                if (!stop) {                                           // :90-104
+                    stop = true;
+                    CMI += 1;
+                    if (CMI > goal_ind) {
+                        goal_ind = CMI + W - 1;
+                        int64_t lo = std::max<int64_t>(CMI - buff, 1);
+                        int64_t hi = std::min<int64_t>(CMI + W - 1 + buff, L);
+                        if (align) align(align_user, (int32_t)c, 0, lo, hi, L, &lo, &hi);   // :96-99
+                        kgma_hit h;
+                        memset(&h, 0, sizeof h);
+                        h.contig = (int32_t)c; h.kfv = 0; h.cmi = CMI; h.lo = lo; h.hi = hi;
+                        h.genome_pos = genome_pos; h.D = currmin; h.dist = (double)currmin / scale;
+                        h.flags = cur_flags | (d.flags & KGMA_HIT_AT_THRESHOLD);
+                        ctx->hits.push_back(h);
+                        currmin = d.D_exit;                            // :102
+                    }
+                }
+            }
+            genome_pos += L;                                           // :106
+        }
+    } else {
+        const int m = ctx->m;
+        int64_t genome_pos = genome_pos0;                              // OmnGenomeMiner.jl:25
+        std::vector<int64_t> curr_mins((size_t)m), CMIs((size_t)m);
+        std::vector<char> stops((size_t)m);
+        std::vector<uint32_t> cflags((size_t)m);
+        std::vector<const kgma_dip *> evs;
+        for (int64_t c = 0; c < nc; c++) {
+            const int64_t L = ctx->contig_len[(size_t)c];
+            while (di < ctx->dips.size() && ctx->dips[di].contig < c) di++;
+            if (ctx->contig_nwin[(size_t)c] > 0) {
+                int64_t prev_lo = 0, prev_hi = 0;                      // prev_hit_range = 0:0, :59
+                const int64_t tb = ctx->contig_tile_base[(size_t)c];
+                for (int j = 0; j < m; j++) {                          // :61-82
+                    curr_mins[(size_t)j] = ctx->D0[(size_t)j * (size_t)n_tiles + (size_t)tb];
+                    CMIs[(size_t)j] = 1; stops[(size_t)j] = 1; cflags[(size_t)j] = 0;
+                }
+                evs.clear();
+                for (; di < ctx->dips.size() && ctx->dips[di].contig == c; di++) evs.push_back(&ctx->dips[di]);
+                // per-KFV minimum updates happen inside the dip, exits are ordered by (iteration, KFV)
+                std::stable_sort(evs.begin(), evs.end(), [](const kgma_dip *a, const kgma_dip *b) {
+                    const int64_t ea = a->exit_pos ? a->exit_pos : INT64_MAX, eb = b->exit_pos ? b->exit_pos : INT64_MAX;
+                    if (ea != eb) return ea < eb;
+                    return a->kfv < b->kfv;
+                });
+                for (const kgma_dip *dp : evs) {
+                    const kgma_dip &d = *dp;
+                    const int j = d.kfv - 1;
+                    const KfvInfo &f = ctx->kfv[(size_t)j];
+                    if (d.D_min < curr_mins[(size_t)j]) {              // :114-119
+                        curr_mins[(size_t)j] = d.D_min;
+                        CMIs[(size_t)j] = d.argmin - 1;                // i = window start - 1
+                        stops[(size_t)j] = 0;
+                        cflags[(size_t)j] = d.flags;
+                    }
+                    if (d.exit_pos == 0) continue;
+                    if (!stops[(size_t)j]) {                           // :122
+                        stops[(size_t)j] = 1;
+                        const int64_t CMI = CMIs[(size_t)j];
+                        if (!(CMI >= prev_lo && CMI <= prev_hi)) {     // :126
+                            int64_t lo = std::max<int64_t>(CMI - buff, 1);
+                            int64_t hi = std::min<int64_t>(CMI + f.W - 1 + buff, L);
+                            if (align) align(align_user, (int32_t)c, j + 1, lo, hi, L, &lo, &hi);   // :130-136
+                            if (hi < prev_lo || lo > prev_hi) {        // :139
+                                kgma_hit h;
+                                memset(&h, 0, sizeof h);
+                                h.contig = (int32_t)c; h.kfv = j + 1; h.cmi = CMI; h.lo = lo; h.hi = hi;
+                                h.genome_pos = genome_pos; h.D = curr_mins[(size_t)j];
+                                h.dist = (double)h.D / (2.0 * (double)k * (double)f.N * (double)f.N);
+                                h.flags = cflags[(size_t)j] | (d.flags & KGMA_HIT_AT_THRESHOLD);
+                                ctx->hits.push_back(h);
+                                prev_lo = lo; prev_hi = hi;            // :152
+                                curr_mins[(size_t)j] = d.D_exit;       // :153
+                            }
+                        }
+                    }
+                }
+            }
+            genome_pos += L;                                           // :159 (always)
+        }
+    }
+    ctx->stats.n_hits = (int64_t)ctx->hits.size();
+    ctx->stats.replay_ms = now_ms() - t0;
+    return KGMA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// results
+// ------------------------------------------------------------------------------------------
+int kgma_get_hits(kgma_ctx *ctx, kgma_hit *out, int64_t cap, int64_t *n)
+{
+    if (!ctx || !n) return KGMA_E_ARG;
+    *n = (int64_t)ctx->hits.size();
+    if (!out) return KGMA_OK;
+    if (cap < *n) return fail(ctx, KGMA_E_ARG, "kgma_get_hits: capacity %lld < %lld", (long long)cap, (long long)*n);
+    if (*n) memcpy(out, ctx->hits.data(), (size_t)*n * sizeof(kgma_hit));
+    return KGMA_OK;
+}
+
+int kgma_get_dips(kgma_ctx *ctx, kgma_dip *out, int64_t cap, int64_t *n)
+{
+    if (!ctx || !n) return KGMA_E_ARG;
+    *n = (int64_t)ctx->dips.size();
+    if (!out) return KGMA_OK;
+    if (cap < *n) return fail(ctx, KGMA_E_ARG, "kgma_get_dips: capacity %lld < %lld", (long long)cap, (long long)*n);
+    if (*n) memcpy(out, ctx->dips.data(), (size_t)*n * sizeof(kgma_dip));
+    return KGMA_OK;
+}
+
+int kgma_get_first_window(kgma_ctx *ctx, int32_t kfv, int64_t *out, int64_t cap, int64_t *n)
+{
+    if (!ctx || !n) return KGMA_E_ARG;
+    if (ctx->last_mode < 0) return fail(ctx, KGMA_E_STATE, "no scan has been run");
+    if (kfv < 1 || kfv > ctx->m) return fail(ctx, KGMA_E_ARG, "kfv %d out of range", kfv);
+    const int64_t nc = (int64_t)ctx->contig_len.size();
+    *n = nc;
+    if (!out) return KGMA_OK;
+    if (cap < nc) return fail(ctx, KGMA_E_ARG, "kgma_get_first_window: capacity too small");
+    const int64_t n_tiles = (int64_t)ctx->tiles.size();
+    for (int64_t c = 0; c < nc; c++) {
+        const int64_t tb = ctx->contig_tile_base[(size_t)c];
+        out[c] = tb < 0 ? -1 : ctx->D0[(size_t)(kfv - 1) * (size_t)std::max<int64_t>(1, n_tiles) + (size_t)tb];
+    }
+    return KGMA_OK;
+}
+
+int kgma_get_dists(kgma_ctx *ctx, int32_t kfv, double *out, int64_t cap, int64_t *n)
+{
+    if (!ctx || !n) return KGMA_E_ARG;
+    if (ctx->last_mode < 0 || !ctx->have_dists) return fail(ctx, KGMA_E_STATE, "the last scan did not keep distances (KGMA_F_RETURN_DISTS)");
+    const int m_used = ctx->last_mode == KGMA_MODE_SINGLE ? 1 : ctx->m;
+    if (kfv < 1 || kfv > m_used) return fail(ctx, KGMA_E_ARG, "kfv %d out of range", kfv);
+    *n = ctx->n_dists_per_kfv;
+    if (!out) return KGMA_OK;
+    if (cap < *n) return fail(ctx, KGMA_E_ARG, "kgma_get_dists: capacity too small");
+    (void)hipSetDevice(ctx->device);
+    if (*n) HIP_TRY(ctx, hipMemcpy(out, ctx->d_dist[(size_t)(kfv - 1)], (size_t)*n * sizeof(double), hipMemcpyDeviceToHost));
+    return KGMA_OK;
+}
+
+int kgma_get_stats(kgma_ctx *ctx, kgma_stats *out)
+{
+    if (!ctx || !out) return KGMA_E_ARG;
+    *out = ctx->stats;
+    return KGMA_OK;
+}
+
+}  // extern "C"

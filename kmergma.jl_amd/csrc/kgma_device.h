@@ -1,0 +1,67 @@
+// kgma_device.h -- structures shared between the host side (kgma_api.cpp) and the gfx950 kernels
+// (kgma_kernels.hip).  Internal to libkgma; the public boundary is include/kgma.h.
+#pragma once
+#include <stdint.h>
+
+namespace kgma {
+
+// Geometry of one scan tile: a workgroup of KGMA_THREADS lanes, each owning KGMA_R consecutive
+// 32-window words, i.e. KGMA_TILE_WINDOWS consecutive window starts of one record.
+constexpr int KGMA_THREADS = 256;
+constexpr int KGMA_R = 4;
+constexpr int KGMA_TILE_WORDS = KGMA_THREADS * KGMA_R;        // 1024 words
+constexpr int KGMA_TILE_WINDOWS = KGMA_TILE_WORDS * 32;        // 32768 window starts
+constexpr int KGMA_MAX_GROUP = 8;                              // KFVs of one window size per launch
+constexpr int KGMA_NPLANES = 9;                                // bit-sliced counter width
+constexpr int KGMA_MAX_NK = 16 * 31;                           // max k-mers per window (counter range)
+
+// One tile of the scan grid (built on the host, read by every workgroup).
+struct TileDesc {
+    int64_t word_base;   // word index (per plane) of the tile's first base in the plane array
+    int64_t win0;        // 1-based window start of local position 0
+    int64_t dist_base;   // index into the per-KFV distance array of local position 0 (may be -1)
+    int32_t n_valid;     // windows of this tile that exist and are evaluated (1..KGMA_TILE_WINDOWS)
+    int32_t first_test;  // first local position that is TESTED against the threshold (1 on a
+                         // record's first tile: the first window is never tested, GenomeMiner.jl:57)
+    int32_t contig;
+    int32_t pad;
+};
+
+// Per-KFV parameters of one launch group (all KFVs of the group share the window size).
+struct GroupParams {
+    int32_t n_kfv;                       // KFVs in this group (<= KGMA_MAX_GROUP)
+    int32_t k;                           // k-mer length
+    int32_t nk;                          // k-mers per window = W - k + 1
+    int32_t nblocks;                     // ceil(nk / 16): 16-offset blocks of the match loop
+    int32_t kfv_id[KGMA_MAX_GROUP];      // 1-based KFV index reported in records
+    int32_t N[KGMA_MAX_GROUP];           // reference count of each KFV
+    int64_t T[KGMA_MAX_GROUP];           // integer threshold: d < thr  <=>  D < T
+    int64_t sumS2[KGMA_MAX_GROUP];       // sum_x S[x]^2
+    double inv_scale[KGMA_MAX_GROUP];    // 2 k N^2 as a double (distance = D / that)
+};
+
+// Device record kinds.
+enum : int32_t { REC_RUN = 0, REC_EXIT = 1, REC_ATT = 2 };
+
+// One record emitted by the scan kernel (positions are local to the tile; E is the integer
+// prefix (D - D0[tile]) / (2N)).
+struct DevRecord {
+    int32_t tile;
+    int32_t kind_kfv;     // kind | (1-based KFV index << 8)
+    int32_t start, end;   // RUN: first/last local position of the under-threshold fragment
+                          // EXIT/ATT: start = position
+    int32_t minE;         // RUN: minimum E;  EXIT/ATT: E at the position
+    int32_t argf, argl;   // RUN: first / last local position attaining minE
+    int32_t nmin;         // RUN: number of positions attaining minE
+    int32_t exitE;        // RUN: E at end+1 when has_exit
+    int32_t has_exit;     // RUN: 1 if end+1 lies inside the same lane span and was evaluated
+};
+
+// Per-record info for the pack kernel.
+struct ContigDesc {
+    int64_t ascii_off;    // byte offset of the record's first residue in the ASCII buffer (32-aligned)
+    int64_t word_off;     // word index of the record's first base in the plane array
+    int64_t len;          // residues
+};
+
+}  // namespace kgma

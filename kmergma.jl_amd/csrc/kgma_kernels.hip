@@ -1,0 +1,586 @@
+// kgma_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of libkgma.
+//
+// Replaces the per-record body of the reference's scan engines
+// (src/GenomeMiner.jl:32-107 ac_gma_testing!, src/OmnGenomeMiner.jl:55-160 Omn_KmerGMA!) and the
+// base encoding they use (src/Consts.jl:22-28 NUCLEOTIDE_BITS, src/Kmers.jl:33-44 kmer_count!).
+//
+// Algorithm (DESIGN.md has the derivation).  The reference keeps a 4^k count table per window
+// and rolls the distance one base at a time; that is a serial chain per stream and the table
+// (8 KiB at k=6) caps a CU at ~20 streams.  Here the same integer quantity
+//     D_s = sum_x (S[x] - N c_s[x])^2            (d_s = D_s / (2 k N^2), S = N * refVec)
+// is obtained without any count table.  With n = W-k+1 k-mers per window and K_p the k-mer at p:
+//     D_{s+1} - D_s = 2N [ (S[K_s] - S[K_{s+n}]) - N (fwd_s - back_{s+n}) ]
+//     fwd_s  = #{ o in [1,n-1] : K_{s+o} == K_s }      (copies of the leaving k-mer left inside)
+//     back_p = #{ o in [1,n-1] : K_{p-n+o} == K_p }    (copies of the entering k-mer already inside)
+// Both counts compare the n-1 interior k-mers with one k-mer outside the window, so they are a
+// banded self-match count.  It is evaluated bit-parallel on the 2-bit genome stored as two
+// bit-planes: for every offset o one shifted copy of the planes is XOR-ed against the two anchor
+// copies (offset 0 and offset n), a k-long run-OR turns base mismatches into k-mer mismatches for
+// 32 window positions per VALU op, and the 0/1 masks are summed in bit-sliced (carry-save)
+// counters.  Everything is exact integer arithmetic, independent of how the genome is tiled.
+//
+// No MFMA (there is no contraction), no count table, no atomics on the hot path; LDS holds the
+// tile's bit-planes and the (plane-index-permuted) S tables.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kgma_device.h"
+
+namespace kgma {
+
+// ------------------------------------------------------------------------------------------
+// ASCII -> bit-planes (src/Consts.jl:22-28: A0 C1 G2 T3, N -> 3; either case).
+// One lane packs 32 residues (two 16-byte loads) into one {hi,lo} word pair.  Words past a
+// record's end (padding) are written as zero.  first_bad[c] receives the smallest 1-based
+// position of a residue outside A/C/G/T/N (atomicMin), or stays at its initial huge value.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_contig(const ContigDesc *cd, int n_contigs, int64_t g)
+{
+    int lo = 0, hi = n_contigs - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (cd[mid].word_off <= g) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii,
+                                                   uint32_t *__restrict__ planes,
+                                                   const ContigDesc *__restrict__ cd, int n_contigs,
+                                                   int64_t total_words,
+                                                   unsigned long long *__restrict__ first_bad)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total_words; g += stride) {
+        const int c = find_contig(cd, n_contigs, g);
+        const int64_t w = g - cd[c].word_off;
+        const int64_t L = cd[c].len;
+        const int64_t base0 = w * 32;
+        uint32_t h = 0, l = 0, bad = 0;
+        if (base0 < L) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(ascii + cd[c].ascii_off + base0);
+            const uint4 a = p[0], b = p[1];
+            const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            const int nvalid = (L - base0) < 32 ? (int)(L - base0) : 32;
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const uint32_t ch = ((x[i >> 2] >> (8 * (i & 3))) & 0xFFu) & 0xDFu;  // fold case
+                const uint32_t isA = ch == 'A', isC = ch == 'C', isG = ch == 'G';
+                const uint32_t isT = (ch == 'T') | (ch == 'N');
+                const uint32_t in = i < nvalid;
+                h |= ((isG | isT) & in) << i;
+                l |= ((isC | isT) & in) << i;
+                bad |= ((1u ^ (isA | isC | isG | isT)) & in) << i;
+            }
+        }
+        if (bad) {
+            const unsigned long long pos = (unsigned long long)(base0 + __builtin_ctz(bad) + 1);
+            atomicMin(&first_bad[c], pos);
+        }
+        reinterpret_cast<uint2 *>(planes)[g] = make_uint2(h, l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Synthetic genome (benchmarks): 32 residues per 64-bit splitmix64 output, written as ASCII.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t synth_word(uint64_t seed, uint64_t contig, uint64_t w)
+{
+    uint64_t z = seed + (contig + 1) * 0xD1B54A32D192ED03ull + (w + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void synth_kernel(uint8_t *__restrict__ ascii,
+                                                    const ContigDesc *__restrict__ cd, int n_contigs,
+                                                    int64_t total_words, uint64_t seed)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total_words; g += stride) {
+        const int c = find_contig(cd, n_contigs, g);
+        const int64_t w = g - cd[c].word_off;
+        const int64_t L = cd[c].len;
+        const int64_t base0 = w * 32;
+        if (base0 >= ((L + 31) & ~31ll)) continue;   // padding words carry no ASCII
+        const uint64_t z = synth_word(seed, (uint64_t)c, (uint64_t)w);
+        uint32_t out[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int bi = 4 * i + j;
+                const uint32_t code = (uint32_t)(z >> (2 * bi)) & 3u;
+                // "ACGT"[code]
+                const uint32_t ch = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : 'T';
+                v |= ((base0 + bi) < L ? ch : 0u) << (8 * j);
+            }
+            out[i] = v;
+        }
+        uint4 *p = reinterpret_cast<uint4 *>(ascii + cd[c].ascii_off + base0);
+        p[0] = make_uint4(out[0], out[1], out[2], out[3]);
+        p[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Scan kernel
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t s)
+{
+    return __builtin_amdgcn_alignbit(hi, lo, s);   // ({hi,lo} >> (s & 31)) low 32 bits
+}
+
+// h = majority(a,b,c), l = a^b^c  (carry-save adder on 32 window positions at once)
+#define KGMA_CSA(h, l, a, b, c)                      \
+    do {                                             \
+        const uint32_t u__ = (a) ^ (b);              \
+        const uint32_t h__ = ((a) & ~u__) | ((c) & u__); \
+        (l) = u__ ^ (c);                             \
+        (h) = h__;                                   \
+    } while (0)
+
+// Bit-sliced counter of one (direction, word): planes c[0..NP-1] plus the pending partial sums
+// of the Harley-Seal tree.
+struct Counter {
+    uint32_t c[KGMA_NPLANES];
+    uint32_t p0, p1, p2, p3;
+};
+
+// Add mask m (weight 1) as the I-th of 16 masks of a block.
+template <int I>
+__device__ __forceinline__ void counter_add(Counter &s, uint32_t m)
+{
+    if constexpr ((I & 1) == 0) { s.p0 = m; return; }
+    uint32_t c1; KGMA_CSA(c1, s.c[0], s.c[0], s.p0, m);
+    if constexpr ((I & 2) == 0) { s.p1 = c1; return; }
+    uint32_t c2; KGMA_CSA(c2, s.c[1], s.c[1], s.p1, c1);
+    if constexpr ((I & 4) == 0) { s.p2 = c2; return; }
+    uint32_t c3; KGMA_CSA(c3, s.c[2], s.c[2], s.p2, c2);
+    if constexpr ((I & 8) == 0) { s.p3 = c3; return; }
+    uint32_t c4; KGMA_CSA(c4, s.c[3], s.c[3], s.p3, c3);
+#pragma unroll
+    for (int p = 4; p < KGMA_NPLANES; p++) {
+        const uint32_t t = s.c[p] & c4;
+        s.c[p] ^= c4;
+        c4 = t;
+    }
+}
+
+// base-mismatch words o1[0..R] (R own words + 1 halo word) -> k-mer-mismatch words out[0..R-1]:
+// out bit q = OR_{i<K} o1 bit (q+i); `force` (0 or ~0) ORs in a forced mismatch.
+template <int K, int R>
+__device__ __forceinline__ void kmer_mismatch(const uint32_t (&o1)[R + 1], uint32_t force,
+                                              uint32_t (&out)[R])
+{
+    if constexpr (K == 1) {
+#pragma unroll
+        for (int w = 0; w < R; w++) out[w] = o1[w] | force;
+        return;
+    }
+    uint32_t o2[R + 1];
+#pragma unroll
+    for (int w = 0; w < R; w++) o2[w] = o1[w] | alignbit(o1[w + 1], o1[w], 1) | force;
+    o2[R] = o1[R] | (o1[R] >> 1);   // halo: only its low K-2 bits are consumed
+#pragma unroll
+    for (int w = 0; w < R; w++) {
+        uint32_t r = o2[w];
+        // cover offsets [0,K) with 2-wide pieces at shifts 2,4,... (and K-2 when K is odd)
+#pragma unroll
+        for (int sft = 2; sft + 2 <= K; sft += 2) r |= alignbit(o2[w + 1], o2[w], sft);
+        if constexpr ((K & 1) && K > 2) r |= alignbit(o2[w + 1], o2[w], K - 2);
+        out[w] = r;
+    }
+}
+
+// index of the k-mer at bit offset b of the word pair (cur,next) in "plane order":
+// low K bits = hi-plane bits, next K bits = lo-plane bits (host permutes the S tables to match).
+template <int K>
+__device__ __forceinline__ uint32_t plane_index(uint32_t hc, uint32_t hn, uint32_t lc, uint32_t ln,
+                                                uint32_t b)
+{
+    constexpr uint32_t km = (1u << K) - 1u;
+    const uint32_t hh = alignbit(hn, hc, b) & km;
+    const uint32_t ll = alignbit(ln, lc, b) & km;
+    return hh | (ll << K);
+}
+
+__device__ __forceinline__ int64_t shfl_down_i64(int64_t v, int d)
+{
+    int lo = (int)(uint32_t)v, hi = (int)(uint32_t)((uint64_t)v >> 32);
+    lo = __shfl_down(lo, d);
+    hi = __shfl_down(hi, d);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+__host__ __device__ inline int scan_pad_words(int nk)
+{
+    // words needed past the tile's own KGMA_TILE_WORDS: offsets up to nk+15, anchors at nk (+1
+    // halo word, +1 "next" word), k-mer extraction (+1).
+    return (nk + 16 + 31) / 32 + KGMA_R + 4;
+}
+
+__device__ __forceinline__ void emit_record(DevRecord *recs, unsigned int *rec_count,
+                                            unsigned int rec_cap, const DevRecord &r)
+{
+    const unsigned int idx = atomicAdd(rec_count, 1u);
+    if (idx < rec_cap) recs[idx] = r;
+}
+
+struct ScanArgs {
+    const uint32_t *planes;
+    const TileDesc *tiles;
+    const int32_t *Stab;        // n_kfv x 4^K int32, plane-index order
+    int64_t *D0out;             // [n_kfv][n_tiles]
+    DevRecord *recs;
+    unsigned int *rec_count;
+    unsigned int rec_cap;
+    int32_t n_tiles;
+    double *dist[KGMA_MAX_GROUP];   // per-KFV distance arrays or nullptr
+    unsigned long long *n_att;      // stats: windows with D == T
+};
+
+template <int K>
+__global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupParams gp)
+{
+    constexpr int R = KGMA_R;
+    constexpr int NP = KGMA_NPLANES;
+    constexpr int NB = 1 << (2 * K);
+    extern __shared__ uint32_t smem[];
+
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const TileDesc td = a.tiles[tile];
+    const int nk = gp.nk;
+    const int NW = KGMA_TILE_WORDS + scan_pad_words(nk);
+
+    uint32_t *sH = smem;
+    uint32_t *sL = sH + NW;
+    int32_t *sS = reinterpret_cast<int32_t *>(sL + NW);
+    int32_t *sHist = sS + gp.n_kfv * NB;
+    int32_t *sMisc = sHist + NB;                 // [0..15] scan scratch, [16..271] per-lane flags
+    int64_t *sRed = reinterpret_cast<int64_t *>(sMisc + 16 + KGMA_THREADS);   // 8-byte aligned
+
+    // ---- stage the tile's bit-planes and the S tables in LDS --------------------------------
+    {
+        const uint2 *g2 = reinterpret_cast<const uint2 *>(a.planes) + td.word_base;
+        for (int w = tid; w < NW; w += KGMA_THREADS) {
+            const uint2 v = g2[w];
+            sH[w] = v.x;
+            sL[w] = v.y;
+        }
+        for (int i = tid; i < gp.n_kfv * NB; i += KGMA_THREADS) sS[i] = a.Stab[i];
+        for (int i = tid; i < NB; i += KGMA_THREADS) sHist[i] = 0;
+    }
+    __syncthreads();
+
+    // ---- D of the tile's first window, directly: histogram of its nk k-mers ------------------
+    // (Kmers.jl:33-44 kmer_count! + the sqeuclidean call sites GenomeMiner.jl:46-47,
+    //  OmnGenomeMiner.jl:73-74, in exact integers)
+    for (int q = tid; q < nk; q += KGMA_THREADS) {
+        const int w = q >> 5;
+        const uint32_t idx = plane_index<K>(sH[w], sH[w + 1], sL[w], sL[w + 1], (uint32_t)(q & 31));
+        atomicAdd(&sHist[idx], 1);
+    }
+    __syncthreads();
+    for (int j = 0; j < gp.n_kfv; j++) {
+        int64_t acc = 0;
+        const int64_t Nj = gp.N[j];
+        for (int x = tid; x < NB; x += KGMA_THREADS) {
+            const int64_t d = (int64_t)sS[j * NB + x] - Nj * (int64_t)sHist[x];
+            acc += d * d;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += shfl_down_i64(acc, d);
+        if ((tid & 63) == 0) sRed[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            const int64_t D0 = sRed[0] + sRed[1] + sRed[2] + sRed[3];
+            a.D0out[(size_t)j * a.n_tiles + tile] = D0;
+            sRed[4 + j] = D0;
+        }
+        __syncthreads();
+    }
+
+    // ---- anchors: planes at offset 0 (leaving k-mer) and at offset nk (entering k-mer) -------
+    const int w0 = R * tid;
+    uint32_t A0h[R + 2], A0l[R + 2], Anh[R + 2], Anl[R + 2];
+    {
+        const int jn = nk >> 5;
+        const uint32_t sn = (uint32_t)(nk & 31);
+#pragma unroll
+        for (int w = 0; w < R + 2; w++) {
+            A0h[w] = sH[w0 + w];
+            A0l[w] = sL[w0 + w];
+            Anh[w] = alignbit(sH[w0 + jn + w + 1], sH[w0 + jn + w], sn);
+            Anl[w] = alignbit(sL[w0 + jn + w + 1], sL[w0 + jn + w], sn);
+        }
+    }
+
+    // ---- match loop: offsets o = 0 .. 16*nblocks-1, two directions, R words per lane ---------
+    Counter cf[R], cb[R];
+#pragma unroll
+    for (int w = 0; w < R; w++) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) { cf[w].c[p] = 0; cb[w].c[p] = 0; }
+        cf[w].p0 = cf[w].p1 = cf[w].p2 = cf[w].p3 = 0;
+        cb[w].p0 = cb[w].p1 = cb[w].p2 = cb[w].p3 = 0;
+    }
+
+    for (int blk = 0; blk < gp.nblocks; blk++) {
+        const int jw = blk >> 1;
+        const uint32_t s0 = (uint32_t)(blk & 1) << 4;
+        uint32_t Xh[R + 2], Xl[R + 2];
+#pragma unroll
+        for (int w = 0; w < R + 2; w++) {
+            Xh[w] = sH[w0 + jw + w];
+            Xl[w] = sL[w0 + jw + w];
+        }
+        const int obase = blk << 4;
+
+#define KGMA_STEP(I)                                                                       \
+        {                                                                                  \
+            const uint32_t s = s0 + (I);                                                   \
+            const uint32_t force = (obase + (I)) >= nk ? 0xFFFFFFFFu : 0u;                 \
+            uint32_t f1[R + 1], b1[R + 1];                                                 \
+            _Pragma("unroll") for (int w = 0; w <= R; w++) {                               \
+                const uint32_t xh = alignbit(Xh[w + 1], Xh[w], s);                         \
+                const uint32_t xl = alignbit(Xl[w + 1], Xl[w], s);                         \
+                f1[w] = (xh ^ A0h[w]) | (xl ^ A0l[w]);                                     \
+                b1[w] = (xh ^ Anh[w]) | (xl ^ Anl[w]);                                     \
+            }                                                                              \
+            uint32_t mf[R], mb[R];                                                         \
+            kmer_mismatch<K, R>(f1, force, mf);                                            \
+            kmer_mismatch<K, R>(b1, force, mb);                                            \
+            _Pragma("unroll") for (int w = 0; w < R; w++) {                                \
+                counter_add<I>(cf[w], mf[w]);                                              \
+                counter_add<I>(cb[w], mb[w]);                                              \
+            }                                                                              \
+        }
+        KGMA_STEP(0) KGMA_STEP(1) KGMA_STEP(2) KGMA_STEP(3)
+        KGMA_STEP(4) KGMA_STEP(5) KGMA_STEP(6) KGMA_STEP(7)
+        KGMA_STEP(8) KGMA_STEP(9) KGMA_STEP(10) KGMA_STEP(11)
+        KGMA_STEP(12) KGMA_STEP(13) KGMA_STEP(14) KGMA_STEP(15)
+#undef KGMA_STEP
+    }
+
+    // ---- diff = fwd - back = (cb - cf) - mm0, bit-sliced two's complement, NP+1 planes --------
+    // mismatch counts: cf = (nk-1) - fwd + forced, cb = (nk-1) - back + forced + mm0 where mm0 is
+    // the offset-0 mask of the back direction (K_q != K_{q+nk}); forced terms cancel.
+    uint32_t dpl[R][NP + 1];
+    {
+        uint32_t b0[R + 1], mm0[R];
+#pragma unroll
+        for (int w = 0; w <= R; w++) b0[w] = (A0h[w] ^ Anh[w]) | (A0l[w] ^ Anl[w]);
+        kmer_mismatch<K, R>(b0, 0u, mm0);
+#pragma unroll
+        for (int w = 0; w < R; w++) {
+            uint32_t bw = mm0[w];
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const uint32_t x = cb[w].c[p], y = cf[w].c[p];
+                const uint32_t u = x ^ y;
+                dpl[w][p] = u ^ bw;
+                bw = (y & u) | (bw & ~u);
+            }
+            dpl[w][NP] = bw;   // sign plane
+        }
+    }
+
+    // ---- position phase, per KFV of the group -------------------------------------------------
+    const int n_valid = td.n_valid;
+    const int first_test = td.first_test;
+    const int lim = n_valid - 1;              // roll q -> q+1 exists for q < lim
+    const int qa = 32 * w0;                   // first local position of this lane
+    int32_t *sScan = sMisc;                   // [0..3] wave totals, [4] spare
+    int32_t *sPrev = sMisc + 16;              // KGMA_THREADS ints
+
+    // walks the lane's 32*R positions in order, calling body(q, e_q) with e_q the integer roll
+    // delta (D_{q+1}-D_q)/(2N) of KFV slot j
+    auto walk = [&](int j, auto &&body) {
+        const int32_t *S = sS + j * NB;
+        const int32_t Nj = gp.N[j];
+#pragma unroll
+        for (int w = 0; w < R; w++) {
+            for (uint32_t b = 0; b < 32; b++) {
+                uint32_t v = (dpl[w][0] >> b) & 1u;
+#pragma unroll
+                for (int p = 1; p <= NP; p++) v |= ((dpl[w][p] >> b) & 1u) << p;
+                const int32_t diff = ((int32_t)(v << (31 - NP))) >> (31 - NP);   // sign-extend NP+1 bits
+                const uint32_t il = plane_index<K>(A0h[w], A0h[w + 1], A0l[w], A0l[w + 1], b);
+                const uint32_t ir = plane_index<K>(Anh[w], Anh[w + 1], Anl[w], Anl[w + 1], b);
+                const int q = qa + 32 * w + (int)b;
+                int32_t e = S[il] - S[ir] - Nj * diff;
+                e = q < lim ? e : 0;
+                body(q, e);
+            }
+        }
+    };
+
+    for (int j = 0; j < gp.n_kfv; j++) {
+        const int64_t D0 = sRed[4 + j];
+        const int64_t twoN = 2 * (int64_t)gp.N[j];
+        // E_q < TE  <=>  D0 + 2N E_q < T
+        int64_t TE64;
+        bool t_exact;
+        {
+            const int64_t num = gp.T[j] - D0;
+            TE64 = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
+            t_exact = (num % twoN) == 0;
+            if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; t_exact = false; }
+            if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; t_exact = false; }
+        }
+        const int32_t TE = (int32_t)TE64;
+
+        // pass A: lane-local prefix, its minimum over tested positions, and the lane total
+        int32_t r = 0, rmin = 0x7FFFFFFF, rlast = 0;
+        walk(j, [&](int q, int32_t e) {
+            const bool testable = q >= first_test && q < n_valid;
+            rmin = testable ? (r < rmin ? r : rmin) : rmin;
+            rlast = r;
+            r += e;
+        });
+        const int32_t total = r;
+
+        // workgroup exclusive scan of the lane totals
+        int32_t incl = total;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t t = __shfl_up(incl, d);
+            if ((tid & 63) >= d) incl += t;
+        }
+        if ((tid & 63) == 63) sScan[tid >> 6] = incl;
+        __syncthreads();
+        int32_t offset = incl - total;
+        for (int wv = 0; wv < (tid >> 6); wv++) offset += sScan[wv];
+
+        const int qb = qa + 32 * R - 1;
+        const bool last_testable = qb >= first_test && qb < n_valid;
+        const bool last_under = last_testable && (offset + rlast < TE);
+        sPrev[tid] = last_under ? 1 : 0;
+        __syncthreads();
+        const bool prev_under = tid > 0 && sPrev[tid - 1] != 0;
+        double *dist = a.dist[j];
+        const bool any_under = rmin != 0x7FFFFFFF && (offset + rmin < TE + (t_exact ? 1 : 0));
+        const bool need = (any_under || prev_under || dist != nullptr) && qa < n_valid;
+
+        if (need) {
+            // pass B: walk again with the absolute prefix and emit the dip fragments of this lane
+            const int slot = gp.kfv_id[j];
+            bool in_run = false;
+            int32_t run_start = 0, minE = 0, argf = 0, argl = 0, nmin = 0;
+            int32_t E = offset;
+            const double scale = gp.inv_scale[j];
+            walk(j, [&](int q, int32_t e) {
+                const bool testable = q >= first_test && q < n_valid;
+                const bool under = testable && E < TE;
+                if (testable && dist != nullptr)
+                    dist[td.dist_base + q] = (double)(D0 + twoN * (int64_t)E) / scale;
+                if (under) {
+                    if (!in_run) {
+                        in_run = true; run_start = q; minE = E; argf = argl = q; nmin = 1;
+                    } else if (E < minE) {
+                        minE = E; argf = argl = q; nmin = 1;
+                    } else if (E == minE) {
+                        argl = q; nmin++;
+                    }
+                } else {
+                    if (in_run) {
+                        DevRecord rec;
+                        rec.tile = tile; rec.kind_kfv = REC_RUN | (slot << 8);
+                        rec.start = run_start; rec.end = q - 1; rec.minE = minE;
+                        rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
+                        rec.exitE = E; rec.has_exit = q < n_valid ? 1 : 0;
+                        emit_record(a.recs, a.rec_count, a.rec_cap, rec);
+                        in_run = false;
+                    } else if (q == qa && prev_under && q < n_valid) {
+                        DevRecord rec;
+                        rec.tile = tile; rec.kind_kfv = REC_EXIT | (slot << 8);
+                        rec.start = q; rec.end = q; rec.minE = E;
+                        rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 1;
+                        emit_record(a.recs, a.rec_count, a.rec_cap, rec);
+                    }
+                    if (t_exact && testable && E == TE) {
+                        DevRecord rec;
+                        rec.tile = tile; rec.kind_kfv = REC_ATT | (slot << 8);
+                        rec.start = q; rec.end = q; rec.minE = E;
+                        rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
+                        emit_record(a.recs, a.rec_count, a.rec_cap, rec);
+                        atomicAdd(a.n_att, 1ull);
+                    }
+                }
+                E += e;
+            });
+            if (in_run) {
+                DevRecord rec;
+                rec.tile = tile; rec.kind_kfv = REC_RUN | (slot << 8);
+                rec.start = run_start; rec.end = qb; rec.minE = minE;
+                rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
+                rec.exitE = 0; rec.has_exit = 0;
+                emit_record(a.recs, a.rec_count, a.rec_cap, rec);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers (called from kgma_api.cpp)
+// ------------------------------------------------------------------------------------------
+size_t scan_lds_bytes(int k, int nk, int n_kfv)
+{
+    const size_t NW = KGMA_TILE_WORDS + scan_pad_words(nk);
+    const size_t NB = (size_t)1 << (2 * k);
+    return (2 * NW + (size_t)n_kfv * NB + NB + 16 + KGMA_THREADS) * 4 + (4 + KGMA_MAX_GROUP) * 8 + 64;
+}
+
+hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc *cd, int n_contigs,
+                       int64_t total_words, unsigned long long *first_bad, hipStream_t st)
+{
+    if (total_words <= 0) return hipSuccess;
+    int64_t blocks = (total_words + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ascii, planes, cd,
+                       n_contigs, total_words, first_bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int64_t total_words,
+                        uint64_t seed, hipStream_t st)
+{
+    if (total_words <= 0) return hipSuccess;
+    int64_t blocks = (total_words + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(synth_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ascii, cd, n_contigs,
+                       total_words, seed);
+    return hipGetLastError();
+}
+
+template <int K>
+static hipError_t launch_scan_k(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+{
+    const size_t lds = scan_lds_bytes(K, gp.nk, gp.n_kfv);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(scan_kernel<K>, dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+{
+    if (a.n_tiles <= 0) return hipSuccess;
+    switch (gp.k) {
+    case 2: return launch_scan_k<2>(a, gp, st);
+    case 3: return launch_scan_k<3>(a, gp, st);
+    case 4: return launch_scan_k<4>(a, gp, st);
+    case 5: return launch_scan_k<5>(a, gp, st);
+    case 6: return launch_scan_k<6>(a, gp, st);
+    case 7: return launch_scan_k<7>(a, gp, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace kgma

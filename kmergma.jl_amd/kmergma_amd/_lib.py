@@ -1,0 +1,288 @@
+"""ctypes binding of libkgma.so (the C ABI of include/kgma.h).
+
+This is what the Julia shim's `ccall`s mirror one to one.  The library is
+the product: if it is missing or no MI355X is present the calls fail loudly -- there is no CPU
+fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_DIR, "libkgma.so")
+
+KGMA_OK = 0
+KGMA_E_ARG, KGMA_E_NODEVICE, KGMA_E_HIP, KGMA_E_BADBASE, KGMA_E_BOUNDS = 1, 2, 3, 4, 5
+KGMA_E_UNSUPPORTED, KGMA_E_OVERFLOW, KGMA_E_NOMEM, KGMA_E_STATE = 6, 7, 8, 9
+MODE_SINGLE, MODE_OMN = 0, 1
+F_RETURN_DISTS = 1
+HIT_TIE, HIT_AT_THRESHOLD = 1, 2
+
+EXPORTS = [
+    "kgma_version", "kgma_status_string", "kgma_last_error", "kgma_create", "kgma_destroy",
+    "kgma_set_refs", "kgma_set_thresholds", "kgma_genome_from_host", "kgma_genome_synthetic",
+    "kgma_genome_fetch", "kgma_genome_num_contigs", "kgma_genome_contig_len", "kgma_genome_total_bases",
+    "kgma_genome_free", "kgma_genome_repack", "kgma_scan", "kgma_scan_device", "kgma_get_hits",
+    "kgma_get_dips", "kgma_get_first_window", "kgma_get_dists", "kgma_get_stats", "kgma_stream",
+]
+
+
+class KgmaHit(C.Structure):
+    _fields_ = [("contig", C.c_int32), ("kfv", C.c_int32), ("cmi", C.c_int64), ("lo", C.c_int64),
+                ("hi", C.c_int64), ("genome_pos", C.c_int64), ("dist", C.c_double), ("D", C.c_int64),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class KgmaDip(C.Structure):
+    _fields_ = [("contig", C.c_int32), ("kfv", C.c_int32), ("start", C.c_int64), ("end", C.c_int64),
+                ("argmin", C.c_int64), ("D_min", C.c_int64), ("exit_pos", C.c_int64), ("D_exit", C.c_int64),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class KgmaStats(C.Structure):
+    _fields_ = [("bases_scanned", C.c_int64), ("windows_scanned", C.c_int64), ("n_dips", C.c_int64),
+                ("n_hits", C.c_int64), ("n_tie_flagged", C.c_int64), ("n_at_threshold", C.c_int64),
+                ("pack_ms", C.c_double), ("scan_ms", C.c_double), ("replay_ms", C.c_double),
+                ("device_bytes", C.c_int64), ("n_tiles", C.c_int32), ("n_launches", C.c_int32)]
+
+
+ALIGN_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
+                       C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+
+
+class KgmaError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libkgma status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+class BadBaseError(KgmaError, KeyError):
+    """KGMA_E_BADBASE: the reference raises KeyError from NUCLEOTIDE_BITS (src/Consts.jl:22-28)."""
+
+
+class RecordBoundsError(KgmaError, IndexError):
+    """KGMA_E_BOUNDS: BoundsError in the reference (src/OmnGenomeMiner.jl:84-86)."""
+
+
+_lib = None
+
+
+def load():
+    """Load libkgma.so; raises (never falls back) when the extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `make -C kmergma.jl_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
+    P = C.POINTER
+    L.kgma_version.restype = C.c_int
+    L.kgma_status_string.restype = C.c_char_p
+    L.kgma_status_string.argtypes = [C.c_int]
+    L.kgma_last_error.restype = C.c_char_p
+    L.kgma_last_error.argtypes = [vp]
+    L.kgma_create.argtypes = [C.c_int, P(vp)]
+    L.kgma_destroy.argtypes = [vp]
+    L.kgma_destroy.restype = None
+    L.kgma_set_refs.argtypes = [vp, i32, i32, P(dbl), P(i64), P(dbl), P(i64)]
+    L.kgma_set_thresholds.argtypes = [vp, P(dbl)]
+    L.kgma_genome_from_host.argtypes = [vp, P(C.c_char_p), P(i64), i64, P(vp)]
+    L.kgma_genome_synthetic.argtypes = [vp, P(i64), i64, u64, C.c_char_p, i64, P(i64), P(i64), i64, P(vp)]
+    L.kgma_genome_fetch.argtypes = [vp, vp, i64, i64, i64, C.c_char_p]
+    L.kgma_genome_num_contigs.argtypes = [vp]
+    L.kgma_genome_num_contigs.restype = i64
+    L.kgma_genome_contig_len.argtypes = [vp, i64]
+    L.kgma_genome_contig_len.restype = i64
+    L.kgma_genome_total_bases.argtypes = [vp]
+    L.kgma_genome_total_bases.restype = i64
+    L.kgma_genome_free.argtypes = [vp, vp]
+    L.kgma_genome_free.restype = None
+    L.kgma_genome_repack.argtypes = [vp, vp]
+    L.kgma_scan.argtypes = [vp, vp, i32, i64, i64, u32, ALIGN_FN, vp]
+    L.kgma_scan_device.argtypes = [vp, vp, i32, u32]
+    L.kgma_get_hits.argtypes = [vp, P(KgmaHit), i64, P(i64)]
+    L.kgma_get_dips.argtypes = [vp, P(KgmaDip), i64, P(i64)]
+    L.kgma_get_first_window.argtypes = [vp, i32, P(i64), i64, P(i64)]
+    L.kgma_get_dists.argtypes = [vp, i32, P(dbl), i64, P(i64)]
+    L.kgma_get_stats.argtypes = [vp, P(KgmaStats)]
+    L.kgma_stream.argtypes = [vp]
+    L.kgma_stream.restype = vp
+    _lib = L
+    return L
+
+
+def _np_ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Genome:
+    """Device-resident genome (two bit-planes + the ASCII residues)."""
+
+    def __init__(self, ctx: "Context", handle):
+        self._ctx = ctx
+        self._h = handle
+
+    @property
+    def n_contigs(self) -> int:
+        return int(load().kgma_genome_num_contigs(self._h))
+
+    def contig_len(self, c: int) -> int:
+        return int(load().kgma_genome_contig_len(self._h, c))
+
+    @property
+    def total_bases(self) -> int:
+        return int(load().kgma_genome_total_bases(self._h))
+
+    def fetch(self, contig: int, pos: int, length: int) -> bytes:
+        buf = C.create_string_buffer(max(length, 1))
+        self._ctx._check(load().kgma_genome_fetch(self._ctx._h, self._h, contig, pos, length, buf))
+        return buf.raw[:length]
+
+    def repack(self) -> None:
+        self._ctx._check(load().kgma_genome_repack(self._ctx._h, self._h))
+
+    def free(self) -> None:
+        if self._h is not None:
+            load().kgma_genome_free(self._ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            if self._ctx._h is not None:
+                self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One libkgma context = one GPU."""
+
+    def __init__(self, device: int = 0):
+        L = load()
+        h = C.c_void_p()
+        st = L.kgma_create(device, C.byref(h))
+        if st != KGMA_OK:
+            raise KgmaError(st, L.kgma_status_string(st).decode())
+        self._h = h
+        self.k = 0
+        self.m = 0
+
+    def close(self) -> None:
+        if self._h is not None:
+            load().kgma_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st: int) -> None:
+        if st == KGMA_OK:
+            return
+        msg = load().kgma_last_error(self._h).decode()
+        if st == KGMA_E_BADBASE:
+            raise BadBaseError(st, msg)
+        if st == KGMA_E_BOUNDS:
+            raise RecordBoundsError(st, msg)
+        raise KgmaError(st, msg)
+
+    def set_refs(self, k: int, refs: Sequence[np.ndarray], windowsizes: Sequence[int], thr: Sequence[float],
+                 n_refs: Optional[Sequence[int]] = None) -> None:
+        m = len(windowsizes)
+        R = np.ascontiguousarray(np.stack([np.asarray(r, dtype=np.float64) for r in refs[:m]]))
+        if R.shape[1] != 4 ** k:
+            raise ValueError(f"KFV length {R.shape[1]} != 4^{k}")
+        ws = np.asarray(windowsizes, dtype=np.int64)
+        th = np.asarray(list(thr)[:m], dtype=np.float64)
+        if th.size != m:
+            raise ValueError("need one threshold per KFV")
+        nr = None if n_refs is None else np.asarray(n_refs, dtype=np.int64)
+        self._check(load().kgma_set_refs(self._h, k, m, _np_ptr(R, C.c_double), _np_ptr(ws, C.c_int64),
+                                         _np_ptr(th, C.c_double), None if nr is None else _np_ptr(nr, C.c_int64)))
+        self.k, self.m = k, m
+
+    def set_thresholds(self, thr: Sequence[float]) -> None:
+        th = np.asarray(list(thr)[:self.m], dtype=np.float64)
+        self._check(load().kgma_set_thresholds(self._h, _np_ptr(th, C.c_double)))
+
+    def genome_from_host(self, contigs: Sequence[bytes]) -> Genome:
+        n = len(contigs)
+        arr = (C.c_char_p * max(n, 1))(*[bytes(c) for c in contigs])
+        lens = np.asarray([len(c) for c in contigs], dtype=np.int64)
+        h = C.c_void_p()
+        self._check(load().kgma_genome_from_host(self._h, arr, _np_ptr(lens, C.c_int64) if n else None, n, C.byref(h)))
+        return Genome(self, h)
+
+    def genome_synthetic(self, contig_lens: Sequence[int], seed: int, plant: bytes = b"",
+                         plants: Sequence = ()) -> Genome:
+        lens = np.asarray(contig_lens, dtype=np.int64)
+        pc = np.asarray([p[0] for p in plants], dtype=np.int64)
+        pp = np.asarray([p[1] for p in plants], dtype=np.int64)
+        h = C.c_void_p()
+        self._check(load().kgma_genome_synthetic(
+            self._h, _np_ptr(lens, C.c_int64), lens.size, C.c_uint64(seed & (2 ** 64 - 1)), plant if plants else None,
+            len(plant), _np_ptr(pc, C.c_int64) if len(plants) else None, _np_ptr(pp, C.c_int64) if len(plants) else None,
+            len(plants), C.byref(h)))
+        return Genome(self, h)
+
+    def scan(self, genome: Genome, mode: int, buff: int = 50, genome_pos: int = 0, flags: int = 0,
+             align: Optional[Callable] = None) -> None:
+        if align is None:
+            cb = C.cast(None, ALIGN_FN)
+        else:
+            def tramp(_u, contig, kfv, lo, hi, L, plo, phi):
+                nlo, nhi = align(int(contig), int(kfv), int(lo), int(hi), int(L))
+                plo[0], phi[0] = int(nlo), int(nhi)
+            cb = ALIGN_FN(tramp)
+        self._check(load().kgma_scan(self._h, genome._h, mode, buff, genome_pos, flags, cb, None))
+
+    def scan_device(self, genome: Genome, mode: int, flags: int = 0) -> None:
+        self._check(load().kgma_scan_device(self._h, genome._h, mode, flags))
+
+    def hits(self) -> List[dict]:
+        n = C.c_int64(0)
+        self._check(load().kgma_get_hits(self._h, None, 0, C.byref(n)))
+        arr = (KgmaHit * max(n.value, 1))()
+        self._check(load().kgma_get_hits(self._h, arr, n.value, C.byref(n)))
+        return [dict(contig=h.contig, kfv=h.kfv, cmi=h.cmi, lo=h.lo, hi=h.hi, genome_pos=h.genome_pos,
+                     dist=h.dist, D=h.D, flags=h.flags) for h in arr[:n.value]]
+
+    def dips(self) -> List[dict]:
+        n = C.c_int64(0)
+        self._check(load().kgma_get_dips(self._h, None, 0, C.byref(n)))
+        arr = (KgmaDip * max(n.value, 1))()
+        self._check(load().kgma_get_dips(self._h, arr, n.value, C.byref(n)))
+        return [dict(contig=d.contig, kfv=d.kfv, start=d.start, end=d.end, argmin=d.argmin, D_min=d.D_min,
+                     exit_pos=d.exit_pos, D_exit=d.D_exit, flags=d.flags) for d in arr[:n.value]]
+
+    def first_window(self, kfv: int = 1) -> np.ndarray:
+        n = C.c_int64(0)
+        self._check(load().kgma_get_first_window(self._h, kfv, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.int64)
+        self._check(load().kgma_get_first_window(self._h, kfv, _np_ptr(out, C.c_int64), out.size, C.byref(n)))
+        return out[:n.value]
+
+    def dists(self, kfv: int = 1) -> np.ndarray:
+        n = C.c_int64(0)
+        self._check(load().kgma_get_dists(self._h, kfv, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.float64)
+        self._check(load().kgma_get_dists(self._h, kfv, _np_ptr(out, C.c_double), out.size, C.byref(n)))
+        return out[:n.value]
+
+    def stats(self) -> dict:
+        s = KgmaStats()
+        self._check(load().kgma_get_stats(self._h, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in KgmaStats._fields_}
+
+    @property
+    def stream(self) -> int:
+        return int(load().kgma_stream(self._h) or 0)
