@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- Mbp scanned / s of the sliding-window k-mer-distance scan (findGenes hot path).
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run, one rank per GPU.  One step = one pass of the hot path over the rank's
+resident synthetic genome: ASCII -> bit-plane pack kernel, scan kernel, record download and the
+host hit state machine (kgma_scan), plus -- for N > 1 only -- the RCCL gather of the hit records
+on rank 0.  Inputs (the ASCII genome) are resident in HBM before the timed region starts.
+
+Workload (BASELINE.json configs[1]): findGenes k=6, one reference cluster (the reference's alpaca
+IGHV fixture, 84 genes, W=289) against a chr22-size record (50 818 468 bases, synthetic: no real
+genome is available offline), thr=30, buff=50, do_align=false.  Weak scaling: every rank scans
+its own chr22-size record (records shard across GPUs).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "kmergma.jl_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ALGO_BYTES_PER_BASE = 0.25     # scan kernel reads the 2-bit genome once
+
+
+def cpu_baseline(ctx_genome_fetch, refs, length, thr, max_bases=50_818_468, reps=3):
+    """Times the CPU oracle (reference-order Float64 restatement, single thread) on the same record.
+    The oracle is the checker / baseline only; it is never on the product path."""
+    from oracle import oracle as orc
+    n = min(length, max_bases)
+    seq = ctx_genome_fetch(0, 1, n)
+    best = None
+    nh = 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        hits, _ = orc.single_scan([seq], refs["RV"], refs["k"], refs["ws"], thr, 50)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        nh = len(hits)
+    return n / best / 1e6, n, nh
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--length", type=int, default=0, help="record length per rank (default chr22-size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from kmergma_amd import _lib, parallel, workloads
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the scan")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    refs = workloads.fixture_refs(os.path.join(ROOT, "tests", "data"), 6)
+    thr = 30.0
+    length = args.length or workloads.CHR22_LEN
+    ctx = _lib.Context(local_rank)
+    ctx.set_refs(6, [refs["RV"]], [refs["ws"]], [thr], [refs["N"]])
+    genome, plants = workloads.make_chr22_like(ctx, refs["genes"], seed=22 + rank, length=length)
+    scale = 2.0 * 6 * refs["N"] ** 2
+
+    def step():
+        genome.repack()                                   # ASCII -> bit-planes (Kmers.jl encoding)
+        ctx.scan(genome, _lib.MODE_SINGLE, 50, 0, 0, None)   # scan kernel + dips + hit state machine
+        st = ctx.stats()
+        hits = ctx.hits()
+        if world > 1:
+            hits = parallel.gather_hits(hits, rank, parallel.genome_pos_advance([length], True, refs["ws"]),
+                                        lambda kfv: scale, device=dev)
+        return st, hits
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    scan_ms, pack_ms = [], []
+    hits = []
+    for _ in range(args.steps):
+        st, hits = step()
+        scan_ms.append(st["scan_ms"])
+        pack_ms.append(st["pack_ms"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_bases = length * world
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = total_bases * args.steps / elapsed / 1e6
+        avg_scan_ms = sum(scan_ms) / len(scan_ms)          # hipEvents on the library's stream
+        achieved = ALGO_BYTES_PER_BASE * length / (avg_scan_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mbp scanned/sec (whole node) at k=6, 1 ref cluster", "value": round(value, 1),
+            "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "findGenes k=6, 84-gene alpaca IGHV fixture KFV (W=289, thr=30, buff=50, "
+                                   "do_align=false) vs chr22-size synthetic record (%d bases per GPU); "
+                                   "step = pack + scan + hit replay%s" % (length, " + RCCL hit gather" if world > 1 else ""),
+                       "k": 6, "windowsize": int(refs["ws"]), "n_ref_clusters": 1, "bases_per_gpu": length,
+                       "n_hits": len(hits), "n_planted": len(plants), "sharding": "records across GPUs"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "kernel": "scan_kernel<6>", "kernel_ms": round(avg_scan_ms, 4),
+                         "pack_kernel_ms": round(sum(pack_ms) / len(pack_ms), 4),
+                         "algorithmic_bytes": ALGO_BYTES_PER_BASE * length,
+                         "scan_only_Gbp_s": round(length / avg_scan_ms / 1e6, 2),
+                         "note": "VALU-issue bound, not HBM bound: see DESIGN.md (lane-ops roofline)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            v, n, nh = cpu_baseline(genome.fetch, refs, length, thr)
+            out["cpu_baseline"] = {"value": round(v, 2), "unit": "Mbp/s", "cores": 1, "kind": "port",
+                                   "sample": "CPU oracle (reference-order Float64 restatement of GenomeMiner.jl) on "
+                                             "the same record, first %d bases, best of 3, %d hits" % (n, nh),
+                                   "published_reference": "README.md:50: ~40 Mbp/s (Julia, hardware not stated)"}
+        print(json.dumps(out), flush=True)
+    genome.free()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

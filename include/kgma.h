@@ -165,7 +165,13 @@ int64_t kgma_genome_contig_len(const kgma_genome *g, int64_t contig);
 int64_t kgma_genome_total_bases(const kgma_genome *g);
 void kgma_genome_free(kgma_ctx *ctx, kgma_genome *g);
 
-/* Re-run only the ASCII -> bit-plane pack kernel of a resident genome (benchmarks). */
+/* Overwrite `len` ASCII residues of record `contig` starting at 1-based `pos` with host bytes
+ * (used to plant genes / runs of N in synthetic genomes).  Call kgma_genome_repack afterwards. */
+int kgma_genome_poke(kgma_ctx *ctx, kgma_genome *g, int64_t contig, int64_t pos, int64_t len,
+                     const uint8_t *bytes);
+
+/* Re-run the ASCII -> bit-plane pack kernel of a resident genome (after kgma_genome_poke, and in
+ * benchmarks that time pack + scan). */
 int kgma_genome_repack(kgma_ctx *ctx, kgma_genome *g);
 
 /* Scan every record of `g`.  mode: KGMA_MODE_*.  buff: `buff`.  genome_pos0: the cluster

@@ -509,6 +509,17 @@ int kgma_genome_fetch(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int64
     return KGMA_OK;
 }
 
+int kgma_genome_poke(kgma_ctx *ctx, kgma_genome *g, int64_t contig, int64_t pos, int64_t len, const uint8_t *bytes)
+{
+    if (!ctx || !g) return KGMA_E_ARG;
+    if (contig < 0 || contig >= g->n_contigs || pos < 1 || len < 0 || pos + len - 1 > g->cd[(size_t)contig].len || (!bytes && len > 0))
+        return fail(ctx, KGMA_E_ARG, "kgma_genome_poke: range outside the record");
+    if (len == 0) return KGMA_OK;
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipMemcpy(g->d_ascii + g->cd[(size_t)contig].ascii_off + (pos - 1), bytes, (size_t)len, hipMemcpyHostToDevice));
+    return KGMA_OK;
+}
+
 int64_t kgma_genome_num_contigs(const kgma_genome *g) { return g ? g->n_contigs : 0; }
 int64_t kgma_genome_contig_len(const kgma_genome *g, int64_t c)
 {

@@ -26,7 +26,7 @@ EXPORTS = [
     "kgma_version", "kgma_status_string", "kgma_last_error", "kgma_create", "kgma_destroy",
     "kgma_set_refs", "kgma_set_thresholds", "kgma_genome_from_host", "kgma_genome_synthetic",
     "kgma_genome_fetch", "kgma_genome_num_contigs", "kgma_genome_contig_len", "kgma_genome_total_bases",
-    "kgma_genome_free", "kgma_genome_repack", "kgma_scan", "kgma_scan_device", "kgma_get_hits",
+    "kgma_genome_free", "kgma_genome_repack", "kgma_genome_poke", "kgma_scan", "kgma_scan_device", "kgma_get_hits",
     "kgma_get_dips", "kgma_get_first_window", "kgma_get_dists", "kgma_get_stats", "kgma_stream",
 ]
 
@@ -105,6 +105,7 @@ def load():
     L.kgma_genome_free.argtypes = [vp, vp]
     L.kgma_genome_free.restype = None
     L.kgma_genome_repack.argtypes = [vp, vp]
+    L.kgma_genome_poke.argtypes = [vp, vp, i64, i64, i64, C.c_char_p]
     L.kgma_scan.argtypes = [vp, vp, i32, i64, i64, u32, ALIGN_FN, vp]
     L.kgma_scan_device.argtypes = [vp, vp, i32, u32]
     L.kgma_get_hits.argtypes = [vp, P(KgmaHit), i64, P(i64)]
@@ -144,6 +145,9 @@ class Genome:
         buf = C.create_string_buffer(max(length, 1))
         self._ctx._check(load().kgma_genome_fetch(self._ctx._h, self._h, contig, pos, length, buf))
         return buf.raw[:length]
+
+    def poke(self, contig: int, pos: int, data: bytes) -> None:
+        self._ctx._check(load().kgma_genome_poke(self._ctx._h, self._h, contig, pos, len(data), bytes(data)))
 
     def repack(self) -> None:
         self._ctx._check(load().kgma_genome_repack(self._ctx._h, self._h))

@@ -1,0 +1,298 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Integer / index results are compared bit-exactly; the distance value is compared with the
+reference-order Float64 oracle at 1e-6 relative (BASELINE.json north_star) and bit-exactly with
+the exact-integer oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from kmergma_amd import _lib, headers, refprep
+from oracle import oracle as orc
+from tests.helpers import hit_key, make_genome, random_dna
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6   # rolling distance tolerance stated by BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def genes(data_dir):
+    from kmergma_amd import fasta
+    return [r.sequence.upper() for r in fasta.read_fasta(os.path.join(data_dir, "Alp_V_ref.fasta"))]
+
+
+def _scan_single(ctx, contigs, ref, thr, buff=50, dists=False, align=None):
+    ctx.set_refs(ref["k"], [ref["RV"]], [ref["ws"]], [thr], [ref["N"]])
+    g = ctx.genome_from_host(contigs)
+    try:
+        ctx.scan(g, _lib.MODE_SINGLE, buff, 0, _lib.F_RETURN_DISTS if dists else 0, align)
+        return ctx.hits(), (ctx.dists(1) if dists else None), ctx.first_window(1), ctx.stats(), ctx.dips()
+    finally:
+        g.free()
+
+
+def _assert_single_parity(ctx, contigs, ref, thr, buff=50, align=None):
+    k, W, N, S = ref["k"], ref["ws"], ref["N"], ref["S"]
+    hits, d, D1, stats, dips = _scan_single(ctx, contigs, ref, thr, buff, dists=True, align=align)
+    # exact-integer oracle: everything bit-identical
+    T = orc.int_threshold(thr, k, N)
+    ohi, oD, oD1 = orc.single_scan_int(contigs, S, N, k, W, T, buff, return_D=True)
+    assert np.array_equal(D1, oD1)
+    assert np.array_equal(d, oD / (2.0 * k * N * N))
+    if align is None:
+        assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi]
+        assert [h["D"] for h in hits] == [h["D"] for h in ohi]
+    # reference-order Float64 oracle: coordinates identical (except where a dip's minimum is an
+    # exact tie that Float64 rounding noise breaks -- flagged by the device), distances within tol
+    ohits, od = orc.single_scan(contigs, ref["RV"], k, W, thr, buff, return_dists=True, align=align)
+    assert len(od) == len(d)
+    if len(d):
+        assert np.max(np.abs(d - od) / np.maximum(od, 1e-300)) < REL_TOL
+    flagged = sum(1 for x in dips if x["flags"])
+    if [hit_key(h) for h in hits] != [hit_key(h) for h in ohits]:
+        assert flagged > 0, "hits differ from the Float64 oracle although no dip was flagged ambiguous"
+        assert len(hits) == len(ohits)
+        for a, b in zip(hits, ohits):
+            if hit_key(a) != hit_key(b):
+                assert a["flags"] != 0
+    for a, b in zip(hits, ohits):
+        if hit_key(a) == hit_key(b):
+            assert abs(a["dist"] - b["dist"]) <= REL_TOL * max(b["dist"], 1e-300)
+    return hits, stats
+
+
+def test_golden_single_no_align(ctx, golden, alp_ref, loci):
+    g = golden["scan"]["single_no_align"]
+    hits, *_ = _scan_single(ctx, [r.sequence for r in loci], alp_ref, g["thr"], g["buff"])
+    assert len(hits) == g["n_hits"]
+    for idx, expected in g["headers"].items():
+        h = hits[int(idx) - 1]
+        assert headers.single_header(loci[h["contig"]].identifier, h["dist"], h["lo"], h["hi"], h["genome_pos"]) == expected
+
+
+def test_golden_single_dists(ctx, golden, alp_ref, loci):
+    g = golden["scan"]["single_dists"]
+    hits, d, *_ = _scan_single(ctx, [r.sequence for r in loci], alp_ref, g["thr"], g["buff"], dists=True)
+    assert len(d) == g["n_dists"]
+    assert round(float(d.mean())) == g["round_mean"]
+    assert len(hits) == g["n_hits"]
+    first, last = hits[0], hits[-1]
+    assert headers.single_header(loci[first["contig"]].identifier, first["dist"], first["lo"], first["hi"], first["genome_pos"]) == g["headers"]["1"]
+    assert headers.single_header(loci[last["contig"]].identifier, last["dist"], last["lo"], last["hi"], last["genome_pos"]) == g["headers"]["3"]
+
+
+def test_fixture_full_parity(ctx, alp_ref, loci):
+    _assert_single_parity(ctx, [r.sequence for r in loci], alp_ref, 30.0)
+    _assert_single_parity(ctx, [r.sequence for r in loci], alp_ref, 10.0)
+
+
+def test_golden_omn_dist_kfv(ctx, golden, alp_clusters, alp_locus):
+    g = golden["scan"]["omn_buff200"]
+    c = alp_clusters
+    ctx.set_refs(6, c["KFVs"], c["ws"], g["thr_vec"][:len(c["ws"])], c["N"])
+    gen = ctx.genome_from_host([r.sequence for r in alp_locus])
+    ctx.scan(gen, _lib.MODE_OMN, g["buff"], 0, 0, None)
+    hits = ctx.hits()
+    gen.free()
+    assert [[headers.julia_round2(h["dist"]), h["kfv"]] for h in hits] == g["dist_kfv"]
+    assert [h["cmi"] for h in hits] == [6851, 23690, 33843]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_genomes_single(ctx, alp_ref, genes, seed):
+    rng = np.random.default_rng(seed)
+    W = alp_ref["ws"]
+    P = 32768
+    lengths = [W - 1, W, W + 1, 5, P + W - 1, P + W, P + W + 1, 2 * P + W + 17, 70001, 3 * P + 1000, 64]
+    contigs, plants = make_genome(rng, lengths, genes)
+    for thr in (22.0, 30.0, 38.5):
+        _assert_single_parity(ctx, contigs, alp_ref, thr, buff=50)
+
+
+def test_dip_across_tile_and_lane_boundaries(ctx, alp_ref, genes):
+    """Plant exact gene copies so that the dip straddles a tile boundary (32768 windows) and
+    lane boundaries (128 windows), including a dip that is still open at the record end."""
+    rng = np.random.default_rng(7)
+    W = alp_ref["ws"]
+    P = 32768
+    gene = genes[3][:W] if len(genes[3]) >= W else genes[3]
+    for off in (-300, -150, -20, -1, 0, 1, 40):
+        L = 2 * P + 4000
+        a = bytearray(random_dna(rng, L))
+        pos = P + off            # 0-based start of the planted copy -> window start pos+1
+        a[pos:pos + len(gene)] = gene
+        # second copy ending exactly at the record end: its dip stays open
+        a[L - len(gene):] = gene
+        # third copy at the very start: first window is under the threshold
+        a[:len(gene)] = gene
+        _assert_single_parity(ctx, [bytes(a)], alp_ref, 30.0)
+        _assert_single_parity(ctx, [bytes(a)], alp_ref, 45.0)   # huge dips (most windows under)
+
+
+def test_everything_under_threshold(ctx, alp_ref):
+    rng = np.random.default_rng(11)
+    contigs = [random_dna(rng, 40000), random_dna(rng, 700)]
+    _assert_single_parity(ctx, contigs, alp_ref, 1000.0)
+    _assert_single_parity(ctx, contigs, alp_ref, 0.0)
+
+
+def test_low_complexity_and_n_runs(ctx, alp_ref):
+    """Homopolymers / tandem repeats drive the self-match counters to their maximum (W-k)."""
+    rng = np.random.default_rng(5)
+    a = bytearray(random_dna(rng, 50000))
+    a[1000:3000] = b"A" * 2000
+    a[5000:7000] = b"AC" * 1000
+    a[9000:12000] = b"N" * 3000
+    a[20000:21000] = b"ACGTTGCA" * 125
+    a[30000:30289] = b"T" * 289
+    _assert_single_parity(ctx, [bytes(a)], alp_ref, 30.0)
+    _assert_single_parity(ctx, [bytes(a)], alp_ref, 60.0)
+
+
+def test_align_callback_single(ctx, alp_ref, genes):
+    rng = np.random.default_rng(21)
+    contigs, _ = make_genome(rng, [60000, 9000], genes, n_plants_per_mb=150)
+
+    def fake_align(contig, kfv, lo, hi, L):
+        return lo + 7, hi - 11
+
+    hits, _ = _assert_single_parity(ctx, contigs, alp_ref, 30.0, align=fake_align)
+    ohits, _ = orc.single_scan(contigs, alp_ref["RV"], 6, alp_ref["ws"], 30.0, 50, align=fake_align)
+    assert len(hits) > 0
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_random_genomes_omn(ctx, alp_clusters, genes, seed):
+    rng = np.random.default_rng(seed)
+    c = alp_clusters
+    k, ws = c["k"], c["ws"]
+    maxws = max(ws)
+    P = 32768
+    lengths = [maxws + k - 2, maxws + k - 1, maxws + k, 200, P + maxws + k - 2, P + maxws + k, 90011, 2 * P + 5000, 6]
+    contigs, _ = make_genome(rng, lengths, genes, n_plants_per_mb=120)
+    thr = [37, 33, 38, 34, 28]
+
+    def fake_align(contig, kfv, lo, hi, L):
+        return lo + 3 + kfv, hi - 5
+
+    for align in (None, fake_align):
+        for buff in (50, 200):
+            ctx.set_refs(k, c["KFVs"], ws, thr, c["N"])
+            gen = ctx.genome_from_host(contigs)
+            ctx.scan(gen, _lib.MODE_OMN, buff, 1234, _lib.F_RETURN_DISTS, align)
+            hits = ctx.hits()
+            dists = [ctx.dists(j + 1) for j in range(len(ws))]
+            dips = ctx.dips()
+            gen.free()
+            T = [orc.int_threshold(t, k, n) for t, n in zip(thr, c["N"])]
+            ohi, oD = orc.omn_scan_int(contigs, c["S"], c["N"], k, ws, T, buff, 1234, return_D=True, align=align)
+            assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi]
+            assert [h["D"] for h in hits] == [h["D"] for h in ohi]
+            for j in range(len(ws)):
+                assert np.array_equal(dists[j], oD[j] / (2.0 * k * c["N"][j] ** 2))
+            ohits, od = orc.omn_scan(contigs, c["KFVs"], k, ws, thr, buff, 1234, return_dists=True, align=align)
+            for j in range(len(ws)):
+                assert np.max(np.abs(dists[j] - od[j]) / od[j]) < REL_TOL
+            if [hit_key(h) for h in hits] != [hit_key(h) for h in ohits]:
+                assert any(x["flags"] for x in dips)
+
+
+def test_bad_base_errors(ctx, alp_ref, alp_clusters):
+    rng = np.random.default_rng(3)
+    W = alp_ref["ws"]
+    good = random_dna(rng, 2000)
+    bad = bytearray(random_dna(rng, 2000)); bad[777] = ord("R")
+    short_bad = bytearray(random_dna(rng, W - 1)); short_bad[5] = ord("-")
+    ctx.set_refs(6, [alp_ref["RV"]], [W], [30.0], [alp_ref["N"]])
+    # a short record is skipped before any lookup: no error (GenomeMiner.jl:37-39)
+    g = ctx.genome_from_host([good, bytes(short_bad)])
+    ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)
+    g.free()
+    g = ctx.genome_from_host([good, bytes(bad)])
+    with pytest.raises(_lib.BadBaseError) as e:
+        ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)
+    assert "record 1 position 778" in str(e.value)
+    g.free()
+    with pytest.raises(orc.OracleError) as oe:
+        orc.single_scan([good, bytes(bad)], alp_ref["RV"], 6, W, 30.0)
+    assert (oe.value.record, oe.value.position) == (1, 778)
+    # cluster engine: the last k-2 residues are never looked up (OmnGenomeMiner.jl:89,97)
+    c = alp_clusters
+    tail_bad = bytearray(random_dna(rng, 3000)); tail_bad[-1] = ord("Y"); tail_bad[-4] = ord("Y")
+    ctx.set_refs(6, c["KFVs"], c["ws"], [37, 33, 38, 34, 28], c["N"])
+    g = ctx.genome_from_host([bytes(tail_bad)])
+    ctx.scan(g, _lib.MODE_OMN, 50, 0, 0, None)
+    orc.omn_scan([bytes(tail_bad)], c["KFVs"], 6, c["ws"], [37, 33, 38, 34, 28], 50)
+    g.free()
+    tail_bad[-5] = ord("Y")
+    g = ctx.genome_from_host([bytes(tail_bad)])
+    with pytest.raises(_lib.BadBaseError):
+        ctx.scan(g, _lib.MODE_OMN, 50, 0, 0, None)
+    with pytest.raises(orc.OracleError):
+        orc.omn_scan([bytes(tail_bad)], c["KFVs"], 6, c["ws"], [37, 33, 38, 34, 28], 50)
+    g.free()
+    g = ctx.genome_from_host([b"ACG"])
+    with pytest.raises(_lib.RecordBoundsError):
+        ctx.scan(g, _lib.MODE_OMN, 50, 0, 0, None)
+    g.free()
+
+
+def test_other_k_values(ctx, data_dir, genes):
+    rng = np.random.default_rng(9)
+    tf = os.path.join(data_dir, "Alp_V_ref.fasta")
+    contigs, _ = make_genome(rng, [40000, 33100, 500], genes, n_plants_per_mb=200)
+    for k, thr in ((2, 300.0), (3, 200.0), (4, 120.0), (5, 60.0), (7, 25.0)):
+        RV, ws, cons, (S, N) = refprep.gen_ref_ws_cons(tf, k, return_int=True)
+        ref = dict(RV=RV, ws=ws, S=S, N=N, k=k)
+        _assert_single_parity(ctx, contigs, ref, thr)
+
+
+def test_empty_and_tiny_inputs(ctx, alp_ref):
+    ctx.set_refs(6, [alp_ref["RV"]], [alp_ref["ws"]], [30.0], [alp_ref["N"]])
+    g = ctx.genome_from_host([])
+    ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_RETURN_DISTS, None)
+    assert ctx.hits() == [] and len(ctx.dists(1)) == 0
+    g.free()
+    g = ctx.genome_from_host([b"", b"ACGT"])
+    ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)
+    assert ctx.hits() == []
+    g.free()
+
+
+def test_set_refs_errors(ctx, alp_ref):
+    with pytest.raises(_lib.KgmaError) as e:
+        ctx.set_refs(6, [alp_ref["RV"]], [6], [30.0], [alp_ref["N"]])   # k >= windowsize, API.jl:70
+    assert e.value.status == _lib.KGMA_E_ARG
+    with pytest.raises(_lib.KgmaError):
+        ctx.set_refs(6, [alp_ref["RV"] + 0.123456789], [289], [30.0], None)   # not S/N
+    # N inferred when n_refs is omitted
+    ctx.set_refs(6, [alp_ref["RV"]], [289], [30.0], None)
+
+
+def test_synthetic_generator_matches_host_model(ctx):
+    """kgma_genome_synthetic is the bench input: check it against a numpy restatement."""
+    lens = [1000, 77, 32 * 50]
+    seed = 22
+    g = ctx.genome_synthetic(lens, seed)
+    M = (1 << 64) - 1
+    for c, L in enumerate(lens):
+        out = bytearray()
+        for w in range((L + 31) // 32):
+            z = (seed + (c + 1) * 0xD1B54A32D192ED03 + (w + 1) * 0x9E3779B97F4A7C15) & M
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+            z ^= z >> 31
+            for i in range(32):
+                out.append(b"ACGT"[(z >> (2 * i)) & 3])
+        assert g.fetch(c, 1, L) == bytes(out[:L])
+    g.free()
