@@ -196,6 +196,15 @@ int kgma_get_dists(kgma_ctx *ctx, int32_t kfv, double *out, int64_t cap, int64_t
 
 int kgma_get_stats(kgma_ctx *ctx, kgma_stats *out);
 
+/* HOST-side helper (not on the device path; a Julia host keeps using BioAlignments.jl): semi-global
+ * affine-gap alignment of `a` (global; the consensus) against `b` (leading/trailing residues of b
+ * free), EDNAFULL scores, gap of length L scoring gap_open_score + L*gap_extend_score
+ * (AffineGapScoreModel, src/GenomeMiner.jl:28).  Writes the CIGAR text ('=','X','I','D') that
+ * cigar_to_UnitRange (src/Alignment.jl:13-30) consumes. */
+int kgma_host_semiglobal_cigar(const uint8_t *a, int64_t m, const uint8_t *b, int64_t n,
+                               int32_t gap_open_score, int32_t gap_extend_score, char *cigar,
+                               int64_t cigar_cap, int64_t *score_out);
+
 /* Host stream handle (hipStream_t) the context launches on, for callers that time with hipEvents. */
 void *kgma_stream(kgma_ctx *ctx);
 

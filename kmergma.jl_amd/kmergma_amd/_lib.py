@@ -28,6 +28,7 @@ EXPORTS = [
     "kgma_genome_fetch", "kgma_genome_num_contigs", "kgma_genome_contig_len", "kgma_genome_total_bases",
     "kgma_genome_free", "kgma_genome_repack", "kgma_genome_poke", "kgma_scan", "kgma_scan_device", "kgma_get_hits",
     "kgma_get_dips", "kgma_get_first_window", "kgma_get_dists", "kgma_get_stats", "kgma_stream",
+    "kgma_host_semiglobal_cigar",
 ]
 
 
@@ -113,6 +114,7 @@ def load():
     L.kgma_get_first_window.argtypes = [vp, i32, P(i64), i64, P(i64)]
     L.kgma_get_dists.argtypes = [vp, i32, P(dbl), i64, P(i64)]
     L.kgma_get_stats.argtypes = [vp, P(KgmaStats)]
+    L.kgma_host_semiglobal_cigar.argtypes = [C.c_char_p, i64, C.c_char_p, i64, i32, i32, C.c_char_p, i64, P(i64)]
     L.kgma_stream.argtypes = [vp]
     L.kgma_stream.restype = vp
     _lib = L

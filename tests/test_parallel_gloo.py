@@ -1,0 +1,74 @@
+"""Multi-GPU path on CPU: world_size-2 gloo run of the shard + gather logic (the scan itself needs
+a GPU, so ranks exchange synthetic hit records here; the RCCL path uses the same code with
+device tensors)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+from kmergma_amd import parallel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_contigs_balanced_and_contiguous():
+    lens = [248956422, 242193529, 198295559, 190214555, 181538259, 16569, 50818468, 57227415]
+    for world in (1, 2, 3, 4, 8):
+        shards = parallel.shard_contigs(lens, world)
+        assert shards[0][0] == 0 and shards[-1][1] == len(lens)
+        assert all(a[1] == b[0] for a, b in zip(shards, shards[1:]))
+    two = parallel.shard_contigs([10, 10, 10, 10], 2)
+    assert two == [(0, 2), (2, 4)]
+    assert parallel.shard_contigs([5], 4)[-1][1] == 1
+
+
+def test_genome_pos_advance_quirk():
+    # single engine skips short records (GenomeMiner.jl:37-39); cluster engine counts all (:159)
+    assert parallel.genome_pos_advance([100, 500, 50], True, 289) == 500
+    assert parallel.genome_pos_advance([100, 500, 50], False, 289) == 650
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "kmergma.jl_amd"))
+    import torch.distributed as dist
+    from kmergma_amd import parallel as par
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lens = [[1000, 200, 3000], [5000, 100]][rank]
+    begin = [0, 3][rank]
+    hits = [
+        [dict(contig=0, kfv=0, cmi=10, lo=1, hi=300, genome_pos=0, D=1000, flags=0),
+         dict(contig=2, kfv=0, cmi=77, lo=27, hi=416, genome_pos=1000, D=2000, flags=1)],
+        [dict(contig=0, kfv=0, cmi=5, lo=1, hi=295, genome_pos=0, D=3000, flags=0)],
+    ][rank]
+    adv = par.genome_pos_advance(lens, True, 289)
+    out = par.gather_hits(hits, begin, adv, lambda kfv: 84672.0)
+    if rank == 0:
+        q.put(out)
+    else:
+        assert out == []
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_hits_world2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [h["contig"] for h in out] == [0, 2, 3]
+    # rank 0 advanced genome_pos by 1000 + 3000 (the 200-base record is skipped by the single engine)
+    assert [h["genome_pos"] for h in out] == [0, 1000, 4000]
+    assert [h["cmi"] for h in out] == [10, 77, 5]
+    assert abs(out[2]["dist"] - 3000 / 84672.0) < 1e-15
+    assert out[1]["flags"] == 1
