@@ -1,0 +1,231 @@
+# KmerGMAHIP.jl -- Julia shim over libkgma (include/kgma.h): drop-in replacements for the two scan
+# engines of KmerGMA.jl with the SAME keyword signatures, so `findGenes` / `findGenes_cluster_mode`
+# (src/API.jl:83-94, :201-216) can call them instead of `ac_gma_testing!` / `Omn_KmerGMA!`.
+#
+# NOTE: Julia is not installed in the build container nor on the GPU box, so this file has never
+# been executed.  It is deliberately thin (marshalling only) and mirrors, call for call, the Python
+# ctypes host (kmergma_amd/_lib.py, kmergma_amd/api.py) that IS tested against the same library.
+#
+# What stays in Julia (exactly the reference's own code): FASTA parsing (FASTX), reference
+# preparation (gen_ref_ws_cons / cluster_ref_API), re-alignment of hits (BioAlignments.pairalign +
+# cigar_to_UnitRange) and FASTA.Record construction.  What moves to the GPU: the per-record body
+# of the engines (src/GenomeMiner.jl:32-107, src/OmnGenomeMiner.jl:55-160).
+
+module KmerGMAHIP
+
+using KmerGMA, FASTX, BioSequences, BioAlignments
+
+const libkgma = get(ENV, "KGMA_LIB", joinpath(@__DIR__, "..", "libkgma.so"))
+
+struct KgmaHit            # must match kgma_hit in include/kgma.h (64 bytes)
+    contig::Int32
+    kfv::Int32
+    cmi::Int64
+    lo::Int64
+    hi::Int64
+    genome_pos::Int64
+    dist::Float64
+    D::Int64
+    flags::UInt32
+    reserved::UInt32
+end
+
+const KGMA_MODE_SINGLE = Int32(0)
+const KGMA_MODE_OMN = Int32(1)
+const KGMA_F_RETURN_DISTS = UInt32(1)
+const KGMA_E_BADBASE = 4
+const KGMA_E_BOUNDS = 5
+
+mutable struct Context
+    h::Ptr{Cvoid}
+    function Context(device::Integer = 0)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        st = ccall((:kgma_create, libkgma), Cint, (Cint, Ref{Ptr{Cvoid}}), device, r)
+        st == 0 || error("kgma_create failed: " * unsafe_string(ccall((:kgma_status_string, libkgma), Cstring, (Cint,), st)))
+        ctx = new(r[])
+        finalizer(c -> (c.h == C_NULL || ccall((:kgma_destroy, libkgma), Cvoid, (Ptr{Cvoid},), c.h); c.h = C_NULL), ctx)
+        return ctx
+    end
+end
+
+const DEFAULT_CTX = Ref{Union{Nothing, Context}}(nothing)
+default_context() = (DEFAULT_CTX[] === nothing && (DEFAULT_CTX[] = Context(0)); DEFAULT_CTX[])
+
+function check(ctx::Context, st::Integer)
+    st == 0 && return
+    msg = unsafe_string(ccall((:kgma_last_error, libkgma), Cstring, (Ptr{Cvoid},), ctx.h))
+    st == KGMA_E_BADBASE && throw(KeyError(msg))        # NUCLEOTIDE_BITS lookup, src/Consts.jl:22-28
+    st == KGMA_E_BOUNDS && throw(BoundsError(msg))      # src/OmnGenomeMiner.jl:84-86
+    error("libkgma status $st: $msg")
+end
+
+# read the records exactly as the engines do (FASTX reader, getSeq) but keep the raw residue bytes
+function load_records(genome_path::String)
+    records = FASTA.Record[]
+    open(FASTA.Reader, genome_path) do reader
+        for record in reader; push!(records, record) end
+    end
+    return records
+end
+
+function upload_genome(ctx::Context, records::Vector{FASTA.Record})
+    seqs = [Vector{UInt8}(FASTA.sequence(String, r)) for r in records]   # raw residues, either case
+    ptrs = [pointer(s) for s in seqs]
+    lens = Int64[length(s) for s in seqs]
+    g = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve seqs begin
+        check(ctx, ccall((:kgma_genome_from_host, libkgma), Cint,
+            (Ptr{Cvoid}, Ptr{Ptr{UInt8}}, Ptr{Int64}, Int64, Ref{Ptr{Cvoid}}),
+            ctx.h, ptrs, lens, length(seqs), g))
+    end
+    return g[]
+end
+
+function fetch_hits(ctx::Context)
+    n = Ref{Int64}(0)
+    check(ctx, ccall((:kgma_get_hits, libkgma), Cint, (Ptr{Cvoid}, Ptr{KgmaHit}, Int64, Ref{Int64}), ctx.h, C_NULL, 0, n))
+    hits = Vector{KgmaHit}(undef, n[])
+    check(ctx, ccall((:kgma_get_hits, libkgma), Cint, (Ptr{Cvoid}, Ptr{KgmaHit}, Int64, Ref{Int64}), ctx.h, hits, n[], n))
+    return hits
+end
+
+function fetch_dists!(ctx::Context, kfv::Integer, dist_vec)
+    n = Ref{Int64}(0)
+    check(ctx, ccall((:kgma_get_dists, libkgma), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Ref{Int64}), ctx.h, kfv, C_NULL, 0, n))
+    buf = Vector{Float64}(undef, n[])
+    check(ctx, ccall((:kgma_get_dists, libkgma), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Ref{Int64}), ctx.h, kfv, buf, n[], n))
+    append!(dist_vec, buf)
+end
+
+# alignment callback: the library calls this in reference order with the candidate range and
+# expects the aligned range back (Alignment.jl:33-52 / OmnGenomeMiner.jl:130-136).
+mutable struct AlignState
+    seqs::Vector{KmerGMA.Seq}
+    consensus::Vector{KmerGMA.Seq}
+    windowsize::Int            # > 0: single engine (view(consensus, 1:windowsize)); 0: cluster engine
+    score_model
+    keep::Bool
+    out::Vector
+end
+
+function align_trampoline(user::Ptr{Cvoid}, contig::Int32, kfv::Int32, lo::Int64, hi::Int64, L::Int64,
+                          out_lo::Ptr{Int64}, out_hi::Ptr{Int64})::Cvoid
+    st = unsafe_pointer_to_objref(user)::AlignState
+    seq = st.seqs[contig + 1]
+    cons = kfv == 0 ? view(st.consensus[1], 1:st.windowsize) : st.consensus[kfv]
+    aligned_obj = pairalign(SemiGlobalAlignment(), cons, view(seq, lo:hi), st.score_model)
+    st.keep && push!(st.out, aligned_obj)
+    r = cigar_to_UnitRange(aligned_obj)
+    unsafe_store!(out_lo, max(1, lo + first(r) - 1))
+    unsafe_store!(out_hi, min(lo + last(r) - 1, L))
+    return
+end
+
+"""
+    ac_gma_testing!(; kwargs...)   -- same keywords as KmerGMA.ac_gma_testing! (src/GenomeMiner.jl:4-23)
+plus `n_refs` (number of reference sequences averaged into refVec; inferred when omitted).
+"""
+function ac_gma_testing!(; genome_path::String, refVec::Vector{Float64}, consensus_refseq::KmerGMA.Seq,
+    k::Int64 = 6, windowsize::Int64 = 289, thr::Union{Int64, Float64} = 33.5, buff::Int64 = 50,
+    mask::UInt64 = unsigned(4095), Nt_bits = NUCLEOTIDE_BITS, ScaleFactor::Float64 = 1/6,
+    do_align::Bool = true, result_align_vec = [], gap_open_score::Int = -69, gap_extend_score::Int = -1,
+    do_return_dists::Bool = false, dist_vec = Float64[], do_return_align::Bool = false,
+    get_hit_loci::Bool = false, hit_loci_vec::Vector{Int} = Int[],
+    resultVec::Vector{FASTA.Record} = FASTA.Record[], n_refs::Union{Nothing, Int} = nothing,
+    ctx::Context = default_context())
+
+    mask == unsigned(4^k - 1) || error("mask must be 4^k - 1")
+    records = load_records(genome_path)
+    nref = n_refs === nothing ? C_NULL : Int64[n_refs]
+    check(ctx, ccall((:kgma_set_refs, libkgma), Cint,
+        (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}),
+        ctx.h, k, 1, refVec, Int64[windowsize], Float64[thr], nref))
+    g = upload_genome(ctx, records)
+    try
+        seqs = do_align ? [getSeq(r) for r in records] : KmerGMA.Seq[]
+        st = AlignState(seqs, [consensus_refseq], windowsize,
+            AffineGapScoreModel(EDNAFULL, gap_open = gap_open_score, gap_extend = gap_extend_score),
+            do_return_align, result_align_vec)
+        cb = do_align ? @cfunction(align_trampoline, Cvoid,
+            (Ptr{Cvoid}, Int32, Int32, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64})) : C_NULL
+        GC.@preserve st begin
+            check(ctx, ccall((:kgma_scan, libkgma), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int64, Int64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}),
+                ctx.h, g, KGMA_MODE_SINGLE, buff, 0, do_return_dists ? KGMA_F_RETURN_DISTS : UInt32(0),
+                cb, pointer_from_objref(st)))
+        end
+        for h in fetch_hits(ctx)
+            record = records[h.contig + 1]
+            seq = getSeq(record)
+            # the reference's own record builder (src/Alignment.jl:57-81)
+            append_hit!(resultVec, record, seq, false, 0, h.dist, Int(h.lo):Int(h.hi), Int(h.genome_pos))
+            get_hit_loci && push!(hit_loci_vec, h.lo + h.genome_pos)
+        end
+        do_return_dists && fetch_dists!(ctx, 1, dist_vec)
+    finally
+        ccall((:kgma_genome_free, libkgma), Cvoid, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.h, g)
+    end
+    return nothing
+end
+
+"""
+    Omn_KmerGMA!(; kwargs...)   -- same keywords as KmerGMA.Omn_KmerGMA! (src/OmnGenomeMiner.jl:7-30)
+plus `n_refs::Vector{Int}` (reference count per cluster).
+"""
+function Omn_KmerGMA!(; genome_path::String, refVecs::Vector{Vector{Float64}}, windowsizes::Vector{Int64},
+    consensus_seqs::Vector{KmerGMA.Seq}, resultVec::Vector{FASTA.Record}, k::Int64 = 6, ScaleFactor::Real = 1/6,
+    mask::UInt64 = unsigned(4095), thr_vec = Float64[35, 31, 38, 34, 27, 27], buff::Int64 = 50,
+    Nt_bits = NUCLEOTIDE_BITS, align_hits::Bool = true, align_vec = [], gap_open_score::Int = -200,
+    gap_extend_score::Int = -1, genome_pos::Int64 = 0, get_hit_loci::Bool = false,
+    hit_loci_vec::Vector{Int} = Int[], get_aligns::Bool = false, do_return_dists::Bool = false,
+    dist_vec_vec::Vector{Vector{Float64}} = [Float64[] for _ in 1:6],
+    n_refs::Union{Nothing, Vector{Int}} = nothing, ctx::Context = default_context())
+
+    m = length(windowsizes)
+    records = load_records(genome_path)
+    refmat = reduce(vcat, refVecs[1:m])                  # m x 4^k, row-major as the C side expects
+    nref = n_refs === nothing ? C_NULL : Int64.(n_refs)
+    check(ctx, ccall((:kgma_set_refs, libkgma), Cint,
+        (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}),
+        ctx.h, k, m, refmat, Int64.(windowsizes), Float64.(thr_vec[1:m]), nref))
+    g = upload_genome(ctx, records)
+    try
+        seqs = align_hits ? [getSeq(r) for r in records] : KmerGMA.Seq[]
+        st = AlignState(seqs, consensus_seqs, 0,
+            AffineGapScoreModel(EDNAFULL, gap_open = gap_open_score, gap_extend = gap_extend_score),
+            get_aligns, align_vec)
+        cb = align_hits ? @cfunction(align_trampoline, Cvoid,
+            (Ptr{Cvoid}, Int32, Int32, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64})) : C_NULL
+        GC.@preserve st begin
+            check(ctx, ccall((:kgma_scan, libkgma), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int64, Int64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}),
+                ctx.h, g, KGMA_MODE_OMN, buff, genome_pos, do_return_dists ? KGMA_F_RETURN_DISTS : UInt32(0),
+                cb, pointer_from_objref(st)))
+        end
+        for h in fetch_hits(ctx)
+            record = records[h.contig + 1]
+            seq = getSeq(record)
+            seq_UnitRange = Int(h.lo):Int(h.hi)
+            # record construction as in src/OmnGenomeMiner.jl:141-149
+            push!(resultVec, FASTA.Record(
+                FASTA.identifier(record) *
+                    " | Dist = " * string(round(h.dist, digits = 2)) *
+                    " | KFV = $(h.kfv)" *
+                    " | MatchPos = $seq_UnitRange" *
+                    " | GenomePos = $(h.genome_pos)" *
+                    " | Len = " * string(last(seq_UnitRange) - first(seq_UnitRange) + 1),
+                view(seq, seq_UnitRange)))
+            get_hit_loci && push!(hit_loci_vec, first(seq_UnitRange) + h.genome_pos)
+        end
+        if do_return_dists
+            for j in 1:m; fetch_dists!(ctx, j, dist_vec_vec[j]) end
+        end
+    finally
+        ccall((:kgma_genome_free, libkgma), Cvoid, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.h, g)
+    end
+    return nothing
+end
+
+export ac_gma_testing!, Omn_KmerGMA!, Context
+
+end # module
