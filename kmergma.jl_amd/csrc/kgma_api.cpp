@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -40,7 +41,9 @@ hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc 
                        int64_t total_words, unsigned long long *first_bad, hipStream_t st);
 hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int64_t total_words,
                         uint64_t seed, hipStream_t st);
-hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
+hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, int version, hipStream_t st);
+int scan_tile_stride_words(int version, int nk);
+int scan_nblocks(int version, int nk);
 }  // namespace kgma
 
 using namespace kgma;
@@ -48,6 +51,7 @@ using namespace kgma;
 namespace {
 
 constexpr int64_t CONTIG_PAD_WORDS = 32;
+constexpr int64_t LEAD_PAD_WORDS = 8;
 constexpr int64_t TAIL_PAD_WORDS = KGMA_TILE_WORDS + 64;
 constexpr unsigned long long NO_BAD = ~0ull;
 
@@ -73,7 +77,9 @@ struct kgma_genome {
     int64_t total_words = 0;      // plane words incl. padding
     int64_t ascii_bytes = 0;
     std::vector<ContigDesc> cd;
-    std::vector<unsigned long long> first_bad;
+    unsigned long long *first_bad = nullptr;   // pinned host copy, valid once pack_pending is cleared
+    bool pack_pending = false;
+    uint64_t uid = 0;
     uint8_t *d_ascii = nullptr;
     uint32_t *d_planes = nullptr;
     ContigDesc *d_cd = nullptr;
@@ -84,10 +90,15 @@ struct kgma_genome {
 struct kgma_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evp0 = nullptr, evp1 = nullptr;
     std::string err;
+    uint8_t *h_pin = nullptr; size_t h_pin_cap = 0;     // pinned result staging
+    uint64_t next_uid = 1;
+    // key of the tile table currently on the device
+    uint64_t tk_uid = 0; int tk_mode = -1, tk_version = 0, tk_k = 0; int64_t tk_maxws = 0;
     // references
     int k = 0, m = 0;
+    int kernel_version = 3;
     std::vector<KfvInfo> kfv;
     int32_t *d_Stab = nullptr;        // m x 4^k, plane-index order
     // scan scratch
@@ -103,11 +114,14 @@ struct kgma_ctx {
     std::vector<TileDesc> tiles;
     std::vector<int64_t> contig_tile_base;   // per contig: index of its first tile or -1
     std::vector<int64_t> contig_nwin;        // evaluated windows per contig (0 = skipped)
+    std::vector<int64_t> contig_looked;      // last residue the reference looks up (-1: BoundsError)
+    int64_t tk_bases = 0, tk_windows = 0;
     std::vector<int64_t> D0;                 // [m][n_tiles] (slot = kfv index)
     std::vector<kgma_dip> dips;
     std::vector<kgma_hit> hits;
     std::vector<int64_t> contig_len;
     int64_t n_dists_per_kfv = 0;
+    int64_t tile_windows = KGMA_TILE_WINDOWS;
     bool have_dists = false;
     kgma_stats stats{};
     int64_t device_bytes = 0;
@@ -241,8 +255,10 @@ int kgma_create(int device_ordinal, kgma_ctx **out)
     kgma_ctx *ctx = new (std::nothrow) kgma_ctx();
     if (!ctx) return KGMA_E_NOMEM;
     ctx->device = device_ordinal;
+    if (const char *kv = getenv("KGMA_KERNEL")) { const int v = atoi(kv); if (v >= 1 && v <= 3) ctx->kernel_version = v; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipEventCreate(&ctx->evp0) != hipSuccess || hipEventCreate(&ctx->evp1) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&ctx->d_rec_count), sizeof(unsigned int)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&ctx->d_n_att), sizeof(unsigned long long)) != hipSuccess) {
         kgma_destroy(ctx);
@@ -264,6 +280,9 @@ void kgma_destroy(kgma_ctx *ctx)
     if (ctx->d_recs) (void)hipFree(ctx->d_recs);
     if (ctx->d_rec_count) (void)hipFree(ctx->d_rec_count);
     if (ctx->d_n_att) (void)hipFree(ctx->d_n_att);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->evp0) (void)hipEventDestroy(ctx->evp0);
+    if (ctx->evp1) (void)hipEventDestroy(ctx->evp1);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -354,6 +373,7 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
     ctx->d_dist.assign((size_t)m, nullptr);
     ctx->dist_cap.assign((size_t)m, 0);
     ctx->last_mode = -1;
+    ctx->tk_uid = 0;
     return KGMA_OK;
 }
 
@@ -364,7 +384,7 @@ static int genome_layout(kgma_ctx *ctx, kgma_genome *g, const int64_t *contig_le
 {
     g->n_contigs = n_contigs;
     g->cd.resize((size_t)n_contigs);
-    int64_t aoff = 0, woff = 0, total = 0;
+    int64_t aoff = 0, woff = LEAD_PAD_WORDS, total = 0;
     for (int64_t c = 0; c < n_contigs; c++) {
         const int64_t L = contig_len[c];
         if (L < 0) return fail(ctx, KGMA_E_ARG, "contig_len[%lld] < 0", (long long)c);
@@ -381,9 +401,23 @@ static int genome_layout(kgma_ctx *ctx, kgma_genome *g, const int64_t *contig_le
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_planes), (size_t)g->total_words * 8));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_cd), std::max<size_t>(1, (size_t)n_contigs) * sizeof(ContigDesc)));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_first_bad), std::max<size_t>(1, (size_t)n_contigs) * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&g->first_bad), std::max<size_t>(1, (size_t)n_contigs) * sizeof(unsigned long long), hipHostMallocDefault));
+    g->uid = ctx->next_uid++;
     g->device_bytes = g->ascii_bytes + g->total_words * 8 + n_contigs * (int64_t)(sizeof(ContigDesc) + 8);
     if (n_contigs > 0)
         HIP_TRY(ctx, hipMemcpy(g->d_cd, g->cd.data(), (size_t)n_contigs * sizeof(ContigDesc), hipMemcpyHostToDevice));
+    return KGMA_OK;
+}
+
+// Waits for a pending pack of `g` (the pack kernel is launched asynchronously).
+static int genome_sync(kgma_ctx *ctx, kgma_genome *g)
+{
+    if (!g->pack_pending) return KGMA_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->evp0, ctx->evp1);
+    ctx->stats.pack_ms = ms;
+    g->pack_pending = false;
     return KGMA_OK;
 }
 
@@ -391,20 +425,15 @@ int kgma_genome_repack(kgma_ctx *ctx, kgma_genome *g)
 {
     if (!ctx || !g) return KGMA_E_ARG;
     (void)hipSetDevice(ctx->device);
-    g->first_bad.assign((size_t)std::max<int64_t>(1, g->n_contigs), NO_BAD);
     HIP_TRY(ctx, hipMemsetAsync(g->d_first_bad, 0xFF, std::max<size_t>(1, (size_t)g->n_contigs) * 8, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->evp0, ctx->stream));
     if (g->n_contigs > 0)
         HIP_TRY(ctx, launch_pack(g->d_ascii, g->d_planes, g->d_cd, (int)g->n_contigs, g->total_words, g->d_first_bad, ctx->stream));
     else
         HIP_TRY(ctx, hipMemsetAsync(g->d_planes, 0, (size_t)g->total_words * 8, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    if (g->n_contigs > 0)
-        HIP_TRY(ctx, hipMemcpyAsync(g->first_bad.data(), g->d_first_bad, (size_t)g->n_contigs * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-    ctx->stats.pack_ms = ms;
+    HIP_TRY(ctx, hipEventRecord(ctx->evp1, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(g->first_bad, g->d_first_bad, std::max<size_t>(1, (size_t)g->n_contigs) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    g->pack_pending = true;     // completed by the next scan's single synchronisation (or genome_sync)
     return KGMA_OK;
 }
 
@@ -535,6 +564,8 @@ void kgma_genome_free(kgma_ctx *ctx, kgma_genome *g)
     if (g->d_planes) (void)hipFree(g->d_planes);
     if (g->d_cd) (void)hipFree(g->d_cd);
     if (g->d_first_bad) (void)hipFree(g->d_first_bad);
+    if (g->first_bad) (void)hipHostFree(g->first_bad);
+    if (ctx && ctx->tk_uid == g->uid) ctx->tk_uid = 0;
     delete g;
 }
 
@@ -558,7 +589,7 @@ struct Frag {             // one device record in global coordinates
 int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
 {
     const int64_t n_tiles = (int64_t)ctx->tiles.size();
-    const int64_t P = KGMA_TILE_WINDOWS;
+    const int64_t P = ctx->tile_windows;
     std::vector<Frag> fr;
     fr.reserve(recs.size());
     for (const DevRecord &r : recs) {
@@ -650,81 +681,117 @@ int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
 
 extern "C" {
 
-int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, uint32_t flags)
+int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_t flags)
 {
-    if (!ctx || !g) return KGMA_E_ARG;
+    if (!ctx || !gc) return KGMA_E_ARG;
+    kgma_genome *g = const_cast<kgma_genome *>(gc);   // only its pack bookkeeping is updated
     if (ctx->m == 0) return fail(ctx, KGMA_E_STATE, "kgma_set_refs has not been called");
     if (mode != KGMA_MODE_SINGLE && mode != KGMA_MODE_OMN) return fail(ctx, KGMA_E_ARG, "unknown mode %d", mode);
     (void)hipSetDevice(ctx->device);
     const int k = ctx->k, m_used = mode == KGMA_MODE_SINGLE ? 1 : ctx->m;
-    const int64_t P = KGMA_TILE_WINDOWS;
     int64_t maxws = 0;
     for (int j = 0; j < m_used; j++) maxws = std::max(maxws, ctx->kfv[(size_t)j].W);
-
-    // ---- which windows each record evaluates, and the residues the reference would look up ---
+    const int64_t stride_words = scan_tile_stride_words(ctx->kernel_version, (int)(maxws - k + 1));
+    const int64_t P = stride_words * 32;
     const int64_t nc = g->n_contigs;
-    ctx->contig_len.resize((size_t)nc);
-    ctx->contig_nwin.assign((size_t)nc, 0);
-    ctx->contig_tile_base.assign((size_t)nc, -1);
-    ctx->tiles.clear();
+    const bool want_dists = (flags & KGMA_F_RETURN_DISTS) != 0;
+
     ctx->dips.clear();
     ctx->hits.clear();
     ctx->have_dists = false;
     ctx->last_mode = -1;
-    int64_t dist_total = 0, bases = 0, windows = 0;
-    for (int64_t c = 0; c < nc; c++) {
-        const int64_t L = g->cd[(size_t)c].len;
-        ctx->contig_len[(size_t)c] = L;
-        bases += L;
-        int64_t nwin = 0, looked = 0;
-        if (mode == KGMA_MODE_SINGLE) {
-            const int64_t W = ctx->kfv[0].W;
-            if (L >= W) { nwin = L - W + 1; looked = L; }   // GenomeMiner.jl:37-39,60
-        } else {
-            if (L < k - 1)
-                return fail(ctx, KGMA_E_BOUNDS, "record %lld has %lld residues, fewer than k-1 (BoundsError, OmnGenomeMiner.jl:84-86)",
-                            (long long)c, (long long)L);
-            looked = k - 1;                                                    // :84-86
-            for (int j = 0; j < m_used; j++)
-                if (L >= ctx->kfv[(size_t)j].W) looked = std::max(looked, ctx->kfv[(size_t)j].W);   // :61-82
-            const int64_t n_iter = L - maxws - k + 2;                          // :89
-            if (n_iter >= 1) { nwin = n_iter + 1; looked = std::max(looked, L - k + 2); }   // seq[i+ws], :97
-        }
-        const unsigned long long fb = g->first_bad[(size_t)c];
-        if (fb != NO_BAD && (int64_t)fb <= looked)
-            return fail(ctx, KGMA_E_BADBASE, "record %lld position %llu: residue is not one of A/C/G/T/N (KeyError, Consts.jl:22-28)",
-                        (long long)c, fb);
-        ctx->contig_nwin[(size_t)c] = nwin;
-        if (nwin > 0) {
-            ctx->contig_tile_base[(size_t)c] = (int64_t)ctx->tiles.size();
-            const int64_t nt = (nwin + P - 1) / P;
-            for (int64_t t = 0; t < nt; t++) {
-                TileDesc td;
-                td.word_base = g->cd[(size_t)c].word_off + t * KGMA_TILE_WORDS;
-                td.win0 = t * P + 1;
-                td.dist_base = dist_total + t * P - 1;
-                td.n_valid = (int32_t)std::min<int64_t>(P, nwin - t * P);
-                td.first_test = t == 0 ? 1 : 0;
-                td.contig = (int32_t)c;
-                td.pad = 0;
-                ctx->tiles.push_back(td);
+
+    // ---- which windows each record evaluates (tile table), cached per (genome, mode, W, k) ----
+    const bool tiles_cached = ctx->tk_uid == g->uid && ctx->tk_mode == mode && ctx->tk_maxws == maxws &&
+                              ctx->tk_k == k && ctx->tk_version == ctx->kernel_version;
+    if (!tiles_cached) {
+        ctx->tile_windows = P;
+        ctx->contig_len.resize((size_t)nc);
+        ctx->contig_nwin.assign((size_t)nc, 0);
+        ctx->contig_looked.assign((size_t)nc, 0);
+        ctx->contig_tile_base.assign((size_t)nc, -1);
+        ctx->tiles.clear();
+        int64_t dist_total = 0, bases = 0, windows = 0;
+        for (int64_t c = 0; c < nc; c++) {
+            const int64_t L = g->cd[(size_t)c].len;
+            ctx->contig_len[(size_t)c] = L;
+            bases += L;
+            int64_t nwin = 0, looked = 0;
+            if (mode == KGMA_MODE_SINGLE) {
+                const int64_t W = ctx->kfv[0].W;
+                if (L >= W) { nwin = L - W + 1; looked = L; }   // GenomeMiner.jl:37-39,60
+            } else {
+                if (L < k - 1) {
+                    looked = -1;                                                   // BoundsError, :84-86
+                } else {
+                    looked = k - 1;                                                // :84-86
+                    for (int j = 0; j < m_used; j++)
+                        if (L >= ctx->kfv[(size_t)j].W) looked = std::max(looked, ctx->kfv[(size_t)j].W);   // :61-82
+                    const int64_t n_iter = L - maxws - k + 2;                      // :89
+                    if (n_iter >= 1) { nwin = n_iter + 1; looked = std::max(looked, L - k + 2); }   // seq[i+ws], :97
+                }
             }
-            dist_total += nwin - 1;
-            windows += nwin * m_used;
+            ctx->contig_looked[(size_t)c] = looked;
+            ctx->contig_nwin[(size_t)c] = nwin;
+            if (nwin > 0) {
+                ctx->contig_tile_base[(size_t)c] = (int64_t)ctx->tiles.size();
+                const int64_t nt = (nwin + P - 1) / P;
+                for (int64_t t = 0; t < nt; t++) {
+                    TileDesc td;
+                    td.word_base = g->cd[(size_t)c].word_off + t * stride_words;
+                    td.win0 = t * P + 1;
+                    td.dist_base = dist_total + t * P - 1;
+                    td.n_valid = (int32_t)std::min<int64_t>(P, nwin - t * P);
+                    td.first_test = t == 0 ? 1 : 0;
+                    td.contig = (int32_t)c;
+                    td.pad = 0;
+                    ctx->tiles.push_back(td);
+                }
+                dist_total += nwin - 1;
+                windows += nwin * m_used;
+            }
         }
+        ctx->n_dists_per_kfv = dist_total;
+        ctx->tk_bases = bases;
+        ctx->tk_windows = windows;
+        ctx->tk_uid = 0;   // set once the table is on the device
     }
     const int64_t n_tiles = (int64_t)ctx->tiles.size();
     if (n_tiles > 0x7FFFFFF0ll) return fail(ctx, KGMA_E_UNSUPPORTED, "too many tiles");
-    ctx->n_dists_per_kfv = dist_total;
-    ctx->stats.bases_scanned = bases;
-    ctx->stats.windows_scanned = windows;
+    const int64_t dist_total = ctx->n_dists_per_kfv;
+    ctx->stats.bases_scanned = ctx->tk_bases;
+    ctx->stats.windows_scanned = ctx->tk_windows;
     ctx->stats.n_tiles = (int32_t)n_tiles;
     ctx->stats.n_launches = 0;
     ctx->stats.scan_ms = 0;
     ctx->stats.n_at_threshold = 0;
     ctx->stats.n_dips = ctx->stats.n_hits = ctx->stats.n_tie_flagged = 0;
-    ctx->D0.assign((size_t)ctx->m * (size_t)std::max<int64_t>(1, n_tiles), -1);
-    if (n_tiles == 0) { ctx->last_mode = mode; ctx->have_dists = (flags & KGMA_F_RETURN_DISTS) != 0; return KGMA_OK; }
+
+    // errors the reference raises while walking the records, in record order
+    auto check_records = [&]() -> int {
+        for (int64_t c = 0; c < nc; c++) {
+            const int64_t looked = ctx->contig_looked[(size_t)c];
+            if (looked < 0)
+                return fail(ctx, KGMA_E_BOUNDS, "record %lld has %lld residues, fewer than k-1 (BoundsError, OmnGenomeMiner.jl:84-86)",
+                            (long long)c, (long long)ctx->contig_len[(size_t)c]);
+            const unsigned long long fb = g->first_bad[(size_t)c];
+            if (fb != NO_BAD && (int64_t)fb <= looked)
+                return fail(ctx, KGMA_E_BADBASE, "record %lld position %llu: residue is not one of A/C/G/T/N (KeyError, Consts.jl:22-28)",
+                            (long long)c, fb);
+        }
+        return KGMA_OK;
+    };
+
+    if (n_tiles == 0) {
+        int rc0 = genome_sync(ctx, g);
+        if (rc0) return rc0;
+        rc0 = check_records();
+        if (rc0) return rc0;
+        ctx->D0.assign((size_t)ctx->m, -1);
+        ctx->last_mode = mode;
+        ctx->have_dists = want_dists;
+        return KGMA_OK;
+    }
 
     int rc = dev_reserve(ctx, ctx->d_tiles, ctx->tiles_cap, n_tiles);
     if (rc) return rc;
@@ -736,13 +803,31 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, uint32_t
         if (rc) return rc;
         ctx->rec_cap = (unsigned int)cap;
     }
-    const bool want_dists = (flags & KGMA_F_RETURN_DISTS) != 0;
     if (want_dists)
         for (int j = 0; j < m_used; j++) {
             rc = dev_reserve(ctx, ctx->d_dist[(size_t)j], ctx->dist_cap[(size_t)j], std::max<int64_t>(1, dist_total));
             if (rc) return rc;
         }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tiles, ctx->tiles.data(), (size_t)n_tiles * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
+    // pinned staging: [meta 16 B][D0 n_tiles*m*8][first INLINE_RECS records]
+    constexpr size_t INLINE_RECS = 4096;
+    const size_t d0_bytes = (size_t)n_tiles * (size_t)ctx->m * sizeof(int64_t);
+    const size_t pin_need = 16 + d0_bytes + INLINE_RECS * sizeof(DevRecord);
+    if (pin_need > ctx->h_pin_cap) {
+        if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+        ctx->h_pin = nullptr; ctx->h_pin_cap = 0;
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pin), pin_need + (pin_need >> 2), hipHostMallocDefault));
+        ctx->h_pin_cap = pin_need + (pin_need >> 2);
+    }
+    unsigned int *h_nrecs = reinterpret_cast<unsigned int *>(ctx->h_pin);
+    unsigned long long *h_natt = reinterpret_cast<unsigned long long *>(ctx->h_pin + 8);
+    int64_t *h_D0 = reinterpret_cast<int64_t *>(ctx->h_pin + 16);
+    DevRecord *h_recs = reinterpret_cast<DevRecord *>(ctx->h_pin + 16 + d0_bytes);
+
+    if (!tiles_cached) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tiles, ctx->tiles.data(), (size_t)n_tiles * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
+        // the vector is pageable memory: the runtime stages it before returning, so it may be reused
+        ctx->tk_uid = g->uid; ctx->tk_mode = mode; ctx->tk_maxws = maxws; ctx->tk_k = k; ctx->tk_version = ctx->kernel_version;
+    }
 
     const std::vector<Group> groups = make_groups(ctx, mode);
     const int64_t NB = (int64_t)1 << (2 * k);
@@ -765,7 +850,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, uint32_t
                 gp.n_kfv = (int32_t)(jn - i);
                 gp.k = k;
                 gp.nk = (int32_t)(gr.W - k + 1);
-                gp.nblocks = (gp.nk + 15) / 16;
+                gp.nblocks = scan_nblocks(ctx->kernel_version, gp.nk);
                 for (size_t u = i; u < jn; u++) {
                     const int j = gr.kfvs[u];
                     const KfvInfo &f = ctx->kfv[(size_t)j];
@@ -786,14 +871,27 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, uint32_t
                 a.rec_cap = ctx->rec_cap;
                 a.n_tiles = (int32_t)n_tiles;
                 a.n_att = ctx->d_n_att;
-                HIP_TRY(ctx, launch_scan(a, gp, ctx->stream));
+                HIP_TRY(ctx, launch_scan(a, gp, ctx->kernel_version, ctx->stream));
                 ctx->stats.n_launches++;
                 i = jn;
             }
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(&n_recs, ctx->d_rec_count, sizeof n_recs, hipMemcpyDeviceToHost, ctx->stream));
+        // everything the host needs comes back behind ONE synchronisation (records beyond the
+        // inline block need a second copy; that only happens for dip-dense inputs)
+        HIP_TRY(ctx, hipMemcpyAsync(h_nrecs, ctx->d_rec_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(h_natt, ctx->d_n_att, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(h_D0, ctx->d_D0, d0_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(h_recs, ctx->d_recs, std::min<size_t>(INLINE_RECS, ctx->rec_cap) * sizeof(DevRecord),
+                                    hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (g->pack_pending) {
+            float pms = 0;
+            (void)hipEventElapsedTime(&pms, ctx->evp0, ctx->evp1);
+            ctx->stats.pack_ms = pms;
+            g->pack_pending = false;
+        }
+        n_recs = *h_nrecs;
         if (n_recs <= ctx->rec_cap) break;
         if (attempt >= 4) return fail(ctx, KGMA_E_OVERFLOW, "record buffer overflow (%u records)", n_recs);
         int64_t cap = ctx->rec_cap;
@@ -804,13 +902,16 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, uint32_t
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->stats.scan_ms = ms;
+    rc = check_records();
+    if (rc) return rc;
 
     std::vector<DevRecord> recs((size_t)n_recs);
-    unsigned long long n_att = 0;
-    if (n_recs) HIP_TRY(ctx, hipMemcpy(recs.data(), ctx->d_recs, (size_t)n_recs * sizeof(DevRecord), hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(&n_att, ctx->d_n_att, sizeof n_att, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(ctx->D0.data(), ctx->d_D0, (size_t)n_tiles * (size_t)ctx->m * sizeof(int64_t), hipMemcpyDeviceToHost));
-    ctx->stats.n_at_threshold = (int64_t)n_att;
+    const size_t n_inline = std::min<size_t>(n_recs, INLINE_RECS);
+    if (n_inline) memcpy(recs.data(), h_recs, n_inline * sizeof(DevRecord));
+    if (n_recs > n_inline)
+        HIP_TRY(ctx, hipMemcpy(recs.data() + n_inline, ctx->d_recs + n_inline, ((size_t)n_recs - n_inline) * sizeof(DevRecord), hipMemcpyDeviceToHost));
+    ctx->D0.assign(h_D0, h_D0 + (size_t)n_tiles * (size_t)ctx->m);
+    ctx->stats.n_at_threshold = (int64_t)*h_natt;
     ctx->have_dists = want_dists;
     rc = stitch_dips(ctx, recs);
     if (rc) return rc;

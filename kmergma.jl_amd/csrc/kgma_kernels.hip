@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
         const int64_t L = cd[c].len;
         const int64_t base0 = w * 32;
         uint32_t h = 0, l = 0, bad = 0;
-        if (base0 < L) {
+        if (w >= 0 && base0 < L) {
             const uint4 *p = reinterpret_cast<const uint4 *>(ascii + cd[c].ascii_off + base0);
             const uint4 a = p[0], b = p[1];
             const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void synth_kernel(uint8_t *__restrict__ ascii,
         const int64_t w = g - cd[c].word_off;
         const int64_t L = cd[c].len;
         const int64_t base0 = w * 32;
-        if (base0 >= ((L + 31) & ~31ll)) continue;   // padding words carry no ASCII
+        if (w < 0 || base0 >= ((L + 31) & ~31ll)) continue;   // padding words carry no ASCII
         const uint64_t z = synth_word(seed, (uint64_t)c, (uint64_t)w);
         uint32_t out[8];
 #pragma unroll
@@ -527,8 +527,416 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
 }
 
 // ------------------------------------------------------------------------------------------
+// Scan kernel, version 2: one mask family for both directions, halo words by DPP.
+//
+// F_o[p] = [K_p != K_{p+o}] is computed once per offset.  fwd_q sums F_o[q] in place; the back
+// count of the k-mer entering at p = q + nk is  sum_o F_o[p - o], i.e. the SAME masks shifted by
+// o.  With np = 16*nblocks - 1 and t = np - o = 32 j + s the shift splits into a bit shift s
+// (applied per mask inside the lane: it owns R consecutive words and gets the first word of its
+// right neighbour by DPP) and a word shift j that is constant over a group of <= 32 offsets, so
+// the masks of a group are summed first (6-plane counter, coordinates v = p - np) and only the
+// group sums travel across lanes through LDS (one exchange per group, ~nk/32 per tile).
+//
+// The k-long run-OR and the bit shift need bits of the NEXT word; that word belongs to the next
+// lane, which computes it anyway, so it is fetched with one `v_mov_b32_dpp wave_shl:1` instead of
+// being recomputed.  Lane 63 of a wave has no right neighbour: each wave therefore covers 63
+// lanes' worth of words and its lane 63 duplicates lane 0 of the next wave (results discarded).
+//
+// Tile geometry: slot = 63*wave + lane (0..252); slot s owns local LDS words [R s, R s + R).
+// Slot 0 is a left halo (its group sums feed the bit shift of the first output word), the last
+// v2_right_halo words are a right halo (their masks feed the word-shifted reads); output words
+// are [R, 253 R - halo).
+// ------------------------------------------------------------------------------------------
+constexpr int V2_SLOTS = 253;
+
+__host__ __device__ inline int v2_nblocks(int nk) { return nk / 16 + 1; }   // np = 16B-1 >= nk
+
+__host__ __device__ inline int v2_right_halo(int nk, int R)
+{
+    const int B = v2_nblocks(nk);
+    const int jmax = (16 * B - 1) >> 5;
+    return ((jmax + 2 + R - 1) / R) * R;
+}
+__host__ __device__ inline int v2_stride_words(int nk, int R) { return (V2_SLOTS - 1) * R - v2_right_halo(nk, R); }
+
+struct Counter6 {
+    uint32_t c[6];
+    uint32_t p0, p1, p2, p3;
+};
+
+template <int I>
+__device__ __forceinline__ void counter6_add(Counter6 &s, uint32_t m)
+{
+    if constexpr ((I & 1) == 0) { s.p0 = m; return; }
+    uint32_t c1; KGMA_CSA(c1, s.c[0], s.c[0], s.p0, m);
+    if constexpr ((I & 2) == 0) { s.p1 = c1; return; }
+    uint32_t c2; KGMA_CSA(c2, s.c[1], s.c[1], s.p1, c1);
+    if constexpr ((I & 4) == 0) { s.p2 = c2; return; }
+    uint32_t c3; KGMA_CSA(c3, s.c[2], s.c[2], s.p2, c2);
+    if constexpr ((I & 8) == 0) { s.p3 = c3; return; }
+    uint32_t c4; KGMA_CSA(c4, s.c[3], s.c[3], s.p3, c3);
+    const uint32_t t = s.c[4] & c4;
+    s.c[4] ^= c4;
+    s.c[5] ^= t;      // a group holds at most 32 masks: no carry out of plane 5
+}
+
+// value of `x` in the next lane (lane 63 receives 0)
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
+
+template <int K, int R>
+__global__ __launch_bounds__(KGMA_THREADS) void scan_kernel_v2(ScanArgs a, GroupParams gp)
+{
+    constexpr int NP = KGMA_NPLANES;
+    constexpr int NB = 1 << (2 * K);
+    constexpr int TW = V2_SLOTS * R;             // words covered by the tile's lanes
+    constexpr int XW = TW + 16;                  // words per plane of the exchange buffer
+    constexpr int LH = R;                        // left halo words
+    extern __shared__ uint32_t smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int slot = 63 * wave + lane;
+    const bool dup = lane == 63 && wave < 3;     // duplicates the next wave's lane 0
+    const int tile = blockIdx.x;
+    const TileDesc td = a.tiles[tile];
+    const int nk = gp.nk;
+    const int nblocks = gp.nblocks;
+    const int np = 16 * nblocks - 1;
+    const int delta = np - nk;                   // 0..15
+    const int NW = TW + scan_pad_words(nk);
+
+    uint32_t *sH = smem;
+    uint32_t *sL = sH + NW;
+    int32_t *sS = reinterpret_cast<int32_t *>(sL + NW);
+    uint32_t *sX = reinterpret_cast<uint32_t *>(sS + gp.n_kfv * NB);   // exchange buffer, aliases the histogram
+    constexpr int XSIZE = ((9 * XW > NB ? 9 * XW : NB) + 1) & ~1;
+    int32_t *sHist = reinterpret_cast<int32_t *>(sX);
+    int32_t *sMisc = reinterpret_cast<int32_t *>(sX + XSIZE);
+    int64_t *sRed = reinterpret_cast<int64_t *>(sMisc + 16 + KGMA_THREADS);
+
+    // ---- stage planes (starting LH words before the first output word) and S tables -----------
+    {
+        const uint2 *g2 = reinterpret_cast<const uint2 *>(a.planes) + (td.word_base - LH);
+        for (int w = tid; w < NW; w += KGMA_THREADS) {
+            const uint2 v = g2[w];
+            sH[w] = v.x;
+            sL[w] = v.y;
+        }
+        for (int i = tid; i < gp.n_kfv * NB; i += KGMA_THREADS) sS[i] = a.Stab[i];
+        for (int i = tid; i < NB; i += KGMA_THREADS) sHist[i] = 0;
+    }
+    __syncthreads();
+
+    // ---- D of the tile's first window: histogram of its nk k-mers -----------------------------
+    for (int q = tid; q < nk; q += KGMA_THREADS) {
+        const int pos = 32 * LH + q;
+        const int w = pos >> 5;
+        const uint32_t idx = plane_index<K>(sH[w], sH[w + 1], sL[w], sL[w + 1], (uint32_t)(pos & 31));
+        atomicAdd(&sHist[idx], 1);
+    }
+    __syncthreads();
+    for (int j = 0; j < gp.n_kfv; j++) {
+        int64_t acc = 0;
+        const int64_t Nj = gp.N[j];
+        for (int x = tid; x < NB; x += KGMA_THREADS) {
+            const int64_t d = (int64_t)sS[j * NB + x] - Nj * (int64_t)sHist[x];
+            acc += d * d;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += shfl_down_i64(acc, d);
+        if ((tid & 63) == 0) sRed[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            const int64_t D0 = sRed[0] + sRed[1] + sRed[2] + sRed[3];
+            a.D0out[(size_t)j * a.n_tiles + tile] = D0;
+            sRed[4 + j] = D0;
+        }
+        __syncthreads();
+    }
+
+    // ---- match loop ------------------------------------------------------------------------
+    const int w0 = R * slot;                      // LDS word index of the lane's first word
+    uint32_t A0h[R + 1], A0l[R + 1];
+#pragma unroll
+    for (int w = 0; w < R + 1; w++) { A0h[w] = sH[w0 + w]; A0l[w] = sL[w0 + w]; }
+
+    Counter cf[R];            // forward mismatch counts (own words, in place)
+    Counter6 cg[R];           // group sums of the bit-shifted masks (coordinates v = p - np)
+    uint32_t TB[R][NP];       // backward mismatch counts, coordinates v
+#pragma unroll
+    for (int w = 0; w < R; w++) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) { cf[w].c[p] = 0; TB[w][p] = 0; }
+        cf[w].p0 = cf[w].p1 = cf[w].p2 = cf[w].p3 = 0;
+#pragma unroll
+        for (int p = 0; p < 6; p++) cg[w].c[p] = 0;
+        cg[w].p0 = cg[w].p1 = cg[w].p2 = cg[w].p3 = 0;
+    }
+
+    for (int blk = 0; blk < nblocks; blk++) {
+        const int jw = blk >> 1;
+        const uint32_t s0 = (uint32_t)(blk & 1) << 4;
+        const int m = nblocks - blk;                          // t = 16 m - 1 - i
+        const uint32_t sb0 = (m & 1) ? 15u : 31u;             // bit shift of step i is sb0 - i
+        uint32_t Xh[R + 1], Xl[R + 1];
+#pragma unroll
+        for (int w = 0; w < R + 1; w++) { Xh[w] = sH[w0 + jw + w]; Xl[w] = sL[w0 + jw + w]; }
+        const int obase = blk << 4;
+
+#define KGMA_STEP2(I)                                                                      \
+        {                                                                                  \
+            const uint32_t s = s0 + (I);                                                   \
+            const uint32_t force = (obase + (I)) >= nk ? 0xFFFFFFFFu : 0u;                 \
+            uint32_t f1[R + 1];                                                            \
+            _Pragma("unroll") for (int w = 0; w < R; w++) {                                \
+                const uint32_t xh = alignbit(Xh[w + 1], Xh[w], s);                         \
+                const uint32_t xl = alignbit(Xl[w + 1], Xl[w], s);                         \
+                f1[w] = (xh ^ A0h[w]) | (xl ^ A0l[w]);                                     \
+            }                                                                              \
+            f1[R] = from_next_lane(f1[0]);                                                 \
+            uint32_t F[R + 1];                                                             \
+            {                                                                              \
+                uint32_t Fo[R];                                                            \
+                kmer_mismatch<K, R>(f1, force, Fo);                                        \
+                _Pragma("unroll") for (int w = 0; w < R; w++) F[w] = Fo[w];                \
+            }                                                                              \
+            F[R] = from_next_lane(F[0]);                                                   \
+            const uint32_t sb = sb0 - (I);                                                 \
+            _Pragma("unroll") for (int w = 0; w < R; w++) {                                \
+                counter_add<I>(cf[w], F[w]);                                               \
+                counter6_add<I>(cg[w], alignbit(F[w + 1], F[w], sb));                      \
+            }                                                                              \
+        }
+        KGMA_STEP2(0) KGMA_STEP2(1) KGMA_STEP2(2) KGMA_STEP2(3)
+        KGMA_STEP2(4) KGMA_STEP2(5) KGMA_STEP2(6) KGMA_STEP2(7)
+        KGMA_STEP2(8) KGMA_STEP2(9) KGMA_STEP2(10) KGMA_STEP2(11)
+        KGMA_STEP2(12) KGMA_STEP2(13) KGMA_STEP2(14) KGMA_STEP2(15)
+#undef KGMA_STEP2
+
+        // end of a word-shift group: exchange the group sums through LDS and add them to TB
+        if (((m - 1) & 1) == 0 || blk == nblocks - 1) {
+            const int jsh = (m - 1) >> 1;                     // word shift of this group
+            __syncthreads();                                  // previous readers are done
+            if (!dup) {
+#pragma unroll
+                for (int p = 0; p < 6; p++)
+#pragma unroll
+                    for (int w = 0; w < R; w++) sX[p * XW + w0 + w] = cg[w].c[p];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < R; w++) {
+                uint32_t carry = 0;
+#pragma unroll
+                for (int p = 0; p < 6; p++) {
+                    const uint32_t x = sX[p * XW + w0 + w + jsh];
+                    const uint32_t y = TB[w][p];
+                    const uint32_t u = x ^ y;
+                    TB[w][p] = u ^ carry;
+                    carry = (x & y) | (carry & u);
+                }
+#pragma unroll
+                for (int p = 6; p < NP; p++) {
+                    const uint32_t y = TB[w][p];
+                    TB[w][p] = y ^ carry;
+                    carry &= y;
+                }
+#pragma unroll
+                for (int p = 0; p < 6; p++) cg[w].c[p] = 0;
+            }
+        }
+    }
+
+    // ---- bring TB from coordinates v = q - delta to window coordinates q ------------------------
+    __syncthreads();
+    if (!dup) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) sX[p * XW + slot] = TB[R - 1][p];
+    }
+    __syncthreads();
+    uint32_t dpl[R][NP + 1];
+    {
+        const uint32_t sh = (uint32_t)(32 - delta) & 31u;
+#pragma unroll
+        for (int w = R - 1; w >= 0; w--) {
+            uint32_t bw = 0;
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const uint32_t prev = w > 0 ? TB[w - 1][p] : (slot > 0 ? sX[p * XW + slot - 1] : 0u);
+                const uint32_t x = delta ? alignbit(TB[w][p], prev, sh) : TB[w][p];   // back mismatches at q
+                const uint32_t y = cf[w].c[p];                                         // fwd mismatches at q
+                const uint32_t u = x ^ y;
+                dpl[w][p] = u ^ bw;
+                bw = (y & u) | (bw & ~u);
+            }
+            dpl[w][NP] = bw;
+        }
+    }
+
+    // ---- position phase; local window q = 32*(R*slot - LH + w) + b -----------------------------
+    uint32_t Anh[R + 1], Anl[R + 1];
+    {
+        const int jn = nk >> 5;
+        const uint32_t sn = (uint32_t)(nk & 31);
+#pragma unroll
+        for (int w = 0; w < R + 1; w++) {
+            Anh[w] = alignbit(sH[w0 + jn + w + 1], sH[w0 + jn + w], sn);
+            Anl[w] = alignbit(sL[w0 + jn + w + 1], sL[w0 + jn + w], sn);
+        }
+    }
+    const int n_valid = td.n_valid;
+    const int first_test = td.first_test;
+    const int lim = n_valid - 1;
+    const int qa = 32 * (w0 - LH);
+    int32_t *sScan = sMisc;
+    int32_t *sPrev = sMisc + 16;
+
+    auto walk = [&](int j, auto &&body) {
+        const int32_t *S = sS + j * NB;
+        const int32_t Nj = gp.N[j];
+#pragma unroll
+        for (int w = 0; w < R; w++) {
+            for (uint32_t b = 0; b < 32; b++) {
+                uint32_t v = (dpl[w][0] >> b) & 1u;
+#pragma unroll
+                for (int p = 1; p <= NP; p++) v |= ((dpl[w][p] >> b) & 1u) << p;
+                const int32_t diff = ((int32_t)(v << (31 - NP))) >> (31 - NP);
+                const uint32_t il = plane_index<K>(A0h[w], A0h[w + 1], A0l[w], A0l[w + 1], b);
+                const uint32_t ir = plane_index<K>(Anh[w], Anh[w + 1], Anl[w], Anl[w + 1], b);
+                const int q = qa + 32 * w + (int)b;
+                int32_t e = S[il] - S[ir] - Nj * diff;
+                e = (q >= 0 && q < lim) ? e : 0;
+                body(q, e);
+            }
+        }
+    };
+
+    for (int j = 0; j < gp.n_kfv; j++) {
+        const int64_t D0 = sRed[4 + j];
+        const int64_t twoN = 2 * (int64_t)gp.N[j];
+        int64_t TE64;
+        bool t_exact;
+        {
+            const int64_t num = gp.T[j] - D0;
+            TE64 = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
+            t_exact = (num % twoN) == 0;
+            if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; t_exact = false; }
+            if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; t_exact = false; }
+        }
+        const int32_t TE = (int32_t)TE64;
+
+        int32_t r = 0, rmin = 0x7FFFFFFF, rlast = 0;
+        walk(j, [&](int q, int32_t e) {
+            const bool testable = q >= first_test && q < n_valid;
+            rmin = testable ? (r < rmin ? r : rmin) : rmin;
+            rlast = r;
+            r += e;
+        });
+        const int32_t total = dup ? 0 : r;
+
+        int32_t incl = total;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) sScan[wave] = incl;
+        __syncthreads();
+        int32_t offset = incl - total;
+        for (int wv = 0; wv < wave; wv++) offset += sScan[wv];
+
+        const int qb = qa + 32 * R - 1;
+        const bool last_testable = qb >= first_test && qb < n_valid;
+        const bool last_under = last_testable && (offset + rlast < TE);
+        if (!dup) sPrev[slot] = last_under ? 1 : 0;
+        __syncthreads();
+        const bool prev_under = slot > 0 && sPrev[slot - 1] != 0;
+        double *dist = a.dist[j];
+        const bool any_under = rmin != 0x7FFFFFFF && (offset + rmin < TE + (t_exact ? 1 : 0));
+        const bool need = !dup && (any_under || prev_under || dist != nullptr) && qb >= 0 && qa < n_valid;
+
+        if (need) {
+            const int kid = gp.kfv_id[j];
+            bool in_run = false;
+            int32_t run_start = 0, minE = 0, argf = 0, argl = 0, nmin = 0;
+            int32_t E = offset;
+            const double scale = gp.inv_scale[j];
+            walk(j, [&](int q, int32_t e) {
+                const bool testable = q >= first_test && q < n_valid;
+                const bool under = testable && E < TE;
+                if (testable && dist != nullptr)
+                    dist[td.dist_base + q] = (double)(D0 + twoN * (int64_t)E) / scale;
+                if (under) {
+                    if (!in_run) {
+                        in_run = true; run_start = q; minE = E; argf = argl = q; nmin = 1;
+                    } else if (E < minE) {
+                        minE = E; argf = argl = q; nmin = 1;
+                    } else if (E == minE) {
+                        argl = q; nmin++;
+                    }
+                } else {
+                    if (in_run) {
+                        DevRecord rec;
+                        rec.tile = tile; rec.kind_kfv = REC_RUN | (kid << 8);
+                        rec.start = run_start; rec.end = q - 1; rec.minE = minE;
+                        rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
+                        rec.exitE = E; rec.has_exit = q < n_valid ? 1 : 0;
+                        emit_record(a.recs, a.rec_count, a.rec_cap, rec);
+                        in_run = false;
+                    } else if (q == qa && prev_under && q >= 0 && q < n_valid) {
+                        DevRecord rec;
+                        rec.tile = tile; rec.kind_kfv = REC_EXIT | (kid << 8);
+                        rec.start = q; rec.end = q; rec.minE = E;
+                        rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 1;
+                        emit_record(a.recs, a.rec_count, a.rec_cap, rec);
+                    }
+                    if (t_exact && testable && E == TE) {
+                        DevRecord rec;
+                        rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8);
+                        rec.start = q; rec.end = q; rec.minE = E;
+                        rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
+                        emit_record(a.recs, a.rec_count, a.rec_cap, rec);
+                        atomicAdd(a.n_att, 1ull);
+                    }
+                }
+                E += e;
+            });
+            if (in_run) {
+                DevRecord rec;
+                rec.tile = tile; rec.kind_kfv = REC_RUN | (kid << 8);
+                rec.start = run_start; rec.end = qb; rec.minE = minE;
+                rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
+                rec.exitE = 0; rec.has_exit = 0;
+                emit_record(a.recs, a.rec_count, a.rec_cap, rec);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // launch wrappers (called from kgma_api.cpp)
 // ------------------------------------------------------------------------------------------
+size_t scan_lds_bytes_v2(int k, int nk, int n_kfv, int R)
+{
+    const size_t TW = (size_t)V2_SLOTS * R;
+    const size_t NW = TW + scan_pad_words(nk);
+    const size_t NB = (size_t)1 << (2 * k);
+    const size_t XW = TW + 16;
+    const size_t xsize = ((9 * XW > NB ? 9 * XW : NB) + 1) & ~(size_t)1;
+    return (2 * NW + (size_t)n_kfv * NB + xsize + 16 + KGMA_THREADS) * 4 + (4 + KGMA_MAX_GROUP) * 8 + 64;
+}
+
+// kernel variants: 1 = scan_kernel (R=4, masks rebuilt per direction); 2 = scan_kernel_v2<R=4>; 3 = scan_kernel_v2<R=2>
+int scan_tile_stride_words(int version, int nk)
+{
+    return version == 2 ? v2_stride_words(nk, 4) : version == 3 ? v2_stride_words(nk, 2) : KGMA_TILE_WORDS;
+}
+int scan_nblocks(int version, int nk) { return version >= 2 ? v2_nblocks(nk) : (nk + 15) / 16; }
+
 size_t scan_lds_bytes(int k, int nk, int n_kfv)
 {
     const size_t NW = KGMA_TILE_WORDS + scan_pad_words(nk);
@@ -569,9 +977,36 @@ static hipError_t launch_scan_k(const ScanArgs &a, const GroupParams &gp, hipStr
     return hipGetLastError();
 }
 
-hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+template <int K, int R>
+static hipError_t launch_scan_v2_k(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+{
+    const size_t lds = scan_lds_bytes_v2(K, gp.nk, gp.n_kfv, R);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel_v2<K, R>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((scan_kernel_v2<K, R>), dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
+    return hipGetLastError();
+}
+
+template <int R>
+static hipError_t launch_scan_v2_r(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+{
+    switch (gp.k) {
+    case 2: return launch_scan_v2_k<2, R>(a, gp, st);
+    case 3: return launch_scan_v2_k<3, R>(a, gp, st);
+    case 4: return launch_scan_v2_k<4, R>(a, gp, st);
+    case 5: return launch_scan_v2_k<5, R>(a, gp, st);
+    case 6: return launch_scan_v2_k<6, R>(a, gp, st);
+    case 7: return launch_scan_v2_k<7, R>(a, gp, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, int version, hipStream_t st)
 {
     if (a.n_tiles <= 0) return hipSuccess;
+    if (version == 2) return launch_scan_v2_r<4>(a, gp, st);
+    if (version == 3) return launch_scan_v2_r<2>(a, gp, st);
     switch (gp.k) {
     case 2: return launch_scan_k<2>(a, gp, st);
     case 3: return launch_scan_k<3>(a, gp, st);

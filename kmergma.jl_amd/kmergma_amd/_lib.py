@@ -13,7 +13,7 @@ from typing import Callable, List, Optional, Sequence
 import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, "libkgma.so")
+LIB_PATH = os.environ.get("KGMA_LIB") or os.path.join(_PKG_DIR, "libkgma.so")
 
 KGMA_OK = 0
 KGMA_E_ARG, KGMA_E_NODEVICE, KGMA_E_HIP, KGMA_E_BADBASE, KGMA_E_BOUNDS = 1, 2, 3, 4, 5
