@@ -103,10 +103,9 @@ struct kgma_ctx {
     int32_t *d_Stab = nullptr;        // m x 4^k, plane-index order
     // scan scratch
     TileDesc *d_tiles = nullptr; int64_t tiles_cap = 0;
-    int64_t *d_D0 = nullptr; int64_t d0_cap = 0;
-    DevRecord *d_recs = nullptr; unsigned int rec_cap = 0;
-    unsigned int *d_rec_count = nullptr;
-    unsigned long long *d_n_att = nullptr;
+    // one device block: [counters 16 B: rec_count u32 @0, n_att u64 @8][D0: res_d0_slots int64][records]
+    uint8_t *d_res = nullptr; int64_t res_bytes = 0;
+    int64_t res_d0_slots = 0; unsigned int rec_cap = 0;
     std::vector<double *> d_dist;     // per KFV
     std::vector<int64_t> dist_cap;
     // results of the last scan
@@ -255,12 +254,10 @@ int kgma_create(int device_ordinal, kgma_ctx **out)
     kgma_ctx *ctx = new (std::nothrow) kgma_ctx();
     if (!ctx) return KGMA_E_NOMEM;
     ctx->device = device_ordinal;
-    if (const char *kv = getenv("KGMA_KERNEL")) { const int v = atoi(kv); if (v >= 1 && v <= 3) ctx->kernel_version = v; }
+    if (const char *kv = getenv("KGMA_KERNEL")) { const int v = atoi(kv); if (v >= 1 && v <= 4) ctx->kernel_version = v; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipEventCreate(&ctx->evp0) != hipSuccess || hipEventCreate(&ctx->evp1) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&ctx->d_rec_count), sizeof(unsigned int)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&ctx->d_n_att), sizeof(unsigned long long)) != hipSuccess) {
+        hipEventCreate(&ctx->evp0) != hipSuccess || hipEventCreate(&ctx->evp1) != hipSuccess) {
         kgma_destroy(ctx);
         return KGMA_E_HIP;
     }
@@ -276,10 +273,7 @@ void kgma_destroy(kgma_ctx *ctx)
     for (double *p : ctx->d_dist) if (p) (void)hipFree(p);
     if (ctx->d_Stab) (void)hipFree(ctx->d_Stab);
     if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
-    if (ctx->d_D0) (void)hipFree(ctx->d_D0);
-    if (ctx->d_recs) (void)hipFree(ctx->d_recs);
-    if (ctx->d_rec_count) (void)hipFree(ctx->d_rec_count);
-    if (ctx->d_n_att) (void)hipFree(ctx->d_n_att);
+    if (ctx->d_res) (void)hipFree(ctx->d_res);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->evp0) (void)hipEventDestroy(ctx->evp0);
     if (ctx->evp1) (void)hipEventDestroy(ctx->evp1);
@@ -795,14 +789,22 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
 
     int rc = dev_reserve(ctx, ctx->d_tiles, ctx->tiles_cap, n_tiles);
     if (rc) return rc;
-    rc = dev_reserve(ctx, ctx->d_D0, ctx->d0_cap, n_tiles * ctx->m);
-    if (rc) return rc;
-    if (ctx->rec_cap == 0) {
+    // result block: counters | D0 | records (one memset, one download per scan)
+    auto res_reserve = [&](int64_t d0_slots, int64_t recs) -> int {
+        if (ctx->d_res && d0_slots <= ctx->res_d0_slots && recs <= (int64_t)ctx->rec_cap) return KGMA_OK;
+        d0_slots = std::max(d0_slots, ctx->res_d0_slots);
+        recs = std::max<int64_t>(recs, ctx->rec_cap);
         int64_t cap = 0;
-        rc = dev_reserve(ctx, ctx->d_recs, cap, 1 << 16);
-        if (rc) return rc;
-        ctx->rec_cap = (unsigned int)cap;
-    }
+        uint8_t *fresh = nullptr;
+        const int64_t bytes = 16 + d0_slots * 8 + recs * (int64_t)sizeof(DevRecord);
+        int r2 = dev_reserve(ctx, fresh, cap, bytes);
+        if (r2) return r2;
+        if (ctx->d_res) { (void)hipFree(ctx->d_res); ctx->device_bytes -= ctx->res_bytes; }
+        ctx->d_res = fresh; ctx->res_bytes = cap; ctx->res_d0_slots = d0_slots; ctx->rec_cap = (unsigned int)recs;
+        return KGMA_OK;
+    };
+    rc = res_reserve(n_tiles * ctx->m, std::max<int64_t>(ctx->rec_cap, 1 << 16));
+    if (rc) return rc;
     if (want_dists)
         for (int j = 0; j < m_used; j++) {
             rc = dev_reserve(ctx, ctx->d_dist[(size_t)j], ctx->dist_cap[(size_t)j], std::max<int64_t>(1, dist_total));
@@ -810,7 +812,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         }
     // pinned staging: [meta 16 B][D0 n_tiles*m*8][first INLINE_RECS records]
     constexpr size_t INLINE_RECS = 4096;
-    const size_t d0_bytes = (size_t)n_tiles * (size_t)ctx->m * sizeof(int64_t);
+    const size_t d0_bytes = (size_t)ctx->res_d0_slots * sizeof(int64_t);
     const size_t pin_need = 16 + d0_bytes + INLINE_RECS * sizeof(DevRecord);
     if (pin_need > ctx->h_pin_cap) {
         if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -833,8 +835,10 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     const int64_t NB = (int64_t)1 << (2 * k);
     unsigned int n_recs = 0;
     for (int attempt = 0;; attempt++) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_rec_count, 0, sizeof(unsigned int), ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_n_att, 0, sizeof(unsigned long long), ctx->stream));
+        uint8_t *d_cnt = ctx->d_res;
+        int64_t *d_D0 = reinterpret_cast<int64_t *>(ctx->d_res + 16);
+        DevRecord *d_recs = reinterpret_cast<DevRecord *>(ctx->d_res + 16 + ctx->res_d0_slots * 8);
+        HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 16, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         ctx->stats.n_launches = 0;
         for (const Group &gr : groups) {
@@ -865,12 +869,12 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
                 a.planes = g->d_planes;
                 a.tiles = ctx->d_tiles;
                 a.Stab = ctx->d_Stab + (size_t)j0 * (size_t)NB;
-                a.D0out = ctx->d_D0 + (size_t)j0 * (size_t)n_tiles;
-                a.recs = ctx->d_recs;
-                a.rec_count = ctx->d_rec_count;
+                a.D0out = d_D0 + (size_t)j0 * (size_t)n_tiles;
+                a.recs = d_recs;
+                a.rec_count = reinterpret_cast<unsigned int *>(d_cnt);
                 a.rec_cap = ctx->rec_cap;
                 a.n_tiles = (int32_t)n_tiles;
-                a.n_att = ctx->d_n_att;
+                a.n_att = reinterpret_cast<unsigned long long *>(d_cnt + 8);
                 HIP_TRY(ctx, launch_scan(a, gp, ctx->kernel_version, ctx->stream));
                 ctx->stats.n_launches++;
                 i = jn;
@@ -879,10 +883,9 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         // everything the host needs comes back behind ONE synchronisation (records beyond the
         // inline block need a second copy; that only happens for dip-dense inputs)
-        HIP_TRY(ctx, hipMemcpyAsync(h_nrecs, ctx->d_rec_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(h_natt, ctx->d_n_att, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(h_D0, ctx->d_D0, d0_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(h_recs, ctx->d_recs, std::min<size_t>(INLINE_RECS, ctx->rec_cap) * sizeof(DevRecord),
+        // (the host mirror has the same layout: counters | D0 slots | records)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_res,
+                                    16 + (size_t)ctx->res_d0_slots * 8 + std::min<size_t>(INLINE_RECS, ctx->rec_cap) * sizeof(DevRecord),
                                     hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (g->pack_pending) {
@@ -894,10 +897,8 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         n_recs = *h_nrecs;
         if (n_recs <= ctx->rec_cap) break;
         if (attempt >= 4) return fail(ctx, KGMA_E_OVERFLOW, "record buffer overflow (%u records)", n_recs);
-        int64_t cap = ctx->rec_cap;
-        rc = dev_reserve(ctx, ctx->d_recs, cap, (int64_t)n_recs + (n_recs >> 2) + 1024);
+        rc = res_reserve(n_tiles * ctx->m, (int64_t)n_recs + (n_recs >> 2) + 1024);
         if (rc) return rc;
-        ctx->rec_cap = (unsigned int)cap;
     }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
@@ -909,7 +910,9 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     const size_t n_inline = std::min<size_t>(n_recs, INLINE_RECS);
     if (n_inline) memcpy(recs.data(), h_recs, n_inline * sizeof(DevRecord));
     if (n_recs > n_inline)
-        HIP_TRY(ctx, hipMemcpy(recs.data() + n_inline, ctx->d_recs + n_inline, ((size_t)n_recs - n_inline) * sizeof(DevRecord), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(recs.data() + n_inline,
+                               reinterpret_cast<DevRecord *>(ctx->d_res + 16 + ctx->res_d0_slots * 8) + n_inline,
+                               ((size_t)n_recs - n_inline) * sizeof(DevRecord), hipMemcpyDeviceToHost));
     ctx->D0.assign(h_D0, h_D0 + (size_t)n_tiles * (size_t)ctx->m);
     ctx->stats.n_at_threshold = (int64_t)*h_natt;
     ctx->have_dists = want_dists;
