@@ -36,14 +36,13 @@ struct ScanArgs {
     double *dist[KGMA_MAX_GROUP];
     unsigned long long *n_att;
 };
-size_t scan_lds_bytes(int k, int nk, int n_kfv);
 hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc *cd, int n_contigs,
                        int64_t total_words, unsigned long long *first_bad, hipStream_t st);
 hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int64_t total_words,
                         uint64_t seed, hipStream_t st);
-hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, int version, hipStream_t st);
-int scan_tile_stride_words(int version, int nk);
-int scan_nblocks(int version, int nk);
+hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, int R, hipStream_t st);
+int scan_tile_stride_words(int R, int nk);
+int scan_nblocks(int nk);
 }  // namespace kgma
 
 using namespace kgma;
@@ -98,9 +97,9 @@ struct kgma_ctx {
     uint64_t tk_uid = 0; int tk_mode = -1, tk_version = 0, tk_k = 0; int64_t tk_maxws = 0;
     // references
     int k = 0, m = 0;
-    int kernel_version = 3;
+    int kernel_version = 2;   // words per lane R of the scan kernel: 2 (default) or 4 (KGMA_R=4)
     std::vector<KfvInfo> kfv;
-    int32_t *d_Stab = nullptr;        // m x 4^k, plane-index order
+    int32_t *d_Stab = nullptr;        // m x 4^k, device index order (first base least significant)
     // scan scratch
     TileDesc *d_tiles = nullptr; int64_t tiles_cap = 0;
     // one device block: [counters 16 B: rec_count u32 @0, n_att u64 @8][D0: res_d0_slots int64][records]
@@ -160,15 +159,15 @@ int dev_reserve(kgma_ctx *ctx, T *&ptr, int64_t &cap, int64_t need)
     return KGMA_OK;
 }
 
-// natural k-mer value (first base most significant, 2 bits per base, Kmers.jl:37-43) ->
-// plane-order index used on the device: bit j = hi bit of base j, bit k+j = lo bit of base j.
-uint32_t plane_index_of(uint32_t v, int k)
+// natural k-mer value (first base most significant, 2 bits per base, Kmers.jl:37-43) -> index order
+// used on the device: the same 2-bit codes with the FIRST base least significant (the order in
+// which the 2-bit interleaved genome stream presents a k-mer).
+uint32_t device_index_of(uint32_t v, int k)
 {
     uint32_t idx = 0;
     for (int j = 0; j < k; j++) {
         const uint32_t code = (v >> (2 * (k - 1 - j))) & 3u;
-        idx |= (code >> 1) << j;
-        idx |= (code & 1u) << (k + j);
+        idx |= code << (2 * j);
     }
     return idx;
 }
@@ -254,7 +253,7 @@ int kgma_create(int device_ordinal, kgma_ctx **out)
     kgma_ctx *ctx = new (std::nothrow) kgma_ctx();
     if (!ctx) return KGMA_E_NOMEM;
     ctx->device = device_ordinal;
-    if (const char *kv = getenv("KGMA_KERNEL")) { const int v = atoi(kv); if (v >= 1 && v <= 4) ctx->kernel_version = v; }
+    if (const char *kv = getenv("KGMA_R")) { const int v = atoi(kv); if (v == 2 || v == 4) ctx->kernel_version = v; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreate(&ctx->evp0) != hipSuccess || hipEventCreate(&ctx->evp1) != hipSuccess) {
@@ -356,7 +355,7 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
     std::vector<int32_t> tab((size_t)m * (size_t)NB);
     for (int j = 0; j < m; j++)
         for (int64_t v = 0; v < NB; v++)
-            tab[(size_t)j * (size_t)NB + plane_index_of((uint32_t)v, k)] = (int32_t)kv[(size_t)j].S[(size_t)v];
+            tab[(size_t)j * (size_t)NB + device_index_of((uint32_t)v, k)] = (int32_t)kv[(size_t)j].S[(size_t)v];
     if (ctx->d_Stab) { (void)hipFree(ctx->d_Stab); ctx->d_Stab = nullptr; }
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_Stab), tab.size() * sizeof(int32_t)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_Stab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -854,7 +853,8 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
                 gp.n_kfv = (int32_t)(jn - i);
                 gp.k = k;
                 gp.nk = (int32_t)(gr.W - k + 1);
-                gp.nblocks = scan_nblocks(ctx->kernel_version, gp.nk);
+                gp.nblocks = scan_nblocks(gp.nk);
+                if (const char *ds = getenv("KGMA_DEBUG_SKIP")) gp.debug_skip = atoi(ds);   // timing experiments only
                 for (size_t u = i; u < jn; u++) {
                     const int j = gr.kfvs[u];
                     const KfvInfo &f = ctx->kfv[(size_t)j];

@@ -35,7 +35,9 @@ struct GroupParams {
     int32_t n_kfv;                       // KFVs in this group (<= KGMA_MAX_GROUP)
     int32_t k;                           // k-mer length
     int32_t nk;                          // k-mers per window = W - k + 1
-    int32_t nblocks;                     // ceil(nk / 16): 16-offset blocks of the match loop
+    int32_t nblocks;                     // 16-offset blocks of the match loop
+    int32_t debug_skip;                  // timing experiments only (bit 0: no match loop, bit 1: no position phase); 0 in product use
+    int32_t pad0;
     int32_t kfv_id[KGMA_MAX_GROUP];      // 1-based KFV index reported in records
     int32_t N[KGMA_MAX_GROUP];           // reference count of each KFV
     int64_t T[KGMA_MAX_GROUP];           // integer threshold: d < thr  <=>  D < T

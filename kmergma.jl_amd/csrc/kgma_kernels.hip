@@ -243,292 +243,8 @@ struct ScanArgs {
     unsigned long long *n_att;      // stats: windows with D == T
 };
 
-template <int K>
-__global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupParams gp)
-{
-    constexpr int R = KGMA_R;
-    constexpr int NP = KGMA_NPLANES;
-    constexpr int NB = 1 << (2 * K);
-    extern __shared__ uint32_t smem[];
-
-    const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
-    const TileDesc td = a.tiles[tile];
-    const int nk = gp.nk;
-    const int NW = KGMA_TILE_WORDS + scan_pad_words(nk);
-
-    uint32_t *sH = smem;
-    uint32_t *sL = sH + NW;
-    int32_t *sS = reinterpret_cast<int32_t *>(sL + NW);
-    int32_t *sHist = sS + gp.n_kfv * NB;
-    int32_t *sMisc = sHist + NB;                 // [0..15] scan scratch, [16..271] per-lane flags
-    int64_t *sRed = reinterpret_cast<int64_t *>(sMisc + 16 + KGMA_THREADS);   // 8-byte aligned
-
-    // ---- stage the tile's bit-planes and the S tables in LDS --------------------------------
-    {
-        const uint2 *g2 = reinterpret_cast<const uint2 *>(a.planes) + td.word_base;
-        for (int w = tid; w < NW; w += KGMA_THREADS) {
-            const uint2 v = g2[w];
-            sH[w] = v.x;
-            sL[w] = v.y;
-        }
-        for (int i = tid; i < gp.n_kfv * NB; i += KGMA_THREADS) sS[i] = a.Stab[i];
-        for (int i = tid; i < NB; i += KGMA_THREADS) sHist[i] = 0;
-    }
-    __syncthreads();
-
-    // ---- D of the tile's first window, directly: histogram of its nk k-mers ------------------
-    // (Kmers.jl:33-44 kmer_count! + the sqeuclidean call sites GenomeMiner.jl:46-47,
-    //  OmnGenomeMiner.jl:73-74, in exact integers)
-    for (int q = tid; q < nk; q += KGMA_THREADS) {
-        const int w = q >> 5;
-        const uint32_t idx = plane_index<K>(sH[w], sH[w + 1], sL[w], sL[w + 1], (uint32_t)(q & 31));
-        atomicAdd(&sHist[idx], 1);
-    }
-    __syncthreads();
-    for (int j = 0; j < gp.n_kfv; j++) {
-        int64_t acc = 0;
-        const int64_t Nj = gp.N[j];
-        for (int x = tid; x < NB; x += KGMA_THREADS) {
-            const int64_t d = (int64_t)sS[j * NB + x] - Nj * (int64_t)sHist[x];
-            acc += d * d;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) acc += shfl_down_i64(acc, d);
-        if ((tid & 63) == 0) sRed[tid >> 6] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            const int64_t D0 = sRed[0] + sRed[1] + sRed[2] + sRed[3];
-            a.D0out[(size_t)j * a.n_tiles + tile] = D0;
-            sRed[4 + j] = D0;
-        }
-        __syncthreads();
-    }
-
-    // ---- anchors: planes at offset 0 (leaving k-mer) and at offset nk (entering k-mer) -------
-    const int w0 = R * tid;
-    uint32_t A0h[R + 2], A0l[R + 2], Anh[R + 2], Anl[R + 2];
-    {
-        const int jn = nk >> 5;
-        const uint32_t sn = (uint32_t)(nk & 31);
-#pragma unroll
-        for (int w = 0; w < R + 2; w++) {
-            A0h[w] = sH[w0 + w];
-            A0l[w] = sL[w0 + w];
-            Anh[w] = alignbit(sH[w0 + jn + w + 1], sH[w0 + jn + w], sn);
-            Anl[w] = alignbit(sL[w0 + jn + w + 1], sL[w0 + jn + w], sn);
-        }
-    }
-
-    // ---- match loop: offsets o = 0 .. 16*nblocks-1, two directions, R words per lane ---------
-    Counter cf[R], cb[R];
-#pragma unroll
-    for (int w = 0; w < R; w++) {
-#pragma unroll
-        for (int p = 0; p < NP; p++) { cf[w].c[p] = 0; cb[w].c[p] = 0; }
-        cf[w].p0 = cf[w].p1 = cf[w].p2 = cf[w].p3 = 0;
-        cb[w].p0 = cb[w].p1 = cb[w].p2 = cb[w].p3 = 0;
-    }
-
-    for (int blk = 0; blk < gp.nblocks; blk++) {
-        const int jw = blk >> 1;
-        const uint32_t s0 = (uint32_t)(blk & 1) << 4;
-        uint32_t Xh[R + 2], Xl[R + 2];
-#pragma unroll
-        for (int w = 0; w < R + 2; w++) {
-            Xh[w] = sH[w0 + jw + w];
-            Xl[w] = sL[w0 + jw + w];
-        }
-        const int obase = blk << 4;
-
-#define KGMA_STEP(I)                                                                       \
-        {                                                                                  \
-            const uint32_t s = s0 + (I);                                                   \
-            const uint32_t force = (obase + (I)) >= nk ? 0xFFFFFFFFu : 0u;                 \
-            uint32_t f1[R + 1], b1[R + 1];                                                 \
-            _Pragma("unroll") for (int w = 0; w <= R; w++) {                               \
-                const uint32_t xh = alignbit(Xh[w + 1], Xh[w], s);                         \
-                const uint32_t xl = alignbit(Xl[w + 1], Xl[w], s);                         \
-                f1[w] = (xh ^ A0h[w]) | (xl ^ A0l[w]);                                     \
-                b1[w] = (xh ^ Anh[w]) | (xl ^ Anl[w]);                                     \
-            }                                                                              \
-            uint32_t mf[R], mb[R];                                                         \
-            kmer_mismatch<K, R>(f1, force, mf);                                            \
-            kmer_mismatch<K, R>(b1, force, mb);                                            \
-            _Pragma("unroll") for (int w = 0; w < R; w++) {                                \
-                counter_add<I>(cf[w], mf[w]);                                              \
-                counter_add<I>(cb[w], mb[w]);                                              \
-            }                                                                              \
-        }
-        KGMA_STEP(0) KGMA_STEP(1) KGMA_STEP(2) KGMA_STEP(3)
-        KGMA_STEP(4) KGMA_STEP(5) KGMA_STEP(6) KGMA_STEP(7)
-        KGMA_STEP(8) KGMA_STEP(9) KGMA_STEP(10) KGMA_STEP(11)
-        KGMA_STEP(12) KGMA_STEP(13) KGMA_STEP(14) KGMA_STEP(15)
-#undef KGMA_STEP
-    }
-
-    // ---- diff = fwd - back = (cb - cf) - mm0, bit-sliced two's complement, NP+1 planes --------
-    // mismatch counts: cf = (nk-1) - fwd + forced, cb = (nk-1) - back + forced + mm0 where mm0 is
-    // the offset-0 mask of the back direction (K_q != K_{q+nk}); forced terms cancel.
-    uint32_t dpl[R][NP + 1];
-    {
-        uint32_t b0[R + 1], mm0[R];
-#pragma unroll
-        for (int w = 0; w <= R; w++) b0[w] = (A0h[w] ^ Anh[w]) | (A0l[w] ^ Anl[w]);
-        kmer_mismatch<K, R>(b0, 0u, mm0);
-#pragma unroll
-        for (int w = 0; w < R; w++) {
-            uint32_t bw = mm0[w];
-#pragma unroll
-            for (int p = 0; p < NP; p++) {
-                const uint32_t x = cb[w].c[p], y = cf[w].c[p];
-                const uint32_t u = x ^ y;
-                dpl[w][p] = u ^ bw;
-                bw = (y & u) | (bw & ~u);
-            }
-            dpl[w][NP] = bw;   // sign plane
-        }
-    }
-
-    // ---- position phase, per KFV of the group -------------------------------------------------
-    const int n_valid = td.n_valid;
-    const int first_test = td.first_test;
-    const int lim = n_valid - 1;              // roll q -> q+1 exists for q < lim
-    const int qa = 32 * w0;                   // first local position of this lane
-    int32_t *sScan = sMisc;                   // [0..3] wave totals, [4] spare
-    int32_t *sPrev = sMisc + 16;              // KGMA_THREADS ints
-
-    // walks the lane's 32*R positions in order, calling body(q, e_q) with e_q the integer roll
-    // delta (D_{q+1}-D_q)/(2N) of KFV slot j
-    auto walk = [&](int j, auto &&body) {
-        const int32_t *S = sS + j * NB;
-        const int32_t Nj = gp.N[j];
-#pragma unroll
-        for (int w = 0; w < R; w++) {
-            for (uint32_t b = 0; b < 32; b++) {
-                uint32_t v = (dpl[w][0] >> b) & 1u;
-#pragma unroll
-                for (int p = 1; p <= NP; p++) v |= ((dpl[w][p] >> b) & 1u) << p;
-                const int32_t diff = ((int32_t)(v << (31 - NP))) >> (31 - NP);   // sign-extend NP+1 bits
-                const uint32_t il = plane_index<K>(A0h[w], A0h[w + 1], A0l[w], A0l[w + 1], b);
-                const uint32_t ir = plane_index<K>(Anh[w], Anh[w + 1], Anl[w], Anl[w + 1], b);
-                const int q = qa + 32 * w + (int)b;
-                int32_t e = S[il] - S[ir] - Nj * diff;
-                e = q < lim ? e : 0;
-                body(q, e);
-            }
-        }
-    };
-
-    for (int j = 0; j < gp.n_kfv; j++) {
-        const int64_t D0 = sRed[4 + j];
-        const int64_t twoN = 2 * (int64_t)gp.N[j];
-        // E_q < TE  <=>  D0 + 2N E_q < T
-        int64_t TE64;
-        bool t_exact;
-        {
-            const int64_t num = gp.T[j] - D0;
-            TE64 = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
-            t_exact = (num % twoN) == 0;
-            if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; t_exact = false; }
-            if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; t_exact = false; }
-        }
-        const int32_t TE = (int32_t)TE64;
-
-        // pass A: lane-local prefix, its minimum over tested positions, and the lane total
-        int32_t r = 0, rmin = 0x7FFFFFFF, rlast = 0;
-        walk(j, [&](int q, int32_t e) {
-            const bool testable = q >= first_test && q < n_valid;
-            rmin = testable ? (r < rmin ? r : rmin) : rmin;
-            rlast = r;
-            r += e;
-        });
-        const int32_t total = r;
-
-        // workgroup exclusive scan of the lane totals
-        int32_t incl = total;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int32_t t = __shfl_up(incl, d);
-            if ((tid & 63) >= d) incl += t;
-        }
-        if ((tid & 63) == 63) sScan[tid >> 6] = incl;
-        __syncthreads();
-        int32_t offset = incl - total;
-        for (int wv = 0; wv < (tid >> 6); wv++) offset += sScan[wv];
-
-        const int qb = qa + 32 * R - 1;
-        const bool last_testable = qb >= first_test && qb < n_valid;
-        const bool last_under = last_testable && (offset + rlast < TE);
-        sPrev[tid] = last_under ? 1 : 0;
-        __syncthreads();
-        const bool prev_under = tid > 0 && sPrev[tid - 1] != 0;
-        double *dist = a.dist[j];
-        const bool any_under = rmin != 0x7FFFFFFF && (offset + rmin < TE + (t_exact ? 1 : 0));
-        const bool need = (any_under || prev_under || dist != nullptr) && qa < n_valid;
-
-        if (need) {
-            // pass B: walk again with the absolute prefix and emit the dip fragments of this lane
-            const int slot = gp.kfv_id[j];
-            bool in_run = false;
-            int32_t run_start = 0, minE = 0, argf = 0, argl = 0, nmin = 0;
-            int32_t E = offset;
-            const double scale = gp.inv_scale[j];
-            walk(j, [&](int q, int32_t e) {
-                const bool testable = q >= first_test && q < n_valid;
-                const bool under = testable && E < TE;
-                if (testable && dist != nullptr)
-                    dist[td.dist_base + q] = (double)(D0 + twoN * (int64_t)E) / scale;
-                if (under) {
-                    if (!in_run) {
-                        in_run = true; run_start = q; minE = E; argf = argl = q; nmin = 1;
-                    } else if (E < minE) {
-                        minE = E; argf = argl = q; nmin = 1;
-                    } else if (E == minE) {
-                        argl = q; nmin++;
-                    }
-                } else {
-                    if (in_run) {
-                        DevRecord rec;
-                        rec.tile = tile; rec.kind_kfv = REC_RUN | (slot << 8);
-                        rec.start = run_start; rec.end = q - 1; rec.minE = minE;
-                        rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
-                        rec.exitE = E; rec.has_exit = q < n_valid ? 1 : 0;
-                        emit_record(a.recs, a.rec_count, a.rec_cap, rec);
-                        in_run = false;
-                    } else if (q == qa && prev_under && q < n_valid) {
-                        DevRecord rec;
-                        rec.tile = tile; rec.kind_kfv = REC_EXIT | (slot << 8);
-                        rec.start = q; rec.end = q; rec.minE = E;
-                        rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 1;
-                        emit_record(a.recs, a.rec_count, a.rec_cap, rec);
-                    }
-                    if (t_exact && testable && E == TE) {
-                        DevRecord rec;
-                        rec.tile = tile; rec.kind_kfv = REC_ATT | (slot << 8);
-                        rec.start = q; rec.end = q; rec.minE = E;
-                        rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
-                        emit_record(a.recs, a.rec_count, a.rec_cap, rec);
-                        atomicAdd(a.n_att, 1ull);
-                    }
-                }
-                E += e;
-            });
-            if (in_run) {
-                DevRecord rec;
-                rec.tile = tile; rec.kind_kfv = REC_RUN | (slot << 8);
-                rec.start = run_start; rec.end = qb; rec.minE = minE;
-                rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
-                rec.exitE = 0; rec.has_exit = 0;
-                emit_record(a.recs, a.rec_count, a.rec_cap, rec);
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// Scan kernel, version 2: one mask family for both directions, halo words by DPP.
+// Scan kernel: one mask family for both directions, halo words by DPP.
 //
 // F_o[p] = [K_p != K_{p+o}] is computed once per offset.  fwd_q sums F_o[q] in place; the back
 // count of the k-mer entering at p = q + nk is  sum_o F_o[p - o], i.e. the SAME masks shifted by
@@ -581,6 +297,37 @@ __device__ __forceinline__ void counter6_add(Counter6 &s, uint32_t m)
     s.c[5] ^= t;      // a group holds at most 32 masks: no carry out of plane 5
 }
 
+// spread the 16 low bits of x to the even bit positions
+__device__ __forceinline__ uint32_t spread16(uint32_t x)
+{
+    x &= 0xFFFFu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+// 2-bit interleave of one {hi,lo} word pair: stream bit 2i = lo bit i, bit 2i+1 = hi bit i, so the
+// 2K bits starting at bit 2p are the k-mer at p with its first base least significant -- the index
+// order of the S tables on the device (the host permutes them).
+__device__ __forceinline__ void interleave32(uint32_t h, uint32_t l, uint32_t &out0, uint32_t &out1)
+{
+    out0 = spread16(l) | (spread16(h) << 1);
+    out1 = spread16(l >> 16) | (spread16(h >> 16) << 1);
+}
+
+template <int K>
+__device__ __forceinline__ uint32_t kmer_index_at(const uint32_t *sH, const uint32_t *sL, int pos)
+{
+    const int w = pos >> 5;
+    const uint32_t b = (uint32_t)(pos & 31);
+    constexpr uint32_t km = (1u << K) - 1u;
+    const uint32_t hh = alignbit(sH[w + 1], sH[w], b) & km;
+    const uint32_t ll = alignbit(sL[w + 1], sL[w], b) & km;
+    return spread16(ll) | (spread16(hh) << 1);
+}
+
 // value of `x` in the next lane (lane 63 receives 0; its results are never used)
 __device__ __forceinline__ uint32_t from_next_lane(uint32_t x)
 {
@@ -588,7 +335,7 @@ __device__ __forceinline__ uint32_t from_next_lane(uint32_t x)
 }
 
 template <int K, int R>
-__global__ __launch_bounds__(KGMA_THREADS) void scan_kernel_v2(ScanArgs a, GroupParams gp)
+__global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupParams gp)
 {
     constexpr int NP = KGMA_NPLANES;
     constexpr int NB = 1 << (2 * K);
@@ -606,6 +353,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel_v2(ScanArgs a, Group
     const int nk = gp.nk;
     const int nblocks = gp.nblocks;
     const int np = 16 * nblocks - 1;
+    const int nblocks_run = (gp.debug_skip & 1) ? 0 : nblocks;
     const int delta = np - nk;                   // 0..15
     const int NW = TW + scan_pad_words(nk);
 
@@ -633,10 +381,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel_v2(ScanArgs a, Group
 
     // ---- D of the tile's first window: histogram of its nk k-mers -----------------------------
     for (int q = tid; q < nk; q += KGMA_THREADS) {
-        const int pos = 32 * LH + q;
-        const int w = pos >> 5;
-        const uint32_t idx = plane_index<K>(sH[w], sH[w + 1], sL[w], sL[w + 1], (uint32_t)(pos & 31));
-        atomicAdd(&sHist[idx], 1);
+        atomicAdd(&sHist[kmer_index_at<K>(sH, sL, 32 * LH + q)], 1);
     }
     __syncthreads();
     for (int j = 0; j < gp.n_kfv; j++) {
@@ -754,8 +499,8 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel_v2(ScanArgs a, Group
     // only the last two blocks can contain offsets >= nk (forced mismatches)
     {
         int blk = 0;
-        for (; blk < nblocks - 2; blk++) run_block(blk, std::false_type{});
-        for (; blk < nblocks; blk++) run_block(blk, std::true_type{});
+        for (; blk < nblocks_run - 2; blk++) run_block(blk, std::false_type{});
+        for (; blk < nblocks_run; blk++) run_block(blk, std::true_type{});
     }
 
     // ---- bring TB from coordinates v = q - delta to window coordinates q ------------------------
@@ -785,44 +530,86 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel_v2(ScanArgs a, Group
     }
 
     // ---- position phase; local window q = 32*(R*slot - LH + w) + b -----------------------------
-    uint32_t Anh[R + 1], Anl[R + 1];
+    // k-mer indices come from 2-bit interleaved copies of the two anchors (offset 0: leaving
+    // k-mer, offset nk: entering k-mer): 12 index bits = one alignbit + one and.
+    uint32_t IL[R + 1][2], IR[R + 1][2];
     {
         const int jn = nk >> 5;
         const uint32_t sn = (uint32_t)(nk & 31);
 #pragma unroll
-        for (int w = 0; w < R + 1; w++) {
-            Anh[w] = alignbit(sH[w0 + jn + w + 1], sH[w0 + jn + w], sn);
-            Anl[w] = alignbit(sL[w0 + jn + w + 1], sL[w0 + jn + w], sn);
+        for (int w = 0; w < R; w++) {
+            interleave32(A0h[w], A0l[w], IL[w][0], IL[w][1]);
+            const uint32_t anh = alignbit(sH[w0 + jn + w + 1], sH[w0 + jn + w], sn);
+            const uint32_t anl = alignbit(sL[w0 + jn + w + 1], sL[w0 + jn + w], sn);
+            interleave32(anh, anl, IR[w][0], IR[w][1]);
         }
+        IL[R][0] = from_next_lane(IL[0][0]); IL[R][1] = 0;
+        IR[R][0] = from_next_lane(IR[0][0]); IR[R][1] = 0;
     }
     const int n_valid = td.n_valid;
     const int first_test = td.first_test;
     const int lim = n_valid - 1;
     const int qa = 32 * (w0 - LH);
+    const int qb = qa + 32 * R - 1;
     int32_t *sScan = sMisc;
     int32_t *sPrev = sMisc + 16;
 
-    auto walk = [&](int j, auto &&body) {
+    // wave-uniform fast paths: every |fwd-back| < 8 (4 planes instead of NP+1), and every lane of
+    // the wave strictly inside the tested range (no per-position validity predicates)
+    bool small_w, interior_w;
+    {
+        uint32_t ns = 0;
+#pragma unroll
+        for (int w = 0; w < R; w++)
+#pragma unroll
+            for (int p = 3; p < NP; p++) ns |= dpl[w][p] ^ dpl[w][NP];
+        small_w = __ballot(ns != 0) == 0ull;
+        const bool inside = qa >= first_test && qa >= 0 && qb < lim;
+        interior_w = __ballot(!inside) == 0ull;
+    }
+
+    // walks the lane's 32*R positions in order, calling body(q, e_q) with e_q the integer roll
+    // delta (D_{q+1}-D_q)/(2N) of KFV slot j
+    auto walk = [&](int j, auto small_tag, auto interior_tag, auto &&body) {
+        constexpr bool SMALL = decltype(small_tag)::value;
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
+        constexpr uint32_t IM = (1u << (2 * K)) - 1u;
         const int32_t *S = sS + j * NB;
         const int32_t Nj = gp.N[j];
 #pragma unroll
         for (int w = 0; w < R; w++) {
-            for (uint32_t b = 0; b < 32; b++) {
-                uint32_t v = (dpl[w][0] >> b) & 1u;
 #pragma unroll
-                for (int p = 1; p <= NP; p++) v |= ((dpl[w][p] >> b) & 1u) << p;
-                const int32_t diff = ((int32_t)(v << (31 - NP))) >> (31 - NP);
-                const uint32_t il = plane_index<K>(A0h[w], A0h[w + 1], A0l[w], A0l[w + 1], b);
-                const uint32_t ir = plane_index<K>(Anh[w], Anh[w + 1], Anl[w], Anl[w + 1], b);
-                const int q = qa + 32 * w + (int)b;
-                int32_t e = S[il] - S[ir] - Nj * diff;
-                e = (q >= 0 && q < lim) ? e : 0;
-                body(q, e);
+            for (int half = 0; half < 2; half++) {
+                const uint32_t l0 = half ? IL[w][1] : IL[w][0], l1 = half ? IL[w + 1][0] : IL[w][1];
+                const uint32_t r0 = half ? IR[w][1] : IR[w][0], r1 = half ? IR[w + 1][0] : IR[w][1];
+#pragma unroll 1
+                for (uint32_t bb = 0; bb < 16; bb++) {
+                    const uint32_t b = 16u * half + bb;
+                    const uint32_t il = alignbit(l1, l0, 2u * bb) & IM;
+                    const uint32_t ir = alignbit(r1, r0, 2u * bb) & IM;
+                    int32_t diff;
+                    if constexpr (SMALL) {
+                        uint32_t v = (dpl[w][0] >> b) & 1u;
+                        v |= ((dpl[w][1] >> b) & 1u) << 1;
+                        v |= ((dpl[w][2] >> b) & 1u) << 2;
+                        const int32_t sg = ((int32_t)(dpl[w][NP] << (31u - b))) >> 31;   // 0 or -1
+                        diff = (int32_t)((uint32_t)(sg << 3) | v);
+                    } else {
+                        uint32_t v = (dpl[w][0] >> b) & 1u;
+#pragma unroll
+                        for (int p = 1; p <= NP; p++) v |= ((dpl[w][p] >> b) & 1u) << p;
+                        diff = ((int32_t)(v << (31 - NP))) >> (31 - NP);
+                    }
+                    const int q = qa + 32 * w + (int)b;
+                    int32_t e = S[il] - S[ir] - Nj * diff;
+                    if constexpr (!INTERIOR) e = (q >= 0 && q < lim) ? e : 0;
+                    body(q, e);
+                }
             }
         }
     };
 
-    for (int j = 0; j < gp.n_kfv; j++) {
+    for (int j = 0; j < ((gp.debug_skip & 2) ? 0 : gp.n_kfv); j++) {
         const int64_t D0 = sRed[4 + j];
         const int64_t twoN = 2 * (int64_t)gp.N[j];
         int64_t TE64;
@@ -836,19 +623,25 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel_v2(ScanArgs a, Group
         }
         const int32_t TE = (int32_t)TE64;
 
+        // pass A: lane-local prefix, its minimum over tested positions, and the lane total
         int32_t r = 0, rmin = 0x7FFFFFFF, rlast = 0;
-#ifndef KGMA_TIMING_SKIP_PASS_A
-        walk(j, [&](int q, int32_t e) {
-            const bool testable = q >= first_test && q < n_valid;
-            rmin = testable ? (r < rmin ? r : rmin) : rmin;
-            rlast = r;
-            r += e;
-        });
-#else
-        r = (int32_t)(dpl[0][0] ^ dpl[R - 1][NP] ^ dpl[0][3]);   // keep the match loop alive
-#endif
+        if (interior_w) {
+            auto bodyA = [&](int, int32_t e) { rmin = r < rmin ? r : rmin; rlast = r; r += e; };
+            if (small_w) walk(j, std::true_type{}, std::true_type{}, bodyA);
+            else walk(j, std::false_type{}, std::true_type{}, bodyA);
+        } else {
+            auto bodyA = [&](int q, int32_t e) {
+                const bool testable = q >= first_test && q < n_valid;
+                rmin = testable ? (r < rmin ? r : rmin) : rmin;
+                rlast = r;
+                r += e;
+            };
+            if (small_w) walk(j, std::true_type{}, std::false_type{}, bodyA);
+            else walk(j, std::false_type{}, std::false_type{}, bodyA);
+        }
         const int32_t total = dup ? 0 : r;
 
+        // workgroup exclusive scan of the lane totals (slot order = wave order)
         int32_t incl = total;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -860,7 +653,6 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel_v2(ScanArgs a, Group
         int32_t offset = incl - total;
         for (int wv = 0; wv < wave; wv++) offset += sScan[wv];
 
-        const int qb = qa + 32 * R - 1;
         const bool last_testable = qb >= first_test && qb < n_valid;
         const bool last_under = last_testable && (offset + rlast < TE);
         if (!dup) sPrev[slot] = last_under ? 1 : 0;
@@ -871,12 +663,13 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel_v2(ScanArgs a, Group
         const bool need = !dup && (any_under || prev_under || dist != nullptr) && qb >= 0 && qa < n_valid;
 
         if (need) {
+            // pass B (rare): walk again with the absolute prefix and emit this lane's dip fragments
             const int kid = gp.kfv_id[j];
             bool in_run = false;
             int32_t run_start = 0, minE = 0, argf = 0, argl = 0, nmin = 0;
             int32_t E = offset;
             const double scale = gp.inv_scale[j];
-            walk(j, [&](int q, int32_t e) {
+            walk(j, std::false_type{}, std::false_type{}, [&](int q, int32_t e) {
                 const bool testable = q >= first_test && q < n_valid;
                 const bool under = testable && E < TE;
                 if (testable && dist != nullptr)
@@ -932,7 +725,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel_v2(ScanArgs a, Group
 // ------------------------------------------------------------------------------------------
 // launch wrappers (called from kgma_api.cpp)
 // ------------------------------------------------------------------------------------------
-size_t scan_lds_bytes_v2(int k, int nk, int n_kfv, int R)
+size_t scan_lds_bytes(int k, int nk, int n_kfv, int R)
 {
     const size_t TW = (size_t)V2_SLOTS * R;
     const size_t NW = TW + scan_pad_words(nk);
@@ -942,19 +735,9 @@ size_t scan_lds_bytes_v2(int k, int nk, int n_kfv, int R)
     return (2 * NW + (size_t)n_kfv * NB + xsize + 16 + KGMA_THREADS) * 4 + (4 + KGMA_MAX_GROUP) * 8 + 64;
 }
 
-// kernel variants: 1 = scan_kernel (R=4, masks rebuilt per direction); 2 = scan_kernel_v2<R=4>; 3 = scan_kernel_v2<R=2>
-int scan_tile_stride_words(int version, int nk)
-{
-    return version == 2 ? v2_stride_words(nk, 4) : version == 3 ? v2_stride_words(nk, 2) : version == 4 ? v2_stride_words(nk, 3) : KGMA_TILE_WORDS;
-}
-int scan_nblocks(int version, int nk) { return version >= 2 ? v2_nblocks(nk) : (nk + 15) / 16; }
-
-size_t scan_lds_bytes(int k, int nk, int n_kfv)
-{
-    const size_t NW = KGMA_TILE_WORDS + scan_pad_words(nk);
-    const size_t NB = (size_t)1 << (2 * k);
-    return (2 * NW + (size_t)n_kfv * NB + NB + 16 + KGMA_THREADS) * 4 + (4 + KGMA_MAX_GROUP) * 8 + 64;
-}
+// words per lane R: 2 (default) or 4
+int scan_tile_stride_words(int R, int nk) { return v2_stride_words(nk, R); }
+int scan_nblocks(int nk) { return v2_nblocks(nk); }
 
 hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc *cd, int n_contigs,
                        int64_t total_words, unsigned long long *first_bad, hipStream_t st)
@@ -978,57 +761,35 @@ hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int
     return hipGetLastError();
 }
 
-template <int K>
-static hipError_t launch_scan_k(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
-{
-    const size_t lds = scan_lds_bytes(K, gp.nk, gp.n_kfv);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(scan_kernel<K>, dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
-    return hipGetLastError();
-}
-
 template <int K, int R>
-static hipError_t launch_scan_v2_k(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+static hipError_t launch_scan_kr(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
 {
-    const size_t lds = scan_lds_bytes_v2(K, gp.nk, gp.n_kfv, R);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel_v2<K, R>),
+    const size_t lds = scan_lds_bytes(K, gp.nk, gp.n_kfv, R);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K, R>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((scan_kernel_v2<K, R>), dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
+    hipLaunchKernelGGL((scan_kernel<K, R>), dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
     return hipGetLastError();
 }
 
 template <int R>
-static hipError_t launch_scan_v2_r(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+static hipError_t launch_scan_r(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
 {
     switch (gp.k) {
-    case 2: return launch_scan_v2_k<2, R>(a, gp, st);
-    case 3: return launch_scan_v2_k<3, R>(a, gp, st);
-    case 4: return launch_scan_v2_k<4, R>(a, gp, st);
-    case 5: return launch_scan_v2_k<5, R>(a, gp, st);
-    case 6: return launch_scan_v2_k<6, R>(a, gp, st);
-    case 7: return launch_scan_v2_k<7, R>(a, gp, st);
+    case 2: return launch_scan_kr<2, R>(a, gp, st);
+    case 3: return launch_scan_kr<3, R>(a, gp, st);
+    case 4: return launch_scan_kr<4, R>(a, gp, st);
+    case 5: return launch_scan_kr<5, R>(a, gp, st);
+    case 6: return launch_scan_kr<6, R>(a, gp, st);
+    case 7: return launch_scan_kr<7, R>(a, gp, st);
     default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, int version, hipStream_t st)
+hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, int R, hipStream_t st)
 {
     if (a.n_tiles <= 0) return hipSuccess;
-    if (version == 2) return launch_scan_v2_r<4>(a, gp, st);
-    if (version == 3) return launch_scan_v2_r<2>(a, gp, st);
-    if (version == 4) return launch_scan_v2_r<3>(a, gp, st);
-    switch (gp.k) {
-    case 2: return launch_scan_k<2>(a, gp, st);
-    case 3: return launch_scan_k<3>(a, gp, st);
-    case 4: return launch_scan_k<4>(a, gp, st);
-    case 5: return launch_scan_k<5>(a, gp, st);
-    case 6: return launch_scan_k<6>(a, gp, st);
-    case 7: return launch_scan_k<7>(a, gp, st);
-    default: return hipErrorInvalidValue;
-    }
+    return R == 4 ? launch_scan_r<4>(a, gp, st) : launch_scan_r<2>(a, gp, st);
 }
 
 }  // namespace kgma
