@@ -40,8 +40,8 @@ hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc 
                        int64_t total_words, unsigned long long *first_bad, hipStream_t st);
 hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int64_t total_words,
                         uint64_t seed, hipStream_t st);
-hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, int R, hipStream_t st);
-int scan_tile_stride_words(int R, int nk);
+hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
+int scan_tile_stride_words(int nk);
 int scan_nblocks(int nk);
 }  // namespace kgma
 
@@ -51,7 +51,7 @@ namespace {
 
 constexpr int64_t CONTIG_PAD_WORDS = 32;
 constexpr int64_t LEAD_PAD_WORDS = 8;
-constexpr int64_t TAIL_PAD_WORDS = KGMA_TILE_WORDS + 64;
+constexpr int64_t TAIL_PAD_WORDS = KGMA_TILE_WORDS + 128;
 constexpr unsigned long long NO_BAD = ~0ull;
 
 struct KfvInfo {
@@ -97,7 +97,7 @@ struct kgma_ctx {
     uint64_t tk_uid = 0; int tk_mode = -1, tk_version = 0, tk_k = 0; int64_t tk_maxws = 0;
     // references
     int k = 0, m = 0;
-    int kernel_version = 2;   // words per lane R of the scan kernel: 2 (default) or 4 (KGMA_R=4)
+    int kernel_version = 1;   // bumped when the tile geometry changes (part of the tile-cache key)
     std::vector<KfvInfo> kfv;
     int32_t *d_Stab = nullptr;        // m x 4^k, device index order (first base least significant)
     // scan scratch
@@ -253,7 +253,6 @@ int kgma_create(int device_ordinal, kgma_ctx **out)
     kgma_ctx *ctx = new (std::nothrow) kgma_ctx();
     if (!ctx) return KGMA_E_NOMEM;
     ctx->device = device_ordinal;
-    if (const char *kv = getenv("KGMA_R")) { const int v = atoi(kv); if (v == 2 || v == 4) ctx->kernel_version = v; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreate(&ctx->evp0) != hipSuccess || hipEventCreate(&ctx->evp1) != hipSuccess) {
@@ -684,7 +683,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     const int k = ctx->k, m_used = mode == KGMA_MODE_SINGLE ? 1 : ctx->m;
     int64_t maxws = 0;
     for (int j = 0; j < m_used; j++) maxws = std::max(maxws, ctx->kfv[(size_t)j].W);
-    const int64_t stride_words = scan_tile_stride_words(ctx->kernel_version, (int)(maxws - k + 1));
+    const int64_t stride_words = scan_tile_stride_words((int)(maxws - k + 1));
     const int64_t P = stride_words * 32;
     const int64_t nc = g->n_contigs;
     const bool want_dists = (flags & KGMA_F_RETURN_DISTS) != 0;
@@ -875,7 +874,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
                 a.rec_cap = ctx->rec_cap;
                 a.n_tiles = (int32_t)n_tiles;
                 a.n_att = reinterpret_cast<unsigned long long *>(d_cnt + 8);
-                HIP_TRY(ctx, launch_scan(a, gp, ctx->kernel_version, ctx->stream));
+                HIP_TRY(ctx, launch_scan(a, gp, ctx->stream));
                 ctx->stats.n_launches++;
                 i = jn;
             }

@@ -5,18 +5,17 @@
 
 namespace kgma {
 
-// Geometry of one scan tile: a workgroup of KGMA_THREADS lanes, each owning KGMA_R consecutive
-// 32-window words, i.e. KGMA_TILE_WINDOWS consecutive window starts of one record.
+// Geometry of one scan tile: a workgroup of KGMA_THREADS lanes (4 waves); 253 distinct lane slots
+// each own KGMA_R consecutive 32-window words of one record (kgma_kernels.hip explains the halos).
 constexpr int KGMA_THREADS = 256;
-#ifndef KGMA_R_VALUE
-#define KGMA_R_VALUE 4
-#endif
-constexpr int KGMA_R = KGMA_R_VALUE;
-constexpr int KGMA_TILE_WORDS = KGMA_THREADS * KGMA_R;        // 1024 words
-constexpr int KGMA_TILE_WINDOWS = KGMA_TILE_WORDS * 32;        // 32768 window starts
+constexpr int KGMA_R = 2;
+constexpr int KGMA_TILE_WORDS = 253 * KGMA_R;                 // words covered by one tile (incl. halos)
+constexpr int KGMA_TILE_WINDOWS = KGMA_TILE_WORDS * 32;
 constexpr int KGMA_MAX_GROUP = 8;                              // KFVs of one window size per launch
-constexpr int KGMA_NPLANES = 9;                                // bit-sliced counter width
-constexpr int KGMA_MAX_NK = 16 * 31 - 1;                       // max k-mers per window (counter range)
+constexpr int KGMA_NPLANES_SMALL = 9;                          // bit-sliced counter width for <= 495 k-mers per window
+constexpr int KGMA_NPLANES_LARGE = 11;                         // ... for <= 2031
+constexpr int KGMA_MAX_NK_SMALL = 16 * 31 - 1;
+constexpr int KGMA_MAX_NK = 16 * 127 - 1;                      // max k-mers per window (counter range)
 
 // One tile of the scan grid (built on the host, read by every workgroup).
 struct TileDesc {

@@ -145,14 +145,15 @@ __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t 
 
 // Bit-sliced counter of one (direction, word): planes c[0..NP-1] plus the pending partial sums
 // of the Harley-Seal tree.
+template <int NP>
 struct Counter {
-    uint32_t c[KGMA_NPLANES];
+    uint32_t c[NP];
     uint32_t p0, p1, p2, p3;
 };
 
 // Add mask m (weight 1) as the I-th of 16 masks of a block.
-template <int I>
-__device__ __forceinline__ void counter_add(Counter &s, uint32_t m)
+template <int I, int NP>
+__device__ __forceinline__ void counter_add(Counter<NP> &s, uint32_t m)
 {
     if constexpr ((I & 1) == 0) { s.p0 = m; return; }
     uint32_t c1; KGMA_CSA(c1, s.c[0], s.c[0], s.p0, m);
@@ -163,7 +164,7 @@ __device__ __forceinline__ void counter_add(Counter &s, uint32_t m)
     if constexpr ((I & 8) == 0) { s.p3 = c3; return; }
     uint32_t c4; KGMA_CSA(c4, s.c[3], s.c[3], s.p3, c3);
 #pragma unroll
-    for (int p = 4; p < KGMA_NPLANES; p++) {
+    for (int p = 4; p < NP; p++) {
         const uint32_t t = s.c[p] & c4;
         s.c[p] ^= c4;
         c4 = t;
@@ -334,13 +335,12 @@ __device__ __forceinline__ uint32_t from_next_lane(uint32_t x)
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
 }
 
-template <int K, int R>
+template <int K, int R, int NP>
 __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupParams gp)
 {
-    constexpr int NP = KGMA_NPLANES;
     constexpr int NB = 1 << (2 * K);
     constexpr int TW = V2_SLOTS * R;             // words covered by the tile's lanes
-    constexpr int XW = TW + 16;                  // words per plane of the exchange buffer
+    constexpr int XW = TW + 72;                  // words per plane of the exchange buffer (word shifts <= 63)
     constexpr int LH = R;                        // left halo words
     extern __shared__ uint32_t smem[];
 
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
     uint32_t *sL = sH + NW;
     int32_t *sS = reinterpret_cast<int32_t *>(sL + NW);
     uint32_t *sX = reinterpret_cast<uint32_t *>(sS + gp.n_kfv * NB);   // exchange buffer, aliases the histogram
-    constexpr int XSIZE = ((9 * XW > NB ? 9 * XW : NB) + 1) & ~1;
+    constexpr int XSIZE = ((NP * XW > NB ? NP * XW : NB) + 1) & ~1;
     int32_t *sHist = reinterpret_cast<int32_t *>(sX);
     int32_t *sMisc = reinterpret_cast<int32_t *>(sX + XSIZE);
     int64_t *sRed = reinterpret_cast<int64_t *>(sMisc + 16 + KGMA_THREADS);
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
 #pragma unroll
     for (int w = 0; w < R + 1; w++) { A0h[w] = sH[w0 + w]; A0l[w] = sL[w0 + w]; }
 
-    Counter cf[R];            // forward mismatch counts (own words, in place)
+    Counter<NP> cf[R];        // forward mismatch counts (own words, in place)
     Counter6 cg[R];           // group sums of the bit-shifted masks (coordinates v = p - np)
     uint32_t TB[R][NP];       // backward mismatch counts, coordinates v
 #pragma unroll
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
             F[R] = from_next_lane(F[0]);                                                   \
             const uint32_t sb = sb0 - (I);                                                 \
             _Pragma("unroll") for (int w = 0; w < R; w++) {                                \
-                counter_add<I>(cf[w], F[w]);                                               \
+                counter_add<I, NP>(cf[w], F[w]);                                           \
                 counter6_add<I>(cg[w], alignbit(F[w + 1], F[w], sb));                      \
             }                                                                              \
         }
@@ -725,18 +725,17 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
 // ------------------------------------------------------------------------------------------
 // launch wrappers (called from kgma_api.cpp)
 // ------------------------------------------------------------------------------------------
-size_t scan_lds_bytes(int k, int nk, int n_kfv, int R)
+size_t scan_lds_bytes(int k, int nk, int n_kfv, int R, int NP)
 {
     const size_t TW = (size_t)V2_SLOTS * R;
     const size_t NW = TW + scan_pad_words(nk);
     const size_t NB = (size_t)1 << (2 * k);
-    const size_t XW = TW + 16;
-    const size_t xsize = ((9 * XW > NB ? 9 * XW : NB) + 1) & ~(size_t)1;
+    const size_t XW = TW + 72;
+    const size_t xsize = (((size_t)NP * XW > NB ? (size_t)NP * XW : NB) + 1) & ~(size_t)1;
     return (2 * NW + (size_t)n_kfv * NB + xsize + 16 + KGMA_THREADS) * 4 + (4 + KGMA_MAX_GROUP) * 8 + 64;
 }
 
-// words per lane R: 2 (default) or 4
-int scan_tile_stride_words(int R, int nk) { return v2_stride_words(nk, R); }
+int scan_tile_stride_words(int nk) { return v2_stride_words(nk, KGMA_R); }
 int scan_nblocks(int nk) { return v2_nblocks(nk); }
 
 hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc *cd, int n_contigs,
@@ -761,35 +760,37 @@ hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int
     return hipGetLastError();
 }
 
-template <int K, int R>
-static hipError_t launch_scan_kr(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+template <int K, int R, int NP>
+static hipError_t launch_scan_krn(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
 {
-    const size_t lds = scan_lds_bytes(K, gp.nk, gp.n_kfv, R);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K, R>),
+    const size_t lds = scan_lds_bytes(K, gp.nk, gp.n_kfv, R, NP);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K, R, NP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((scan_kernel<K, R>), dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
+    hipLaunchKernelGGL((scan_kernel<K, R, NP>), dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
     return hipGetLastError();
 }
 
-template <int R>
-static hipError_t launch_scan_r(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+template <int NP>
+static hipError_t launch_scan_n(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
 {
+    constexpr int R = KGMA_R;
     switch (gp.k) {
-    case 2: return launch_scan_kr<2, R>(a, gp, st);
-    case 3: return launch_scan_kr<3, R>(a, gp, st);
-    case 4: return launch_scan_kr<4, R>(a, gp, st);
-    case 5: return launch_scan_kr<5, R>(a, gp, st);
-    case 6: return launch_scan_kr<6, R>(a, gp, st);
-    case 7: return launch_scan_kr<7, R>(a, gp, st);
+    case 2: return launch_scan_krn<2, R, NP>(a, gp, st);
+    case 3: return launch_scan_krn<3, R, NP>(a, gp, st);
+    case 4: return launch_scan_krn<4, R, NP>(a, gp, st);
+    case 5: return launch_scan_krn<5, R, NP>(a, gp, st);
+    case 6: return launch_scan_krn<6, R, NP>(a, gp, st);
+    case 7: return launch_scan_krn<7, R, NP>(a, gp, st);
     default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, int R, hipStream_t st)
+hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
 {
     if (a.n_tiles <= 0) return hipSuccess;
-    return R == 4 ? launch_scan_r<4>(a, gp, st) : launch_scan_r<2>(a, gp, st);
+    return gp.nk <= KGMA_MAX_NK_SMALL ? launch_scan_n<KGMA_NPLANES_SMALL>(a, gp, st)
+                                      : launch_scan_n<KGMA_NPLANES_LARGE>(a, gp, st);
 }
 
 }  // namespace kgma

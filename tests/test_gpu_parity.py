@@ -257,6 +257,32 @@ def test_other_k_values(ctx, data_dir, genes):
         _assert_single_parity(ctx, contigs, ref, thr)
 
 
+@pytest.mark.parametrize("gene_len,k", [(520, 6), (700, 5), (1900, 6), (2036, 6), (495 + 5, 6), (496 + 5, 6)])
+def test_large_windows(ctx, gene_len, k):
+    """Windows beyond the 9-plane counter range (495 k-mers) use the 11-plane kernel (<= 2031)."""
+    from kmergma_amd.fasta import Record
+    rng = np.random.default_rng(gene_len)
+    base = random_dna(rng, gene_len)
+    from tests.helpers import mutate
+    refs = [Record(f"g{i}", mutate(rng, base, 0.03)) for i in range(7)]
+    RV, ws, cons, (S, N) = refprep.gen_ref_ws_cons(refs, k, return_int=True)
+    assert ws == gene_len
+    ref = dict(RV=RV, ws=ws, S=S, N=N, k=k)
+    contigs, _ = make_genome(rng, [60000, gene_len, gene_len + 1, 3 * gene_len, 35000], [base], n_plants_per_mb=150)
+    thr = float(np.round(0.5 * orc.kmer_dist_kfv(random_dna(rng, gene_len), RV, k), 1))
+    hits, _ = _assert_single_parity(ctx, contigs, ref, thr)
+    assert len(hits) > 0
+
+
+def test_window_too_large_is_rejected(ctx):
+    k = 6
+    RV = np.zeros(4 ** k); RV[0] = 1.0
+    with pytest.raises(_lib.KgmaError) as e:
+        ctx.set_refs(k, [RV], [2031 + k], [10.0], [1])
+    assert e.value.status == _lib.KGMA_E_UNSUPPORTED
+    ctx.set_refs(k, [RV], [2031 + k - 1], [10.0], [1])
+
+
 def test_empty_and_tiny_inputs(ctx, alp_ref):
     ctx.set_refs(6, [alp_ref["RV"]], [alp_ref["ws"]], [30.0], [alp_ref["N"]])
     g = ctx.genome_from_host([])
