@@ -65,18 +65,25 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the scan")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # KGMA_BENCH_BACKEND=gloo / KGMA_BENCH_DEVICE=0 exist only to rehearse the multi-rank path on a
+    # one-GPU box; the driver's multi-GPU runs use RCCL ("nccl") with one rank per GPU.
+    backend = os.environ.get("KGMA_BENCH_BACKEND", "nccl")
+    dev_index = int(os.environ.get("KGMA_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     refs = workloads.fixture_refs(os.path.join(ROOT, "tests", "data"), 6)
     thr = 30.0
     length = args.length or workloads.CHR22_LEN
-    ctx = _lib.Context(local_rank)
+    ctx = _lib.Context(dev_index)
     ctx.set_refs(6, [refs["RV"]], [refs["ws"]], [thr], [refs["N"]])
     genome, plants = workloads.make_chr22_like(ctx, refs["genes"], seed=22 + rank, length=length)
     scale = 2.0 * 6 * refs["N"] ** 2
@@ -84,12 +91,13 @@ def main():
     def step():
         genome.repack()                                   # ASCII -> bit-planes (Kmers.jl encoding)
         ctx.scan(genome, _lib.MODE_SINGLE, 50, 0, 0, None)   # scan kernel + dips + hit state machine
-        st = ctx.stats()
-        hits = ctx.hits()
+        hits = ctx.hits_array()                           # kgma_hit records (numpy view, no per-hit objects)
         if world > 1:
-            hits = parallel.gather_hits(hits, rank, parallel.genome_pos_advance([length], True, refs["ws"]),
-                                        lambda kfv: scale, device=dev)
-        return st, hits
+            hl = [dict(contig=int(h["contig"]), kfv=int(h["kfv"]), cmi=int(h["cmi"]), lo=int(h["lo"]), hi=int(h["hi"]),
+                       genome_pos=int(h["genome_pos"]), D=int(h["D"]), flags=int(h["flags"])) for h in hits]
+            hits = parallel.gather_hits(hl, rank, parallel.genome_pos_advance([length], True, refs["ws"]),
+                                        lambda kfv: scale, device=dev if backend == "nccl" else None)
+        return hits
 
     def barrier():
         if world > 1:
@@ -103,13 +111,14 @@ def main():
     scan_ms, pack_ms = [], []
     hits = []
     for _ in range(args.steps):
-        st, hits = step()
+        hits = step()
+        st = ctx.stats()                                  # hipEvent times of this step's kernels
         scan_ms.append(st["scan_ms"])
         pack_ms.append(st["pack_ms"])
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -131,11 +140,12 @@ def main():
                        "n_hits": len(hits), "n_planted": len(plants), "sharding": "records across GPUs"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "kernel": "scan_kernel<6>", "kernel_ms": round(avg_scan_ms, 4),
+                         "kernel": "scan_kernel<6,2,9>", "kernel_ms": round(avg_scan_ms, 4),
                          "pack_kernel_ms": round(sum(pack_ms) / len(pack_ms), 4),
                          "algorithmic_bytes": ALGO_BYTES_PER_BASE * length,
                          "scan_only_Gbp_s": round(length / avg_scan_ms / 1e6, 2),
-                         "note": "VALU-issue bound, not HBM bound: see DESIGN.md (lane-ops roofline)"},
+                         "valu_note": "the binding resource is VALU issue, not HBM: DESIGN.md section 4 "
+                                      "(profiles/ hold the SQ_INSTS_VALU / cycle counts)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             v, n, nh = cpu_baseline(genome.fetch, refs, length, thr)

@@ -51,6 +51,9 @@ class KgmaStats(C.Structure):
                 ("device_bytes", C.c_int64), ("n_tiles", C.c_int32), ("n_launches", C.c_int32)]
 
 
+HIT_DTYPE = np.dtype([("contig", "<i4"), ("kfv", "<i4"), ("cmi", "<i8"), ("lo", "<i8"), ("hi", "<i8"),
+                      ("genome_pos", "<i8"), ("dist", "<f8"), ("D", "<i8"), ("flags", "<u4"), ("reserved", "<u4")])
+
 ALIGN_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                        C.POINTER(C.c_int64), C.POINTER(C.c_int64))
 
@@ -261,6 +264,14 @@ class Context:
         self._check(load().kgma_get_hits(self._h, arr, n.value, C.byref(n)))
         return [dict(contig=h.contig, kfv=h.kfv, cmi=h.cmi, lo=h.lo, hi=h.hi, genome_pos=h.genome_pos,
                      dist=h.dist, D=h.D, flags=h.flags) for h in arr[:n.value]]
+
+    def hits_array(self) -> np.ndarray:
+        """Hits of the last scan as a numpy structured array (no per-hit Python objects)."""
+        n = C.c_int64(0)
+        self._check(load().kgma_get_hits(self._h, None, 0, C.byref(n)))
+        arr = np.zeros(max(n.value, 1), dtype=HIT_DTYPE)
+        self._check(load().kgma_get_hits(self._h, arr.ctypes.data_as(C.POINTER(KgmaHit)), n.value, C.byref(n)))
+        return arr[:n.value]
 
     def dips(self) -> List[dict]:
         n = C.c_int64(0)
