@@ -72,3 +72,32 @@ def make_chr22_like(ctx, genes: List[bytes], seed: int = 22, length: int = CHR22
         kept.append((c, pos, len(data)))
     g.repack()
     return g, kept
+
+
+def make_grch38_like(ctx, genes: List[bytes], seed: int = 38, n_plants: int = 512, scale: float = 1.0):
+    """Config 3: 25 records with the GRCh38 primary-assembly lengths (times `scale`), iid bases,
+    `n_plants` planted mutated fixture genes, a leading N run on every record (telomere gaps)."""
+    lens = [max(1000, int(L * scale)) for L in GRCH38_LENS]
+    g = ctx.genome_synthetic(lens, seed)
+    for c, L in enumerate(lens):
+        n = min(10_000, L // 10)
+        g.poke(c, 1, b"N" * n)
+    plants = planted_genes(genes, lens, n_plants, seed + 2)
+    kept = []
+    for c, pos, data in plants:
+        if pos <= 10_400:
+            pos += 10_400
+        if pos + len(data) >= lens[c]:
+            continue
+        g.poke(c, pos, data)
+        kept.append((c, pos, len(data)))
+    g.repack()
+    return g, kept, lens
+
+
+def fixture_clusters(data_dir: str, k: int = 6, cutoffs=(7, 12, 20, 25)):
+    """Config 4 inputs: the fixture clustered into 5 KFVs (W = 288,288,288,289,290)."""
+    tf = os.path.join(data_dir, "Alp_V_ref.fasta")
+    KFVs, ws, cons, inv, ints = refprep.cluster_ref_API(tf, k, cutoffs=list(cutoffs), include_avg=False, return_int=True)
+    KFVs, ws, cons, ints = refprep.eliminate_null_params(KFVs, ws, cons, inv, ints)
+    return dict(KFVs=KFVs, ws=ws, cons=cons, S=[s for s, _ in ints], N=[n for _, n in ints], k=k)
