@@ -149,6 +149,14 @@ int kgma_set_thresholds(kgma_ctx *ctx, const double *thr);
 int kgma_genome_from_host(kgma_ctx *ctx, const uint8_t *const *contig_ascii, const int64_t *contig_len,
                           int64_t n_contigs, kgma_genome **out);
 
+/* Build a device-resident genome straight from FASTA text (the whole file in host memory, e.g.
+ * mmap-ed): replaces FASTX parsing + getSeq (src/GenomeMiner.jl:31-35).  The host only locates the
+ * header lines; line breaks are stripped and records laid out on the device, then packed as in
+ * kgma_genome_from_host.  Multi-line records, blank lines and CR/LF are accepted.
+ * kgma_genome_header returns record `contig`'s header line (without '>', not NUL-counted). */
+int kgma_genome_from_fasta(kgma_ctx *ctx, const uint8_t *text, int64_t n, kgma_genome **out);
+int kgma_genome_header(const kgma_genome *g, int64_t contig, const char **text, int64_t *len);
+
 /* Build a synthetic genome on the device (benchmarks; no PCIe traffic): n_contigs records of the
  * given lengths, base i of record c = splitmix64(seed + c, i) >> 62 written as ASCII 'A','C','G','T',
  * then `n_plants` copies of `plant` (ASCII, length plant_len) written at the given (contig,

@@ -41,6 +41,9 @@ hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc 
 hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int64_t total_words,
                         uint64_t seed, hipStream_t st);
 hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
+hipError_t launch_fasta_count(const uint8_t *raw, int64_t n, uint32_t *counts, hipStream_t st);
+hipError_t launch_fasta_scatter(const uint8_t *raw, int64_t n, const int64_t *block_base, const int64_t *rec_start,
+                                const ContigDesc *cd, int n_rec, uint8_t *ascii, hipStream_t st);
 int scan_tile_stride_words(int nk);
 int scan_nblocks(int nk);
 }  // namespace kgma
@@ -76,6 +79,7 @@ struct kgma_genome {
     int64_t total_words = 0;      // plane words incl. padding
     int64_t ascii_bytes = 0;
     std::vector<ContigDesc> cd;
+    std::vector<std::string> headers;          // FASTA header lines (without '>'), only for genomes built from FASTA text
     unsigned long long *first_bad = nullptr;   // pinned host copy, valid once pack_pending is cleared
     bool pack_pending = false;
     uint64_t uid = 0;
@@ -516,6 +520,157 @@ int kgma_genome_synthetic(kgma_ctx *ctx, const int64_t *contig_len, int64_t n_co
     rc = kgma_genome_repack(ctx, g);
     if (rc != KGMA_OK) { kgma_genome_free(ctx, g); return rc; }
     *out = g;
+    return KGMA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// FASTA text -> device genome (ingest on the device)
+// ------------------------------------------------------------------------------------------
+int kgma_genome_from_fasta(kgma_ctx *ctx, const uint8_t *text, int64_t n, kgma_genome **out)
+{
+    if (!ctx) return KGMA_E_ARG;
+    if (!out || n < 0 || (n > 0 && !text)) return fail(ctx, KGMA_E_ARG, "null argument");
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    constexpr int64_t FB = 4096;
+    // ---- host: locate the header lines (a '>' at the start of a line); O(file) memchr only ----
+    struct Hdr { int64_t begin, end; };            // [begin, end): from '>' to just past its '\n'
+    std::vector<Hdr> hdrs;
+    {
+        const uint8_t *p = text, *e = text + n;
+        while (p < e) {
+            const uint8_t *q = static_cast<const uint8_t *>(memchr(p, '>', (size_t)(e - p)));
+            if (!q) break;
+            if (q == text || q[-1] == '\n') {
+                const uint8_t *nl = static_cast<const uint8_t *>(memchr(q, '\n', (size_t)(e - q)));
+                const int64_t hb = q - text, he = nl ? (nl - text) + 1 : n;
+                hdrs.push_back(Hdr{hb, he});
+                p = text + he;
+            } else {
+                p = q + 1;
+            }
+        }
+    }
+    const int64_t n_rec = (int64_t)hdrs.size();
+    if (n_rec == 0 && n > 0) {
+        for (int64_t i = 0; i < n; i++)
+            if (text[i] > 0x20) return fail(ctx, KGMA_E_ARG, "FASTA text has sequence data before the first '>' header");
+    }
+    if (n_rec > 0x7FFFFFF0ll) return fail(ctx, KGMA_E_UNSUPPORTED, "too many records");
+    if (n_rec > 0)
+        for (int64_t i = 0; i < hdrs[0].begin; i++)
+            if (text[i] > 0x20) return fail(ctx, KGMA_E_ARG, "FASTA text has sequence data before the first '>' header");
+
+    // ---- upload the text with header lines blanked, padded with '\n' to a block multiple -----
+    const int64_t nb = (n + FB - 1) / FB;
+    const int64_t n_pad = std::max<int64_t>(nb, 1) * FB;
+    uint8_t *d_raw = nullptr;
+    uint32_t *d_counts = nullptr;
+    int64_t *d_base = nullptr, *d_rs = nullptr;
+    uint8_t *stage = nullptr;
+    kgma_genome *g = nullptr;
+    int rc = KGMA_OK;
+    auto cleanup = [&]() {
+        if (d_raw) (void)hipFree(d_raw);
+        if (d_counts) (void)hipFree(d_counts);
+        if (d_base) (void)hipFree(d_base);
+        if (d_rs) (void)hipFree(d_rs);
+        if (stage) (void)hipHostFree(stage);
+    };
+#define FA_TRY(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            rc = fail(ctx, KGMA_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e__));           \
+            cleanup();                                                                            \
+            if (g) kgma_genome_free(ctx, g);                                                      \
+            return rc;                                                                            \
+        }                                                                                         \
+    } while (0)
+    FA_TRY(hipMalloc(reinterpret_cast<void **>(&d_raw), (size_t)n_pad));
+    FA_TRY(hipMalloc(reinterpret_cast<void **>(&d_counts), (size_t)std::max<int64_t>(nb, 1) * sizeof(uint32_t)));
+    const size_t stage_cap = (size_t)64 << 20;
+    FA_TRY(hipHostMalloc(reinterpret_cast<void **>(&stage), stage_cap, hipHostMallocDefault));
+    {
+        size_t hi = 0;   // first header that may intersect the current chunk
+        for (int64_t off = 0; off < n_pad; off += (int64_t)stage_cap) {
+            const int64_t len = std::min<int64_t>((int64_t)stage_cap, n_pad - off);
+            const int64_t data = std::max<int64_t>(0, std::min<int64_t>(len, n - off));
+            if (data) memcpy(stage, text + off, (size_t)data);
+            if (len > data) memset(stage + data, '\n', (size_t)(len - data));
+            while (hi < hdrs.size() && hdrs[hi].end <= off) hi++;
+            for (size_t h = hi; h < hdrs.size() && hdrs[h].begin < off + len; h++) {
+                const int64_t b = std::max<int64_t>(hdrs[h].begin, off), e = std::min<int64_t>(hdrs[h].end, off + len);
+                if (e > b) memset(stage + (b - off), '\n', (size_t)(e - b));
+            }
+            FA_TRY(hipMemcpy(d_raw + off, stage, (size_t)len, hipMemcpyHostToDevice));
+        }
+    }
+    // ---- kernel 1: residues per block; host prefix sum -> block bases --------------------------
+    FA_TRY(launch_fasta_count(d_raw, n_pad, d_counts, ctx->stream));
+    std::vector<uint32_t> counts((size_t)std::max<int64_t>(nb, 1), 0);
+    FA_TRY(hipMemcpyAsync(counts.data(), d_counts, (size_t)std::max<int64_t>(nb, 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FA_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<int64_t> base((size_t)std::max<int64_t>(nb, 1) + 1, 0);
+    for (int64_t b = 0; b < nb; b++) base[(size_t)b + 1] = base[(size_t)b] + counts[(size_t)b];
+    const int64_t total_res = nb > 0 ? base[(size_t)nb] : 0;
+    // residue index of each record's first residue = residues before its header line
+    auto residues_before = [&](int64_t pos) -> int64_t {   // pos is a header start: bytes [blk, pos) hold no header tail
+        const int64_t blk = pos / FB;
+        int64_t c = base[(size_t)blk];
+        size_t h = 0;
+        // count residues in [blk*FB, pos) skipping header bytes (a header may start before the block)
+        int64_t i = blk * FB;
+        // binary search the first header ending after i
+        {
+            size_t lo = 0, hi2 = hdrs.size();
+            while (lo < hi2) { const size_t mid = (lo + hi2) / 2; if (hdrs[mid].end <= i) lo = mid + 1; else hi2 = mid; }
+            h = lo;
+        }
+        while (i < pos) {
+            if (h < hdrs.size() && i >= hdrs[h].begin && i < hdrs[h].end) { i = hdrs[h].end; h++; continue; }
+            const int64_t stop = (h < hdrs.size() && hdrs[h].begin < pos) ? hdrs[h].begin : pos;
+            for (; i < stop; i++) c += text[i] > 0x20;
+        }
+        return c;
+    };
+    std::vector<int64_t> rs((size_t)n_rec + 1, 0), lens((size_t)std::max<int64_t>(n_rec, 1), 0);
+    for (int64_t c = 0; c < n_rec; c++) rs[(size_t)c] = residues_before(hdrs[(size_t)c].begin);
+    rs[(size_t)n_rec] = total_res;
+    for (int64_t c = 0; c < n_rec; c++) lens[(size_t)c] = rs[(size_t)c + 1] - rs[(size_t)c];
+    // ---- layout, kernel 2 (scatter), pack ---------------------------------------------------------
+    g = new (std::nothrow) kgma_genome();
+    if (!g) { cleanup(); return fail(ctx, KGMA_E_NOMEM, "out of host memory"); }
+    rc = genome_layout(ctx, g, lens.data(), n_rec);
+    if (rc != KGMA_OK) { cleanup(); kgma_genome_free(ctx, g); return rc; }
+    g->headers.resize((size_t)n_rec);
+    for (int64_t c = 0; c < n_rec; c++) {
+        int64_t b = hdrs[(size_t)c].begin + 1, e = hdrs[(size_t)c].end;
+        while (e > b && (text[e - 1] == '\n' || text[e - 1] == '\r')) e--;
+        g->headers[(size_t)c].assign(reinterpret_cast<const char *>(text + b), (size_t)(e - b));
+    }
+    if (n_rec > 0) {
+        FA_TRY(hipMalloc(reinterpret_cast<void **>(&d_base), base.size() * sizeof(int64_t)));
+        FA_TRY(hipMalloc(reinterpret_cast<void **>(&d_rs), rs.size() * sizeof(int64_t)));
+        FA_TRY(hipMemcpy(d_base, base.data(), base.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        FA_TRY(hipMemcpy(d_rs, rs.data(), rs.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        FA_TRY(hipMemsetAsync(g->d_ascii, 0, (size_t)g->ascii_bytes, ctx->stream));
+        FA_TRY(launch_fasta_scatter(d_raw, n_pad, d_base, d_rs, g->d_cd, (int)n_rec, g->d_ascii, ctx->stream));
+        FA_TRY(hipStreamSynchronize(ctx->stream));
+    }
+#undef FA_TRY
+    cleanup();
+    rc = kgma_genome_repack(ctx, g);
+    if (rc != KGMA_OK) { kgma_genome_free(ctx, g); return rc; }
+    *out = g;
+    return KGMA_OK;
+}
+
+int kgma_genome_header(const kgma_genome *g, int64_t contig, const char **text, int64_t *len)
+{
+    if (!g || !text || !len || contig < 0 || contig >= g->n_contigs || (size_t)contig >= g->headers.size()) return KGMA_E_ARG;
+    *text = g->headers[(size_t)contig].c_str();
+    *len = (int64_t)g->headers[(size_t)contig].size();
     return KGMA_OK;
 }
 

@@ -85,6 +85,84 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
 }
 
 // ------------------------------------------------------------------------------------------
+// FASTA ingest on the device (replaces FASTX parsing + getSeq, src/GenomeMiner.jl:31-35).
+// The host uploads the raw file with its header lines blanked to '\n'; a residue is any byte
+// > ' ' (line breaks, CR, blanks and tabs are skipped).  Kernel 1 counts residues per 4 KiB
+// block; the host turns the counts into block bases and a record table; kernel 2 moves every
+// residue to its place in the padded per-record ASCII layout the pack kernel reads.
+// ------------------------------------------------------------------------------------------
+constexpr int FASTA_BLOCK = 4096;      // bytes per workgroup (256 lanes x 16 bytes)
+
+__device__ __forceinline__ uint32_t residue_mask16(const uint4 v)
+{
+    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) m |= (uint32_t)(((x[i >> 2] >> (8 * (i & 3))) & 0xFFu) > 0x20u) << i;
+    return m;
+}
+
+__global__ __launch_bounds__(256) void fasta_count_kernel(const uint8_t *__restrict__ raw, int64_t n,
+                                                          uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t red[4];
+    const int64_t off = (int64_t)blockIdx.x * FASTA_BLOCK + (int64_t)threadIdx.x * 16;
+    uint32_t c = 0;
+    if (off < n) {      // the raw buffer is padded with '\n' to a multiple of FASTA_BLOCK
+        const uint4 v = *reinterpret_cast<const uint4 *>(raw + off);
+        c = __builtin_popcount(residue_mask16(v));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// rec_start[c] = index (in residue order over the whole file) of record c's first residue
+__global__ __launch_bounds__(256) void fasta_scatter_kernel(const uint8_t *__restrict__ raw, int64_t n,
+                                                            const int64_t *__restrict__ block_base,
+                                                            const int64_t *__restrict__ rec_start,
+                                                            const ContigDesc *__restrict__ cd, int n_rec,
+                                                            uint8_t *__restrict__ ascii)
+{
+    __shared__ uint32_t wsum[4];
+    const int64_t off = (int64_t)blockIdx.x * FASTA_BLOCK + (int64_t)threadIdx.x * 16;
+    uint4 v = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+    if (off < n) v = *reinterpret_cast<const uint4 *>(raw + off);
+    const uint32_t m = residue_mask16(v);
+    const uint32_t cnt = __builtin_popcount(m);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if ((threadIdx.x & 63) >= (unsigned)d) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - cnt;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) base += wsum[w];
+    if (cnt == 0) return;
+    int64_t ridx = block_base[blockIdx.x] + base;       // file-wide index of this lane's first residue
+    // record of the first residue (binary search), then walk
+    int lo = 0, hi = n_rec - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rec_start[mid] <= ridx) lo = mid; else hi = mid - 1;
+    }
+    int rec = lo;
+    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if ((m >> i) & 1u) {
+            while (rec + 1 < n_rec && rec_start[rec + 1] <= ridx) rec++;
+            ascii[cd[rec].ascii_off + (ridx - rec_start[rec])] = (uint8_t)((x[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+            ridx++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Synthetic genome (benchmarks): 32 residues per 64-bit splitmix64 output, written as ASCII.
 // ------------------------------------------------------------------------------------------
 __host__ __device__ inline uint64_t synth_word(uint64_t seed, uint64_t contig, uint64_t w)
@@ -746,6 +824,24 @@ hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc 
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ascii, planes, cd,
                        n_contigs, total_words, first_bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_fasta_count(const uint8_t *raw, int64_t n, uint32_t *counts, hipStream_t st)
+{
+    const int64_t nb = (n + FASTA_BLOCK - 1) / FASTA_BLOCK;
+    if (nb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fasta_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, raw, n, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_fasta_scatter(const uint8_t *raw, int64_t n, const int64_t *block_base, const int64_t *rec_start,
+                                const ContigDesc *cd, int n_rec, uint8_t *ascii, hipStream_t st)
+{
+    const int64_t nb = (n + FASTA_BLOCK - 1) / FASTA_BLOCK;
+    if (nb <= 0 || n_rec <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fasta_scatter_kernel, dim3((unsigned)nb), dim3(256), 0, st, raw, n, block_base, rec_start, cd,
+                       n_rec, ascii);
     return hipGetLastError();
 }
 

@@ -28,7 +28,7 @@ EXPORTS = [
     "kgma_genome_fetch", "kgma_genome_num_contigs", "kgma_genome_contig_len", "kgma_genome_total_bases",
     "kgma_genome_free", "kgma_genome_repack", "kgma_genome_poke", "kgma_scan", "kgma_scan_device", "kgma_get_hits",
     "kgma_get_dips", "kgma_get_first_window", "kgma_get_dists", "kgma_get_stats", "kgma_stream",
-    "kgma_host_semiglobal_cigar",
+    "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_header",
 ]
 
 
@@ -98,6 +98,8 @@ def load():
     L.kgma_set_refs.argtypes = [vp, i32, i32, P(dbl), P(i64), P(dbl), P(i64)]
     L.kgma_set_thresholds.argtypes = [vp, P(dbl)]
     L.kgma_genome_from_host.argtypes = [vp, P(C.c_char_p), P(i64), i64, P(vp)]
+    L.kgma_genome_from_fasta.argtypes = [vp, vp, i64, P(vp)]
+    L.kgma_genome_header.argtypes = [vp, i64, P(C.c_char_p), P(i64)]
     L.kgma_genome_synthetic.argtypes = [vp, P(i64), i64, u64, C.c_char_p, i64, P(i64), P(i64), i64, P(vp)]
     L.kgma_genome_fetch.argtypes = [vp, vp, i64, i64, i64, C.c_char_p]
     L.kgma_genome_num_contigs.argtypes = [vp]
@@ -145,6 +147,14 @@ class Genome:
     @property
     def total_bases(self) -> int:
         return int(load().kgma_genome_total_bases(self._h))
+
+    def header(self, contig: int) -> str:
+        txt = C.c_char_p()
+        n = C.c_int64(0)
+        st = load().kgma_genome_header(self._h, contig, C.byref(txt), C.byref(n))
+        if st != KGMA_OK:
+            raise KgmaError(st, "genome has no FASTA headers (it was not built from FASTA text)")
+        return C.string_at(txt, n.value).decode("utf-8", "replace")
 
     def fetch(self, contig: int, pos: int, length: int) -> bytes:
         buf = C.create_string_buffer(max(length, 1))
@@ -229,6 +239,17 @@ class Context:
         lens = np.asarray([len(c) for c in contigs], dtype=np.int64)
         h = C.c_void_p()
         self._check(load().kgma_genome_from_host(self._h, arr, _np_ptr(lens, C.c_int64) if n else None, n, C.byref(h)))
+        return Genome(self, h)
+
+    def genome_from_fasta(self, source) -> Genome:
+        """Device-side FASTA ingest. `source` is a path (memory-mapped) or a bytes object."""
+        if isinstance(source, (bytes, bytearray)):
+            buf = np.frombuffer(bytes(source), dtype=np.uint8)
+        else:
+            buf = np.memmap(source, dtype=np.uint8, mode="r") if os.path.getsize(source) else np.zeros(0, np.uint8)
+        h = C.c_void_p()
+        ptr = buf.ctypes.data_as(C.c_void_p) if buf.size else None
+        self._check(load().kgma_genome_from_fasta(self._h, ptr, int(buf.size), C.byref(h)))
         return Genome(self, h)
 
     def genome_synthetic(self, contig_lens: Sequence[int], seed: int, plant: bytes = b"",

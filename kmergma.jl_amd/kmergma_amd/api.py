@@ -43,10 +43,35 @@ def default_context(device: int = 0) -> "_lib.Context":
     return _CTX[device]
 
 
-def _records(genome_path) -> List[Record]:
-    if isinstance(genome_path, str):
-        return read_fasta(genome_path)
-    return list(genome_path)
+class _GenomeView:
+    """The records of a scan input: FASTA path -> parsed and packed on the device
+    (kgma_genome_from_fasta, replaces FASTX + getSeq at src/GenomeMiner.jl:31-35);
+    list of Record -> uploaded from host memory.  Sequences of hits are read back on demand."""
+
+    def __init__(self, ctx, genome_path):
+        if isinstance(genome_path, str):
+            self.genome = ctx.genome_from_fasta(genome_path)
+            self.descriptions = [self.genome.header(c) for c in range(self.genome.n_contigs)]
+            self._recs = None
+        else:
+            self._recs = list(genome_path)
+            self.genome = ctx.genome_from_host([r.sequence for r in self._recs])
+            self.descriptions = [r.description for r in self._recs]
+
+    def identifier(self, c: int) -> str:
+        parts = self.descriptions[c].split(None, 1)
+        return parts[0] if parts else ""
+
+    def subseq(self, c: int, lo: int, hi: int) -> bytes:
+        """view(seq, lo:hi), 1-based inclusive."""
+        if hi < lo:
+            return b""
+        if self._recs is not None:
+            return self._recs[c].sequence[lo - 1:hi]
+        return self.genome.fetch(c, lo, hi - lo + 1)
+
+    def free(self):
+        self.genome.free()
 
 
 def _check_derived(k: int, mask, ScaleFactor) -> None:
@@ -58,15 +83,14 @@ def _check_derived(k: int, mask, ScaleFactor) -> None:
         raise ValueError(f"ScaleFactor = {ScaleFactor} is not 1/k for k = {k}")
 
 
-def _make_align_cb(aligner, recs, consensus_of, windowsize_of, gap_open, gap_extend, store):
+def _make_align_cb(aligner, view, consensus_of, windowsize_of, gap_open, gap_extend, store):
     """Adapts `aligner(consensus, segment, gap_open, gap_extend) -> (first, last)` (the role of
     pairalign + cigar_to_UnitRange, Alignment.jl:13-52) to the library's range callback."""
 
     def cb(contig, kfv, lo, hi, L):
-        seq = recs[contig].sequence
         cons = consensus_of(kfv)
         ws = windowsize_of(kfv)
-        a_first, a_last = aligner(cons[:ws] if ws is not None else cons, seq[lo - 1:hi], gap_open, gap_extend)
+        a_first, a_last = aligner(cons[:ws] if ws is not None else cons, view.subseq(contig, lo, hi), gap_open, gap_extend)
         if store is not None:
             store.append((contig, kfv, lo, hi, a_first, a_last))
         return max(1, lo + a_first - 1), min(lo + a_last - 1, L)
@@ -85,29 +109,29 @@ def ac_gma_testing(*, genome_path, refVec, consensus_refseq: bytes = b"", k: int
     """`ac_gma_testing!` (src/GenomeMiner.jl:4-109): mutates resultVec / hit_loci_vec / dist_vec."""
     _check_derived(k, mask, ScaleFactor)
     resultVec = resultVec if resultVec is not None else []
-    recs = _records(genome_path)
     ctx = ctx or default_context()
     ctx.set_refs(k, [np.asarray(refVec, dtype=np.float64)], [int(windowsize)], [float(thr)],
                  None if n_refs is None else [int(n_refs)])
-    genome = ctx.genome_from_host([r.sequence for r in recs])
+    view = _GenomeView(ctx, genome_path)
+    genome = view.genome
     try:
         cb = None
         if do_align:
             if aligner is None:
                 from .align import align_range as aligner  # noqa: N813
-            cb = _make_align_cb(aligner, recs, lambda kfv: consensus_refseq, lambda kfv: int(windowsize),
+            cb = _make_align_cb(aligner, view, lambda kfv: consensus_refseq, lambda kfv: int(windowsize),
                                 gap_open_score, gap_extend_score, result_align_vec if do_return_align else None)
         ctx.scan(genome, _lib.MODE_SINGLE, int(buff), 0, _lib.F_RETURN_DISTS if do_return_dists else 0, cb)
         for h in ctx.hits():
-            rec = recs[h["contig"]]
-            hdr = headers.single_header(rec.identifier, h["dist"], h["lo"], h["hi"], h["genome_pos"], with_genome_pos)
-            resultVec.append(Record(hdr, rec.sequence[h["lo"] - 1:h["hi"]]))
+            c = h["contig"]
+            hdr = headers.single_header(view.identifier(c), h["dist"], h["lo"], h["hi"], h["genome_pos"], with_genome_pos)
+            resultVec.append(Record(hdr, view.subseq(c, h["lo"], h["hi"])))
             if get_hit_loci and hit_loci_vec is not None:
                 hit_loci_vec.append(h["lo"] + h["genome_pos"])
         if do_return_dists and dist_vec is not None:
             dist_vec.extend(ctx.dists(1).tolist())
     finally:
-        genome.free()
+        view.free()
 
 
 def record_KmerGMA(*, record: Record, refVec, consensus_refseq: bytes = b"", resultVec_vec: List[list],
@@ -131,32 +155,32 @@ def Omn_KmerGMA(*, genome_path, refVecs: Sequence, windowsizes: Sequence[int], c
                 aligner: Optional[Callable] = None, ctx=None) -> None:
     """`Omn_KmerGMA!` (src/OmnGenomeMiner.jl:7-162)."""
     _check_derived(k, mask, ScaleFactor)
-    recs = _records(genome_path)
     m = len(windowsizes)
     ctx = ctx or default_context()
     ctx.set_refs(k, [np.asarray(r, dtype=np.float64) for r in refVecs], [int(w) for w in windowsizes],
                  [float(t) for t in list(thr_vec)[:m]], None if n_refs is None else [int(n) for n in n_refs])
-    genome = ctx.genome_from_host([r.sequence for r in recs])
+    view = _GenomeView(ctx, genome_path)
+    genome = view.genome
     try:
         cb = None
         if align_hits:
             if aligner is None:
                 from .align import align_range as aligner  # noqa: N813
             # the cluster engine aligns against the whole consensus_seqs[ind] (OmnGenomeMiner.jl:131)
-            cb = _make_align_cb(aligner, recs, lambda kfv: consensus_seqs[kfv - 1], lambda kfv: None,
+            cb = _make_align_cb(aligner, view, lambda kfv: consensus_seqs[kfv - 1], lambda kfv: None,
                                 gap_open_score, gap_extend_score, align_vec if get_aligns else None)
         ctx.scan(genome, _lib.MODE_OMN, int(buff), int(genome_pos), _lib.F_RETURN_DISTS if do_return_dists else 0, cb)
         for h in ctx.hits():
-            rec = recs[h["contig"]]
-            hdr = headers.omn_header(rec.identifier, h["dist"], h["kfv"], h["lo"], h["hi"], h["genome_pos"])
-            resultVec.append(Record(hdr, rec.sequence[h["lo"] - 1:h["hi"]]))
+            c = h["contig"]
+            hdr = headers.omn_header(view.identifier(c), h["dist"], h["kfv"], h["lo"], h["hi"], h["genome_pos"])
+            resultVec.append(Record(hdr, view.subseq(c, h["lo"], h["hi"])))
             if get_hit_loci and hit_loci_vec is not None:
                 hit_loci_vec.append(h["lo"] + h["genome_pos"])
         if do_return_dists and dist_vec_vec is not None:
             for j in range(m):
                 dist_vec_vec[j].extend(ctx.dists(j + 1).tolist())
     finally:
-        genome.free()
+        view.free()
 
 
 def warn_helper(k: int, do_return_dists: bool) -> None:

@@ -283,6 +283,53 @@ def test_window_too_large_is_rejected(ctx):
     ctx.set_refs(k, [RV], [2031 + k - 1], [10.0], [1])
 
 
+def test_fasta_ingest_on_device(ctx, data_dir, tmp_path):
+    """kgma_genome_from_fasta (device-side line stripping) vs the host FASTA reader."""
+    from kmergma_amd import fasta
+    for name in ("Loci.fasta", "Alp_V_locus.fasta", "Alp_V_ref.fasta", "8_ident_Alp_V_loci.fasta"):
+        path = os.path.join(data_dir, name)
+        recs = fasta.read_fasta(path)
+        g = ctx.genome_from_fasta(path)
+        assert g.n_contigs == len(recs)
+        for c, r in enumerate(recs):
+            assert g.contig_len(c) == len(r.sequence)
+            assert g.header(c).strip() == r.description
+            assert g.fetch(c, 1, len(r.sequence)) == r.sequence
+        g.free()
+    # awkward layouts: CRLF, blank lines, no trailing newline, empty records, lines of every length
+    # around the 16-byte lane and 4096-byte block granules, '>' inside a header
+    rng = np.random.default_rng(17)
+    parts, expect = [], []
+    for i, L in enumerate([0, 1, 15, 16, 17, 4095, 4096, 4097, 70001, 5, 0, 33]):
+        seq = random_dna(rng, L)
+        hdr = f"rec{i} some >description {i}"
+        width = int(rng.integers(1, 200))
+        lines = [seq[j:j + width] for j in range(0, L, width)]
+        eol = b"\r\n" if i % 3 == 0 else b"\n"
+        body = eol.join(lines) + (eol if lines else b"")
+        if i % 4 == 1:
+            body = b"\n" + body + b"\n\n"
+        parts.append(b">" + hdr.encode() + eol + body)
+        expect.append((hdr, seq))
+    text = b"\n\n" + b"".join(parts)
+    text = text.rstrip(b"\r\n")          # no trailing newline
+    p = tmp_path / "awkward.fasta"
+    p.write_bytes(text)
+    for src in (str(p), text):
+        g = ctx.genome_from_fasta(src)
+        assert g.n_contigs == len(expect)
+        for c, (hdr, seq) in enumerate(expect):
+            assert g.header(c) == hdr
+            assert g.contig_len(c) == len(seq)
+            assert g.fetch(c, 1, len(seq)) == seq
+        g.free()
+    with pytest.raises(_lib.KgmaError):
+        ctx.genome_from_fasta(b"ACGT\n>late header\nACGT\n")
+    g = ctx.genome_from_fasta(b"")
+    assert g.n_contigs == 0
+    g.free()
+
+
 def test_empty_and_tiny_inputs(ctx, alp_ref):
     ctx.set_refs(6, [alp_ref["RV"]], [alp_ref["ws"]], [30.0], [alp_ref["N"]])
     g = ctx.genome_from_host([])
