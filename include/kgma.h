@@ -134,7 +134,7 @@ void kgma_destroy(kgma_ctx *ctx);
  * n_refs[m]: number of reference sequences averaged into each KFV (KFV = S/N, S integer); the
  * device computes in exact integers with S = round(ref*N).  n_refs == NULL: N is inferred
  * (smallest N <= 2^20 making ref*N integral to 1e-9); KGMA_E_UNSUPPORTED if none exists.
- * Requires 2 <= k <= 7 (LDS-resident tables), k < min(windowsizes) (src/API.jl:70,177) and at
+ * Requires 2 <= k <= 10, k < min(windowsizes) (src/API.jl:70,177) and at
  * most 2031 k-mers per window (windowsize - k + 1); KGMA_E_UNSUPPORTED otherwise. */
 int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const int64_t *windowsizes,
                   const double *thr, const int64_t *n_refs);

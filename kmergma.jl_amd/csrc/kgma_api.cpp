@@ -304,7 +304,7 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
 {
     if (!ctx) return KGMA_E_ARG;
     if (!ref || !windowsizes || !thr || m < 1) return fail(ctx, KGMA_E_ARG, "null argument or m < 1");
-    if (k < 2 || k > 7) return fail(ctx, KGMA_E_UNSUPPORTED, "k = %d: the device path supports 2 <= k <= 7", k);
+    if (k < 2 || k > 10) return fail(ctx, KGMA_E_UNSUPPORTED, "k = %d: the device path supports 2 <= k <= 10", k);
     (void)hipSetDevice(ctx->device);
     const int64_t NB = (int64_t)1 << (2 * k);
     std::vector<KfvInfo> kv((size_t)m);

@@ -413,9 +413,22 @@ __device__ __forceinline__ uint32_t from_next_lane(uint32_t x)
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
 }
 
-template <int K, int R, int NP>
+// sum of `v` over the workgroup, returned to every thread (sRed: 4 int64 of LDS scratch)
+__device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t *sRed, int tid)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += shfl_down_i64(v, d);
+    __syncthreads();                 // previous users of sRed are done
+    if ((tid & 63) == 0) sRed[tid >> 6] = v;
+    __syncthreads();
+    return sRed[0] + sRed[1] + sRed[2] + sRed[3];
+}
+
+// SLDS: the S tables of the launch fit in LDS (else they are read from global memory / L2).
+template <int K, int R, int NP, bool SLDS>
 __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupParams gp)
 {
+    constexpr bool HIST = K <= 6;                // first-window D from an LDS histogram (else by pair counting)
     constexpr int NB = 1 << (2 * K);
     constexpr int TW = V2_SLOTS * R;             // words covered by the tile's lanes
     constexpr int XW = TW + 72;                  // words per plane of the exchange buffer (word shifts <= 63)
@@ -438,11 +451,13 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
     uint32_t *sH = smem;
     uint32_t *sL = sH + NW;
     int32_t *sS = reinterpret_cast<int32_t *>(sL + NW);
-    uint32_t *sX = reinterpret_cast<uint32_t *>(sS + gp.n_kfv * NB);   // exchange buffer, aliases the histogram
-    constexpr int XSIZE = ((NP * XW > NB ? NP * XW : NB) + 1) & ~1;
-    int32_t *sHist = reinterpret_cast<int32_t *>(sX);
+    uint32_t *sX = reinterpret_cast<uint32_t *>(sS + (SLDS ? gp.n_kfv * NB : 0));   // exchange buffer; aliases the first-window scratch
+    constexpr int FWS = HIST ? NB : KGMA_MAX_NK + 1;   // first-window scratch: histogram or k-mer list
+    constexpr int XSIZE = ((NP * XW > FWS ? NP * XW : FWS) + 1) & ~1;
     int32_t *sMisc = reinterpret_cast<int32_t *>(sX + XSIZE);
     int64_t *sRed = reinterpret_cast<int64_t *>(sMisc + 16 + KGMA_THREADS);
+    int64_t *sD0 = sRed + 4;
+    const int32_t *Sbase = SLDS ? sS : a.Stab;   // table of KFV slot j at Sbase + j*NB
 
     // ---- stage planes (starting LH words before the first output word) and S tables -----------
     {
@@ -452,34 +467,54 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
             sH[w] = v.x;
             sL[w] = v.y;
         }
-        for (int i = tid; i < gp.n_kfv * NB; i += KGMA_THREADS) sS[i] = a.Stab[i];
-        for (int i = tid; i < NB; i += KGMA_THREADS) sHist[i] = 0;
+        if constexpr (SLDS)
+            for (int i = tid; i < gp.n_kfv * NB; i += KGMA_THREADS) sS[i] = a.Stab[i];
+        if constexpr (HIST)
+            for (int i = tid; i < NB; i += KGMA_THREADS) sX[i] = 0;
     }
     __syncthreads();
 
-    // ---- D of the tile's first window: histogram of its nk k-mers -----------------------------
-    for (int q = tid; q < nk; q += KGMA_THREADS) {
-        atomicAdd(&sHist[kmer_index_at<K>(sH, sL, 32 * LH + q)], 1);
+    // ---- D of the tile's first window (Kmers.jl:33-44 kmer_count! + the sqeuclidean call sites
+    //      GenomeMiner.jl:46-47 / OmnGenomeMiner.jl:73-74, in exact integers) ---------------------
+    if constexpr (HIST) {
+        // D = sum_x (S[x] - N c[x])^2 over a 4^k-bin histogram of the window's nk k-mers
+        int32_t *sHist = reinterpret_cast<int32_t *>(sX);
+        for (int q = tid; q < nk; q += KGMA_THREADS) atomicAdd(&sHist[kmer_index_at<K>(sH, sL, 32 * LH + q)], 1);
+        __syncthreads();
+        for (int j = 0; j < gp.n_kfv; j++) {
+            int64_t acc = 0;
+            const int64_t Nj = gp.N[j];
+            for (int x = tid; x < NB; x += KGMA_THREADS) {
+                const int64_t d = (int64_t)Sbase[j * NB + x] - Nj * (int64_t)sHist[x];
+                acc += d * d;
+            }
+            const int64_t D0 = block_sum_i64(acc, sRed, tid);
+            if (tid == 0) { a.D0out[(size_t)j * a.n_tiles + tile] = D0; sD0[j] = D0; }
+        }
+    } else {
+        // no 4^k table: D = sum S^2 - 2N sum_q S[K_q] + N^2 (nk + 2 #{q < q' : K_q == K_q'})
+        uint32_t *sK = sX;
+        for (int q = tid; q < nk; q += KGMA_THREADS) sK[q] = kmer_index_at<K>(sH, sL, 32 * LH + q);
+        __syncthreads();
+        int64_t pairs = 0;
+        {
+            const int pa = tid >> 4, pb = tid & 15;
+            for (int i = pa; i < nk; i += 16) {
+                const uint32_t ki = sK[i];
+                for (int jj = i + 1 + ((pb - (i + 1)) & 15); jj < nk; jj += 16) pairs += sK[jj] == ki;
+            }
+        }
+        pairs = block_sum_i64(pairs, sRed, tid);
+        for (int j = 0; j < gp.n_kfv; j++) {
+            int64_t acc = 0;
+            for (int q = tid; q < nk; q += KGMA_THREADS) acc += Sbase[j * NB + sK[q]];
+            const int64_t sumS = block_sum_i64(acc, sRed, tid);
+            const int64_t Nj = gp.N[j];
+            const int64_t D0 = gp.sumS2[j] - 2 * Nj * sumS + Nj * Nj * ((int64_t)nk + 2 * pairs);
+            if (tid == 0) { a.D0out[(size_t)j * a.n_tiles + tile] = D0; sD0[j] = D0; }
+        }
     }
     __syncthreads();
-    for (int j = 0; j < gp.n_kfv; j++) {
-        int64_t acc = 0;
-        const int64_t Nj = gp.N[j];
-        for (int x = tid; x < NB; x += KGMA_THREADS) {
-            const int64_t d = (int64_t)sS[j * NB + x] - Nj * (int64_t)sHist[x];
-            acc += d * d;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) acc += shfl_down_i64(acc, d);
-        if ((tid & 63) == 0) sRed[tid >> 6] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            const int64_t D0 = sRed[0] + sRed[1] + sRed[2] + sRed[3];
-            a.D0out[(size_t)j * a.n_tiles + tile] = D0;
-            sRed[4 + j] = D0;
-        }
-        __syncthreads();
-    }
 
     // ---- match loop ------------------------------------------------------------------------
     const int w0 = R * slot;                      // LDS word index of the lane's first word
@@ -652,7 +687,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
         constexpr bool SMALL = decltype(small_tag)::value;
         constexpr bool INTERIOR = decltype(interior_tag)::value;
         constexpr uint32_t IM = (1u << (2 * K)) - 1u;
-        const int32_t *S = sS + j * NB;
+        const int32_t *S = Sbase + j * NB;
         const int32_t Nj = gp.N[j];
 #pragma unroll
         for (int w = 0; w < R; w++) {
@@ -688,7 +723,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
     };
 
     for (int j = 0; j < ((gp.debug_skip & 2) ? 0 : gp.n_kfv); j++) {
-        const int64_t D0 = sRed[4 + j];
+        const int64_t D0 = sD0[j];
         const int64_t twoN = 2 * (int64_t)gp.N[j];
         int64_t TE64;
         bool t_exact;
@@ -803,14 +838,18 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
 // ------------------------------------------------------------------------------------------
 // launch wrappers (called from kgma_api.cpp)
 // ------------------------------------------------------------------------------------------
+bool scan_tables_in_lds(int k, int n_kfv) { return ((size_t)n_kfv << (2 * k)) * 4 <= 65536; }
+
 size_t scan_lds_bytes(int k, int nk, int n_kfv, int R, int NP)
 {
     const size_t TW = (size_t)V2_SLOTS * R;
     const size_t NW = TW + scan_pad_words(nk);
     const size_t NB = (size_t)1 << (2 * k);
     const size_t XW = TW + 72;
-    const size_t xsize = (((size_t)NP * XW > NB ? (size_t)NP * XW : NB) + 1) & ~(size_t)1;
-    return (2 * NW + (size_t)n_kfv * NB + xsize + 16 + KGMA_THREADS) * 4 + (4 + KGMA_MAX_GROUP) * 8 + 64;
+    const size_t fws = k <= 6 ? NB : (size_t)KGMA_MAX_NK + 1;
+    const size_t xsize = (((size_t)NP * XW > fws ? (size_t)NP * XW : fws) + 1) & ~(size_t)1;
+    const size_t tables = scan_tables_in_lds(k, n_kfv) ? (size_t)n_kfv * NB : 0;
+    return (2 * NW + tables + xsize + 16 + KGMA_THREADS) * 4 + (4 + KGMA_MAX_GROUP) * 8 + 64;
 }
 
 int scan_tile_stride_words(int nk) { return v2_stride_words(nk, KGMA_R); }
@@ -856,28 +895,44 @@ hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int
     return hipGetLastError();
 }
 
-template <int K, int R, int NP>
+template <int K, int R, int NP, bool SLDS>
 static hipError_t launch_scan_krn(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
 {
     const size_t lds = scan_lds_bytes(K, gp.nk, gp.n_kfv, R, NP);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K, R, NP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K, R, NP, SLDS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((scan_kernel<K, R, NP>), dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
+    hipLaunchKernelGGL((scan_kernel<K, R, NP, SLDS>), dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
     return hipGetLastError();
+}
+
+template <int K, int NP>
+static hipError_t launch_scan_kn(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+{
+    constexpr int R = KGMA_R;
+    const bool slds = scan_tables_in_lds(K, gp.n_kfv);
+    if constexpr (K <= 5) {
+        return launch_scan_krn<K, R, NP, true>(a, gp, st);      // up to 8 tables of <= 4 KiB always fit
+    } else if constexpr (K <= 7) {
+        return slds ? launch_scan_krn<K, R, NP, true>(a, gp, st) : launch_scan_krn<K, R, NP, false>(a, gp, st);
+    } else {
+        return launch_scan_krn<K, R, NP, false>(a, gp, st);
+    }
 }
 
 template <int NP>
 static hipError_t launch_scan_n(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
 {
-    constexpr int R = KGMA_R;
     switch (gp.k) {
-    case 2: return launch_scan_krn<2, R, NP>(a, gp, st);
-    case 3: return launch_scan_krn<3, R, NP>(a, gp, st);
-    case 4: return launch_scan_krn<4, R, NP>(a, gp, st);
-    case 5: return launch_scan_krn<5, R, NP>(a, gp, st);
-    case 6: return launch_scan_krn<6, R, NP>(a, gp, st);
-    case 7: return launch_scan_krn<7, R, NP>(a, gp, st);
+    case 2: return launch_scan_kn<2, NP>(a, gp, st);
+    case 3: return launch_scan_kn<3, NP>(a, gp, st);
+    case 4: return launch_scan_kn<4, NP>(a, gp, st);
+    case 5: return launch_scan_kn<5, NP>(a, gp, st);
+    case 6: return launch_scan_kn<6, NP>(a, gp, st);
+    case 7: return launch_scan_kn<7, NP>(a, gp, st);
+    case 8: return launch_scan_kn<8, NP>(a, gp, st);
+    case 9: return launch_scan_kn<9, NP>(a, gp, st);
+    case 10: return launch_scan_kn<10, NP>(a, gp, st);
     default: return hipErrorInvalidValue;
     }
 }

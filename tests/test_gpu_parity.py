@@ -207,6 +207,32 @@ def test_random_genomes_omn(ctx, alp_clusters, genes, seed):
                 assert any(x["flags"] for x in dips)
 
 
+@pytest.mark.parametrize("k", [5, 7, 8])
+def test_cluster_mode_other_k(ctx, data_dir, genes, k):
+    """Cluster engine at other k: S tables in LDS (k=5), in global memory (k=7: 5 x 64 KiB, k=8)."""
+    tf = os.path.join(data_dir, "Alp_V_ref.fasta")
+    KFVs, ws, cons, inv, ints = refprep.cluster_ref_API(tf, k, cutoffs=[7, 12, 20, 25], include_avg=True, return_int=True)
+    KFVs, ws, cons, ints = refprep.eliminate_null_params(KFVs, ws, cons, inv, ints)
+    S = [x for x, _ in ints]; N = [n for _, n in ints]
+    rng = np.random.default_rng(k)
+    contigs, _ = make_genome(rng, [50000, 16000, 400], genes, n_plants_per_mb=200)
+    base_thr = {5: 60.0, 7: 26.0, 8: 23.0}[k]
+    thr = [base_thr + 2 * j for j in range(len(ws))]
+    ctx.set_refs(k, KFVs, ws, thr, N)
+    gen = ctx.genome_from_host(contigs)
+    ctx.scan(gen, _lib.MODE_OMN, 100, 0, _lib.F_RETURN_DISTS, None)
+    hits = ctx.hits()
+    dists = [ctx.dists(j + 1) for j in range(len(ws))]
+    gen.free()
+    T = [orc.int_threshold(t, k, n) for t, n in zip(thr, N)]
+    ohi, oD = orc.omn_scan_int(contigs, S, N, k, ws, T, 100, 0, return_D=True)
+    assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi]
+    assert [h["D"] for h in hits] == [h["D"] for h in ohi]
+    assert len(hits) > 0
+    for j in range(len(ws)):
+        assert np.array_equal(dists[j], oD[j] / (2.0 * k * N[j] ** 2))
+
+
 def test_bad_base_errors(ctx, alp_ref, alp_clusters):
     rng = np.random.default_rng(3)
     W = alp_ref["ws"]
@@ -251,7 +277,7 @@ def test_other_k_values(ctx, data_dir, genes):
     rng = np.random.default_rng(9)
     tf = os.path.join(data_dir, "Alp_V_ref.fasta")
     contigs, _ = make_genome(rng, [40000, 33100, 500], genes, n_plants_per_mb=200)
-    for k, thr in ((2, 300.0), (3, 200.0), (4, 120.0), (5, 60.0), (7, 25.0)):
+    for k, thr in ((2, 300.0), (3, 200.0), (4, 120.0), (5, 60.0), (7, 25.0), (8, 22.0), (9, 20.0), (10, 18.0)):
         RV, ws, cons, (S, N) = refprep.gen_ref_ws_cons(tf, k, return_int=True)
         ref = dict(RV=RV, ws=ws, S=S, N=N, k=k)
         _assert_single_parity(ctx, contigs, ref, thr)
