@@ -424,8 +424,9 @@ __device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t *sRed, int t
     return sRed[0] + sRed[1] + sRed[2] + sRed[3];
 }
 
-// SLDS: the S tables of the launch fit in LDS (else they are read from global memory / L2).
-template <int K, int R, int NP, bool SLDS>
+// The S tables stay in global memory: the two gathers per window of the position phase are served
+// by L1/L2 (16 KiB per KFV at k=6) as fast as from LDS, without a per-tile copy or LDS footprint.
+template <int K, int R, int NP>
 __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupParams gp)
 {
     constexpr bool HIST = K <= 6;                // first-window D from an LDS histogram (else by pair counting)
@@ -450,16 +451,15 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
 
     uint32_t *sH = smem;
     uint32_t *sL = sH + NW;
-    int32_t *sS = reinterpret_cast<int32_t *>(sL + NW);
-    uint32_t *sX = reinterpret_cast<uint32_t *>(sS + (SLDS ? gp.n_kfv * NB : 0));   // exchange buffer; aliases the first-window scratch
+    uint32_t *sX = sL + NW;                       // exchange buffer; aliases the first-window scratch
     constexpr int FWS = HIST ? NB : KGMA_MAX_NK + 1;   // first-window scratch: histogram or k-mer list
     constexpr int XSIZE = ((NP * XW > FWS ? NP * XW : FWS) + 1) & ~1;
     int32_t *sMisc = reinterpret_cast<int32_t *>(sX + XSIZE);
     int64_t *sRed = reinterpret_cast<int64_t *>(sMisc + 16 + KGMA_THREADS);
     int64_t *sD0 = sRed + 4;
-    const int32_t *Sbase = SLDS ? sS : a.Stab;   // table of KFV slot j at Sbase + j*NB
+    const int32_t *__restrict__ Sbase = a.Stab;  // table of KFV slot j at Sbase + j*NB (global memory)
 
-    // ---- stage planes (starting LH words before the first output word) and S tables -----------
+    // ---- stage planes (starting LH words before the first output word) ------------------------------
     {
         const uint2 *g2 = reinterpret_cast<const uint2 *>(a.planes) + (td.word_base - LH);
         for (int w = tid; w < NW; w += KGMA_THREADS) {
@@ -467,8 +467,6 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
             sH[w] = v.x;
             sL[w] = v.y;
         }
-        if constexpr (SLDS)
-            for (int i = tid; i < gp.n_kfv * NB; i += KGMA_THREADS) sS[i] = a.Stab[i];
         if constexpr (HIST)
             for (int i = tid; i < NB; i += KGMA_THREADS) sX[i] = 0;
     }
@@ -838,8 +836,6 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
 // ------------------------------------------------------------------------------------------
 // launch wrappers (called from kgma_api.cpp)
 // ------------------------------------------------------------------------------------------
-bool scan_tables_in_lds(int k, int n_kfv) { return ((size_t)n_kfv << (2 * k)) * 4 <= 65536; }
-
 size_t scan_lds_bytes(int k, int nk, int n_kfv, int R, int NP)
 {
     const size_t TW = (size_t)V2_SLOTS * R;
@@ -848,8 +844,8 @@ size_t scan_lds_bytes(int k, int nk, int n_kfv, int R, int NP)
     const size_t XW = TW + 72;
     const size_t fws = k <= 6 ? NB : (size_t)KGMA_MAX_NK + 1;
     const size_t xsize = (((size_t)NP * XW > fws ? (size_t)NP * XW : fws) + 1) & ~(size_t)1;
-    const size_t tables = scan_tables_in_lds(k, n_kfv) ? (size_t)n_kfv * NB : 0;
-    return (2 * NW + tables + xsize + 16 + KGMA_THREADS) * 4 + (4 + KGMA_MAX_GROUP) * 8 + 64;
+    (void)n_kfv;
+    return (2 * NW + xsize + 16 + KGMA_THREADS) * 4 + (4 + KGMA_MAX_GROUP) * 8 + 64;
 }
 
 int scan_tile_stride_words(int nk) { return v2_stride_words(nk, KGMA_R); }
@@ -895,29 +891,16 @@ hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int
     return hipGetLastError();
 }
 
-template <int K, int R, int NP, bool SLDS>
-static hipError_t launch_scan_krn(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
-{
-    const size_t lds = scan_lds_bytes(K, gp.nk, gp.n_kfv, R, NP);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K, R, NP, SLDS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((scan_kernel<K, R, NP, SLDS>), dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
-    return hipGetLastError();
-}
-
 template <int K, int NP>
 static hipError_t launch_scan_kn(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
 {
     constexpr int R = KGMA_R;
-    const bool slds = scan_tables_in_lds(K, gp.n_kfv);
-    if constexpr (K <= 5) {
-        return launch_scan_krn<K, R, NP, true>(a, gp, st);      // up to 8 tables of <= 4 KiB always fit
-    } else if constexpr (K <= 7) {
-        return slds ? launch_scan_krn<K, R, NP, true>(a, gp, st) : launch_scan_krn<K, R, NP, false>(a, gp, st);
-    } else {
-        return launch_scan_krn<K, R, NP, false>(a, gp, st);
-    }
+    const size_t lds = scan_lds_bytes(K, gp.nk, gp.n_kfv, R, NP);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K, R, NP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((scan_kernel<K, R, NP>), dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
+    return hipGetLastError();
 }
 
 template <int NP>
