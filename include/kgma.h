@@ -58,8 +58,10 @@ enum {
 
 /* flags for kgma_scan */
 enum {
-    KGMA_F_RETURN_DISTS = 1u << 0   /* do_return_dists: keep the per-window distances on the device
+    KGMA_F_RETURN_DISTS = 1u << 0,  /* do_return_dists: keep the per-window distances on the device
                                        for kgma_get_dists (8 B per window per KFV)                   */
+    KGMA_F_NO_TIE_RESOLVE = 1u << 1 /* keep exact-arithmetic tie-breaking (first tied window) instead of
+                                       replaying the reference's Float64 rounding over tied minima   */
 };
 
 /* flags in kgma_hit.flags / kgma_dip.flags */
@@ -67,7 +69,10 @@ enum {
     KGMA_HIT_TIE = 1u << 0,        /* the dip's minimum is attained at >=2 positions that are not one
                                       contiguous plateau: exact arithmetic reports the FIRST; the
                                       reference's choice there depends on Float64 rounding noise     */
-    KGMA_HIT_AT_THRESHOLD = 1u << 1 /* some window of the dip (or its exit) has D == T exactly        */
+    KGMA_HIT_AT_THRESHOLD = 1u << 1,/* some window of the dip (or its exit) has D == T exactly        */
+    KGMA_HIT_TIE_RESOLVED = 1u << 2 /* a tie of the kind above, decided the way the reference's Float64
+                                      update decides it (host replay over the tied stretch; the order is
+                                      independent of the chain's history, see kgma_api.cpp)           */
 };
 
 typedef struct kgma_ctx kgma_ctx;

@@ -64,6 +64,7 @@ struct KfvInfo {
     int64_t T = 0;
     int64_t sumS2 = 0;
     std::vector<int64_t> S;   // natural k-mer order
+    std::vector<double> ref;  // the KFV as given (Float64), for the tie resolver
 };
 
 struct Group {
@@ -120,6 +121,7 @@ struct kgma_ctx {
     int64_t tk_bases = 0, tk_windows = 0;
     std::vector<int64_t> D0;                 // [m][n_tiles] (slot = kfv index)
     std::vector<kgma_dip> dips;
+    std::vector<int64_t> dip_argl;           // last window attaining the minimum (parallel to dips)
     std::vector<kgma_hit> hits;
     std::vector<int64_t> contig_len;
     int64_t n_dists_per_kfv = 0;
@@ -334,6 +336,7 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
             if (N == 0) return fail(ctx, KGMA_E_UNSUPPORTED, "KFV %d is not of the form S/N with integer S and N <= 2^20", j + 1);
         }
         f.N = N;
+        f.ref.assign(r, r + NB);
         f.S.resize((size_t)NB);
         __int128 s2 = 0;
         for (int64_t x = 0; x < NB; x++) {
@@ -762,6 +765,7 @@ int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
         return a.kind < b.kind;
     });
     ctx->dips.clear();
+    ctx->dip_argl.clear();
     int64_t n_tie = 0;
     size_t i = 0;
     const size_t n = fr.size();
@@ -817,6 +821,7 @@ int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
         if ((d.exit_pos && d.D_exit == ctx->kfv[(size_t)cur.kfv].T) || att_at(cur.contig, cur.kfv, cur.start - 1))
             d.flags |= KGMA_HIT_AT_THRESHOLD;
         ctx->dips.push_back(d);
+        ctx->dip_argl.push_back(cur.argl);
         i = jx > i ? jx : i + 1;
     }
     ctx->stats.n_dips = (int64_t)ctx->dips.size();
@@ -1077,6 +1082,126 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     return KGMA_OK;
 }
 
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// Tie resolution.  Two situations are decided by Float64 rounding in the reference, not by the
+// exact distances: (A) a dip whose exact minimum is attained at several separated windows -- the
+// reference keeps the first window whose running Float64 value is strictly below all earlier ones
+// (GenomeMiner.jl:82-87); (B) a dip whose exact minimum EQUALS the stale running minimum left by an
+// earlier, suppressed dip (GenomeMiner.jl:93-103) -- whether `kmerDist < currminim` holds is then
+// rounding noise.  Inside one binade every value of the chain is a multiple of the same ulp u, so
+// d_{t+1} = d_t + round_u(inc_t): the DIFFERENCE between the chain values at two windows does not
+// depend on the (unknown) low bits the chain carried in -- unless an addition lands exactly half
+// way between two doubles or the chain changes binade on the way.  The resolver replays the
+// reference's Float64 update (same operation order) from the window that set the running minimum
+// to the last tied window, on the host, over the residues of that stretch only.  If no step was
+// sensitive the outcome is what any IEEE-754 machine running the reference computes
+// (KGMA_HIT_TIE_RESOLVED); otherwise exact arithmetic's choice is kept and KGMA_HIT_TIE is set.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+inline int res_code(uint8_t b)
+{
+    switch (b & 0xDF) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    default: return 3;      // T and N (validated earlier)
+    }
+}
+
+struct TieResolver {
+    kgma_ctx *ctx;
+    const kgma_genome *g;
+    std::vector<int32_t> cnt;
+    std::vector<uint32_t> touched;
+    std::vector<uint8_t> seq;
+    static constexpr int64_t MAX_SPAN = 1 << 22;
+
+    struct Result { bool ok, sensitive, improved; int64_t pos; };
+
+    // Replays windows p_from .. cand_hi of record `contig` for KFV `kfv` (0-based).  The chain value
+    // at p_from stands for the running minimum (exact value D_from).  Candidates are the windows in
+    // [cand_lo, cand_hi] whose exact D equals Dmin.  With include_start the candidates must beat the
+    // value at p_from (case B); otherwise p_from == cand_lo is itself the first candidate (case A).
+    Result replay(int kfv, int64_t contig, int64_t p_from, int64_t D_from, int64_t cand_lo, int64_t cand_hi,
+                  int64_t Dmin, bool include_start)
+    {
+        Result r{false, true, false, cand_lo};
+        const KfvInfo &f = ctx->kfv[(size_t)kfv];
+        const int k = ctx->k;
+        const int64_t NB = (int64_t)1 << (2 * k);
+        const uint64_t mask = (uint64_t)NB - 1;
+        const int64_t W = f.W, N = f.N;
+        if (p_from < 1 || cand_hi < p_from || cand_hi - p_from > MAX_SPAN) return r;
+        const int64_t nbases = (cand_hi - p_from) + W;
+        if (p_from - 1 + nbases > g->cd[(size_t)contig].len) return r;
+        seq.resize((size_t)nbases);
+        (void)hipSetDevice(ctx->device);
+        if (hipMemcpy(seq.data(), g->d_ascii + g->cd[(size_t)contig].ascii_off + (p_from - 1), (size_t)nbases,
+                      hipMemcpyDeviceToHost) != hipSuccess) return r;
+        if (cnt.empty()) cnt.assign((size_t)NB, 0);
+        touched.clear();
+        uint64_t km = 0;
+        for (int64_t i = 0; i < W; i++) {
+            km = ((km << 2) & mask) | (uint64_t)res_code(seq[(size_t)i]);
+            if (i >= k - 1) { if (cnt[(size_t)km]++ == 0) touched.push_back((uint32_t)km); }
+        }
+        uint64_t left = 0, right = 0;
+        for (int64_t i = 0; i < k - 1; i++) left = (left << 2) | (uint64_t)res_code(seq[(size_t)i]);
+        for (int64_t i = W - k + 1; i < W; i++) right = (right << 2) | (uint64_t)res_code(seq[(size_t)i]);
+        const double SF = 1.0 / (double)k;
+        const double scale = 2.0 * (double)k * (double)N * (double)N;
+        int64_t D = D_from;
+        double dist = (double)D / scale;            // grid-aligned stand-in for the chain value at p_from
+        int e0;
+        const double m0 = std::frexp(dist, &e0);
+        bool sensitive = std::fabs(m0 - 0.5) < 1e-9 || std::fabs(m0 - 1.0) < 1e-9;   // chain may sit in the other binade
+        double best = dist;
+        bool improved = false;
+        int64_t best_pos = p_from;
+        bool consistent = true;
+        for (int64_t s = p_from; s < cand_hi; s++) {     // roll window s -> s+1  (GenomeMiner.jl:60-77)
+            const int64_t o = s - p_from;
+            left = ((left << 2) & mask) | (uint64_t)res_code(seq[(size_t)(o + k - 1)]);
+            right = ((right << 2) & mask) | (uint64_t)res_code(seq[(size_t)(o + W)]);
+            if (left != right) {
+                const int64_t cl = cnt[(size_t)left], cr = cnt[(size_t)right];
+                double t = (double)(1 + cr);
+                t = t + f.ref[(size_t)left];
+                t = t - f.ref[(size_t)right];
+                t = t - (double)cl;
+                const double inc = SF * t;
+                const double sum = dist + inc;
+                const double bb = sum - dist;                          // TwoSum: exact error of the addition
+                const double err = (dist - (sum - bb)) + (inc - bb);
+                int es;
+                (void)std::frexp(sum, &es);
+                if (std::fabs(err) == std::ldexp(1.0, es - 54) || es != e0) sensitive = true;
+                dist = sum;
+                D += 2 * N * N + 2 * N * ((f.S[(size_t)left] - N * cl) - (f.S[(size_t)right] - N * cr));
+                if (cnt[(size_t)right]++ == 0) touched.push_back((uint32_t)right);
+                cnt[(size_t)left]--;
+            }
+            const int64_t w = s + 1;
+            if (w >= cand_lo) {
+                if (D < Dmin) consistent = false;                      // the device minimum is exact: cannot happen
+                if (D == Dmin && dist < best) { best = dist; best_pos = w; improved = true; }
+            }
+        }
+        for (uint32_t x : touched) cnt[(size_t)x] = 0;
+        if (!consistent) return r;
+        (void)include_start;
+        r.ok = true; r.sensitive = sensitive; r.improved = improved; r.pos = best_pos;
+        return r;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
 // ------------------------------------------------------------------------------------------
 // scan: host replay of the hit state machine over the dips
 // ------------------------------------------------------------------------------------------
@@ -1086,6 +1211,9 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
     int rc = kgma_scan_device(ctx, g, mode, flags);
     if (rc) return rc;
     if (buff < 0) return fail(ctx, KGMA_E_ARG, "buff < 0");
+    const bool resolve = !(flags & KGMA_F_NO_TIE_RESOLVE);
+    TieResolver tr{ctx, g, {}, {}, {}};
+    int64_t n_resolved = 0, n_ambiguous = 0;
     const double t0 = now_ms();
     const int k = ctx->k;
     const int64_t n_tiles = (int64_t)ctx->tiles.size();
@@ -1102,16 +1230,42 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
             if (ctx->contig_nwin[(size_t)c] == 0) continue;            // L < W: :37-39
             const int64_t D1 = ctx->D0[(size_t)ctx->contig_tile_base[(size_t)c]];
             int64_t CMI = 2, goal_ind = 0, currmin = D1;               // :57
+            int64_t currmin_pos = 1;                                   // window whose value currminim holds
             bool stop = true;
             uint32_t cur_flags = 0;
             while (di < ctx->dips.size() && ctx->dips[di].contig < c) di++;
             for (; di < ctx->dips.size() && ctx->dips[di].contig == c; di++) {
-                const kgma_dip &d = ctx->dips[di];
-                if (d.D_min < currmin) {                               // :83-87 (strict running minimum)
+                kgma_dip &d = ctx->dips[di];
+                bool improved = d.D_min < currmin;                     // :83-87 (strict running minimum)
+                int64_t best_pos = d.argmin;
+                uint32_t dflags = d.flags;
+                if (resolve && improved && (d.flags & KGMA_HIT_TIE)) {
+                    // (A) several separated windows attain the dip's minimum
+                    const TieResolver::Result r = tr.replay(0, c, d.argmin, d.D_min, d.argmin, ctx->dip_argl[di], d.D_min, false);
+                    if (r.ok && !r.sensitive) {
+                        best_pos = r.pos;
+                        dflags = (dflags & ~(uint32_t)KGMA_HIT_TIE) | KGMA_HIT_TIE_RESOLVED;
+                        n_resolved++;
+                    } else n_ambiguous++;
+                } else if (resolve && !improved && d.D_min == currmin) {
+                    // (B) the dip's minimum equals the stale running minimum exactly
+                    const TieResolver::Result r = tr.replay(0, c, currmin_pos, currmin, d.start, ctx->dip_argl[di], d.D_min, true);
+                    if (r.ok && !r.sensitive) {
+                        dflags |= KGMA_HIT_TIE_RESOLVED;
+                        n_resolved++;
+                        if (r.improved) { improved = true; best_pos = r.pos; }
+                    } else { dflags |= KGMA_HIT_TIE; n_ambiguous++; }
+                } else if (!resolve && !improved && d.D_min == currmin) {
+                    dflags |= KGMA_HIT_TIE;
+                }
+                d.flags = dflags;
+                if (improved) {
                     currmin = d.D_min;
-                    CMI = d.argmin + k - 2;                            // i_left of the best window
+                    currmin_pos = best_pos;
+                    d.argmin = best_pos;
+                    CMI = best_pos + k - 2;                            // i_left of the best window
                     stop = false;
-                    cur_flags = d.flags;
+                    cur_flags = dflags;
                 }
                 if (d.exit_pos == 0) continue;                         // dip still open at the record end
                 if (!stop) {                                           // :90-104
@@ -1129,6 +1283,7 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
                         h.flags = cur_flags | (d.flags & KGMA_HIT_AT_THRESHOLD);
                         ctx->hits.push_back(h);
                         currmin = d.D_exit;                            // :102
+                        currmin_pos = d.exit_pos;
                     }
                 }
             }
@@ -1140,7 +1295,8 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
         std::vector<int64_t> curr_mins((size_t)m), CMIs((size_t)m);
         std::vector<char> stops((size_t)m);
         std::vector<uint32_t> cflags((size_t)m);
-        std::vector<const kgma_dip *> evs;
+        std::vector<kgma_dip *> evs;
+        std::vector<int64_t> min_pos((size_t)m, 1);
         for (int64_t c = 0; c < nc; c++) {
             const int64_t L = ctx->contig_len[(size_t)c];
             while (di < ctx->dips.size() && ctx->dips[di].contig < c) di++;
@@ -1149,7 +1305,7 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
                 const int64_t tb = ctx->contig_tile_base[(size_t)c];
                 for (int j = 0; j < m; j++) {                          // :61-82
                     curr_mins[(size_t)j] = ctx->D0[(size_t)j * (size_t)n_tiles + (size_t)tb];
-                    CMIs[(size_t)j] = 1; stops[(size_t)j] = 1; cflags[(size_t)j] = 0;
+                    CMIs[(size_t)j] = 1; stops[(size_t)j] = 1; cflags[(size_t)j] = 0; min_pos[(size_t)j] = 1;
                 }
                 evs.clear();
                 for (; di < ctx->dips.size() && ctx->dips[di].contig == c; di++) evs.push_back(&ctx->dips[di]);
@@ -1159,15 +1315,39 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
                     if (ea != eb) return ea < eb;
                     return a->kfv < b->kfv;
                 });
-                for (const kgma_dip *dp : evs) {
-                    const kgma_dip &d = *dp;
+                for (kgma_dip *dp : evs) {
+                    kgma_dip &d = *dp;
                     const int j = d.kfv - 1;
                     const KfvInfo &f = ctx->kfv[(size_t)j];
-                    if (d.D_min < curr_mins[(size_t)j]) {              // :114-119
+                    const size_t dix = (size_t)(dp - ctx->dips.data());
+                    bool improved = d.D_min < curr_mins[(size_t)j];    // :114-119
+                    int64_t best_pos = d.argmin;
+                    uint32_t dflags = d.flags;
+                    if (resolve && improved && (d.flags & KGMA_HIT_TIE)) {
+                        const TieResolver::Result r = tr.replay(j, c, d.argmin, d.D_min, d.argmin, ctx->dip_argl[dix], d.D_min, false);
+                        if (r.ok && !r.sensitive) {
+                            best_pos = r.pos;
+                            dflags = (dflags & ~(uint32_t)KGMA_HIT_TIE) | KGMA_HIT_TIE_RESOLVED;
+                            n_resolved++;
+                        } else n_ambiguous++;
+                    } else if (resolve && !improved && d.D_min == curr_mins[(size_t)j]) {
+                        const TieResolver::Result r = tr.replay(j, c, min_pos[(size_t)j], curr_mins[(size_t)j], d.start, ctx->dip_argl[dix], d.D_min, true);
+                        if (r.ok && !r.sensitive) {
+                            dflags |= KGMA_HIT_TIE_RESOLVED;
+                            n_resolved++;
+                            if (r.improved) { improved = true; best_pos = r.pos; }
+                        } else { dflags |= KGMA_HIT_TIE; n_ambiguous++; }
+                    } else if (!resolve && !improved && d.D_min == curr_mins[(size_t)j]) {
+                        dflags |= KGMA_HIT_TIE;
+                    }
+                    d.flags = dflags;
+                    if (improved) {
                         curr_mins[(size_t)j] = d.D_min;
-                        CMIs[(size_t)j] = d.argmin - 1;                // i = window start - 1
+                        min_pos[(size_t)j] = best_pos;
+                        d.argmin = best_pos;
+                        CMIs[(size_t)j] = best_pos - 1;                // i = window start - 1
                         stops[(size_t)j] = 0;
-                        cflags[(size_t)j] = d.flags;
+                        cflags[(size_t)j] = dflags;
                     }
                     if (d.exit_pos == 0) continue;
                     if (!stops[(size_t)j]) {                           // :122
@@ -1187,6 +1367,7 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
                                 ctx->hits.push_back(h);
                                 prev_lo = lo; prev_hi = hi;            // :152
                                 curr_mins[(size_t)j] = d.D_exit;       // :153
+                                min_pos[(size_t)j] = d.exit_pos;
                             }
                         }
                     }
@@ -1196,6 +1377,9 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
         }
     }
     ctx->stats.n_hits = (int64_t)ctx->hits.size();
+    ctx->stats.n_tie_flagged = 0;
+    for (const kgma_dip &dd : ctx->dips) ctx->stats.n_tie_flagged += (dd.flags & KGMA_HIT_TIE) ? 1 : 0;
+    (void)n_resolved; (void)n_ambiguous;
     ctx->stats.replay_ms = now_ms() - t0;
     return KGMA_OK;
 }

@@ -19,8 +19,8 @@ KGMA_OK = 0
 KGMA_E_ARG, KGMA_E_NODEVICE, KGMA_E_HIP, KGMA_E_BADBASE, KGMA_E_BOUNDS = 1, 2, 3, 4, 5
 KGMA_E_UNSUPPORTED, KGMA_E_OVERFLOW, KGMA_E_NOMEM, KGMA_E_STATE = 6, 7, 8, 9
 MODE_SINGLE, MODE_OMN = 0, 1
-F_RETURN_DISTS = 1
-HIT_TIE, HIT_AT_THRESHOLD = 1, 2
+F_RETURN_DISTS, F_NO_TIE_RESOLVE = 1, 2
+HIT_TIE, HIT_AT_THRESHOLD, HIT_TIE_RESOLVED = 1, 2, 4
 
 EXPORTS = [
     "kgma_version", "kgma_status_string", "kgma_last_error", "kgma_create", "kgma_destroy",

@@ -55,7 +55,7 @@ def test_config2_chr22_size_full_parity(ctx, refs):
     k, W, N = 6, refs["ws"], refs["N"]
     ctx.set_refs(k, [refs["RV"]], [W], [30.0], [N])
     g, plants = workloads.make_chr22_like(ctx, refs["genes"], seed=22)
-    ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)
+    ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_NO_TIE_RESOLVE, None)
     hits, st, dips = ctx.hits(), ctx.stats(), ctx.dips()
     assert st["bases_scanned"] == workloads.CHR22_LEN
     seq = _fetch_all(g, [workloads.CHR22_LEN])
@@ -65,14 +65,17 @@ def test_config2_chr22_size_full_parity(ctx, refs):
     assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi]
     assert [h["D"] for h in hits] == [h["D"] for h in ohi]
     assert np.array_equal(ctx.first_window(1), oD1)
-    if [hit_key(h) for h in hits] != [hit_key(h) for h in ohits]:
-        assert any(d["flags"] for d in dips)
-    for a, b in zip(hits, ohits):
+    # default mode: ties decided like the reference's Float64 update
+    ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)
+    hits_f, dips_f = ctx.hits(), ctx.dips()
+    if [hit_key(h) for h in hits_f] != [hit_key(h) for h in ohits]:
+        assert any(d["flags"] & (_lib.HIT_TIE | _lib.HIT_AT_THRESHOLD) for d in dips_f)
+    for a, b in zip(hits_f, ohits):
         if hit_key(a) == hit_key(b):
             assert abs(a["dist"] - b["dist"]) <= 1e-6 * b["dist"]
     assert len(hits) >= 40 and _assert_planted_found(hits, plants, W, k) >= 0.7 * len(plants)
     # idempotence: a second scan of the resident genome gives identical records
-    ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)
+    ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_NO_TIE_RESOLVE, None)
     assert ctx.hits() == hits
     g.free()
 
@@ -102,10 +105,19 @@ def test_config3_grch38_size_full_parity(ctx, refs):
     ctx.set_refs(k, [refs["RV"]], [W], [30.0], [N])
     g, plants, lens = workloads.make_grch38_like(ctx, refs["genes"], seed=38)
     ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)
+    hits_f, dips_f = ctx.hits(), ctx.dips()
+    ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_NO_TIE_RESOLVE, None)
     hits, st = ctx.hits(), ctx.stats()
     assert st["bases_scanned"] == sum(lens)
     seqs = _fetch_all(g, lens)
     g.free()
+    ohits, _ = orc.single_scan(seqs, refs["RV"], k, W, 30.0, 50, hit_cap=1 << 18)
+    bad = [(a, b) for a, b in zip(hits_f, ohits) if hit_key(a) != hit_key(b)]
+    assert len(hits_f) == len(ohits)
+    for a, b in bad:
+        assert a["flags"] & (_lib.HIT_TIE | _lib.HIT_AT_THRESHOLD)
+    print("GRCh38-size: dips", len(dips_f), "resolved ties", sum(1 for d in dips_f if d["flags"] & 4),
+          "unresolved", sum(1 for d in dips_f if d["flags"] & 1), "hits differing from the Float64 oracle", len(bad))
     T = orc.int_threshold(30.0, k, N)
     ohi, _, oD1 = orc.single_scan_int(seqs, refs["S"], N, k, W, T, 50, hit_cap=1 << 18)
     assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi]
@@ -122,7 +134,7 @@ def test_config4_cluster_mode_400mb(ctx):
     from kmergma_amd import fasta
     genes = [r.sequence.upper() for r in fasta.read_fasta(os.path.join(DATA, "Alp_V_ref.fasta"))]
     g, plants, lens = workloads.make_grch38_like(ctx, genes, seed=44, n_plants=128, scale=0.04)
-    ctx.scan(g, _lib.MODE_OMN, 100, 0, 0, None)
+    ctx.scan(g, _lib.MODE_OMN, 100, 0, _lib.F_NO_TIE_RESOLVE, None)
     hits = ctx.hits()
     seqs = _fetch_all(g, lens)
     g.free()
