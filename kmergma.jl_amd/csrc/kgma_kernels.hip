@@ -302,9 +302,15 @@ __host__ __device__ inline int scan_pad_words(int nk)
     return (nk + 16 + 31) / 32 + KGMA_R + 4;
 }
 
-__device__ __forceinline__ void emit_record(DevRecord *recs, unsigned int *rec_count,
-                                            unsigned int rec_cap, const DevRecord &r)
+// Records are compacted per workgroup: lanes append to an LDS staging block (LDS atomic cursor) and
+// the workgroup reserves its range of the global record array with ONE global atomic per KFV pass.
+// Only when the staging block is full does a lane fall back to a global atomic of its own.
+__device__ __forceinline__ void emit_record(DevRecord *stage, unsigned int *stage_count, unsigned int stage_cap,
+                                            DevRecord *recs, unsigned int *rec_count, unsigned int rec_cap,
+                                            const DevRecord &r)
 {
+    const unsigned int si = atomicAdd(stage_count, 1u);     // LDS
+    if (si < stage_cap) { stage[si] = r; return; }
     const unsigned int idx = atomicAdd(rec_count, 1u);
     if (idx < rec_cap) recs[idx] = r;
 }
@@ -664,6 +670,11 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
     const int qb = qa + 32 * R - 1;
     int32_t *sScan = sMisc;
     int32_t *sPrev = sMisc + 16;
+    // record staging reuses the exchange buffer (free once the window-coordinate counts are in registers)
+    DevRecord *sStage = reinterpret_cast<DevRecord *>(sX);
+    constexpr unsigned int STAGE_CAP = (unsigned int)((size_t)XSIZE * 4 / sizeof(DevRecord));
+    unsigned int *sStageCount = reinterpret_cast<unsigned int *>(sMisc + 8);
+    unsigned int *sStageBase = reinterpret_cast<unsigned int *>(sMisc + 9);
 
     // wave-uniform fast paths: every |fwd-back| < 8 (4 planes instead of NP+1), and every lane of
     // the wave strictly inside the tested range (no per-position validity predicates)
@@ -760,6 +771,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
             if (lane >= d) incl += t;
         }
         if (lane == 63) sScan[wave] = incl;
+        if (tid == 0) *sStageCount = 0;
         __syncthreads();
         int32_t offset = incl - total;
         for (int wv = 0; wv < wave; wv++) offset += sScan[wv];
@@ -800,21 +812,21 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
                         rec.start = run_start; rec.end = q - 1; rec.minE = minE;
                         rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
                         rec.exitE = E; rec.has_exit = q < n_valid ? 1 : 0;
-                        emit_record(a.recs, a.rec_count, a.rec_cap, rec);
+                        emit_record(sStage, sStageCount, STAGE_CAP, a.recs, a.rec_count, a.rec_cap, rec);
                         in_run = false;
                     } else if (q == qa && prev_under && q >= 0 && q < n_valid) {
                         DevRecord rec;
                         rec.tile = tile; rec.kind_kfv = REC_EXIT | (kid << 8);
                         rec.start = q; rec.end = q; rec.minE = E;
                         rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 1;
-                        emit_record(a.recs, a.rec_count, a.rec_cap, rec);
+                        emit_record(sStage, sStageCount, STAGE_CAP, a.recs, a.rec_count, a.rec_cap, rec);
                     }
                     if (t_exact && testable && E == TE) {
                         DevRecord rec;
                         rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8);
                         rec.start = q; rec.end = q; rec.minE = E;
                         rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
-                        emit_record(a.recs, a.rec_count, a.rec_cap, rec);
+                        emit_record(sStage, sStageCount, STAGE_CAP, a.recs, a.rec_count, a.rec_cap, rec);
                         atomicAdd(a.n_att, 1ull);
                     }
                 }
@@ -826,10 +838,27 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
                 rec.start = run_start; rec.end = qb; rec.minE = minE;
                 rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
                 rec.exitE = 0; rec.has_exit = 0;
-                emit_record(a.recs, a.rec_count, a.rec_cap, rec);
+                emit_record(sStage, sStageCount, STAGE_CAP, a.recs, a.rec_count, a.rec_cap, rec);
             }
         }
         __syncthreads();
+        // flush the staged records: one global atomic for the whole workgroup, coalesced copy
+        {
+            const unsigned int staged = *sStageCount < STAGE_CAP ? *sStageCount : STAGE_CAP;
+            if (staged) {
+                if (tid == 0) *sStageBase = atomicAdd(a.rec_count, staged);
+                __syncthreads();
+                const unsigned int base = *sStageBase;
+                constexpr int RW = (int)(sizeof(DevRecord) / 4);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(sStage);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(a.recs);
+                for (unsigned int i = tid; i < staged * RW; i += KGMA_THREADS) {
+                    const unsigned int rec_i = base + i / RW;
+                    if (rec_i < a.rec_cap) dst[(size_t)base * RW + i] = src[i];
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
