@@ -201,6 +201,9 @@ int64_t int_threshold(double thr, int k, int64_t N)
     return q > (__int128)INT64_MAX ? INT64_MAX : (int64_t)q;
 }
 
+// Launch groups: KFVs sorted by window size; a launch takes up to KGMA_MAX_GROUP KFVs whose sizes
+// span at most KGMA_MAX_DW with at most KGMA_MAX_SIZES distinct values (the match loop runs once, for
+// the largest).
 std::vector<Group> make_groups(const kgma_ctx *ctx, int mode)
 {
     std::vector<Group> gs;
@@ -208,11 +211,25 @@ std::vector<Group> make_groups(const kgma_ctx *ctx, int mode)
         gs.push_back(Group{ctx->kfv[0].W, {0}});
         return gs;
     }
-    for (int j = 0; j < ctx->m; j++) {
+    std::vector<int> order((size_t)ctx->m);
+    for (int j = 0; j < ctx->m; j++) order[(size_t)j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ctx->kfv[(size_t)a].W < ctx->kfv[(size_t)b].W; });
+    for (int j : order) {
+        const int64_t W = ctx->kfv[(size_t)j].W;
         bool placed = false;
-        for (auto &g : gs)
-            if (g.W == ctx->kfv[j].W && (int)g.kfvs.size() < KGMA_MAX_GROUP) { g.kfvs.push_back(j); placed = true; break; }
-        if (!placed) gs.push_back(Group{ctx->kfv[j].W, {j}});
+        if (!gs.empty()) {
+            Group &g = gs.back();
+            int distinct = 0;
+            int64_t last = -1;
+            for (int u : g.kfvs) { if (ctx->kfv[(size_t)u].W != last) { distinct++; last = ctx->kfv[(size_t)u].W; } }
+            const int64_t wmin = ctx->kfv[(size_t)g.kfvs.front()].W;
+            if ((int)g.kfvs.size() < KGMA_MAX_GROUP && W - wmin <= KGMA_MAX_DW && (W == last || distinct < KGMA_MAX_SIZES)) {
+                g.kfvs.push_back(j);
+                g.W = W;        // largest so far (sorted)
+                placed = true;
+            }
+        }
+        if (!placed) gs.push_back(Group{W, {j}});
     }
     return gs;
 }
@@ -990,7 +1007,6 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     }
 
     const std::vector<Group> groups = make_groups(ctx, mode);
-    const int64_t NB = (int64_t)1 << (2 * k);
     unsigned int n_recs = 0;
     for (int attempt = 0;; attempt++) {
         uint8_t *d_cnt = ctx->d_res;
@@ -1000,44 +1016,40 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         ctx->stats.n_launches = 0;
         for (const Group &gr : groups) {
-            // the KFVs of one launch must be contiguous rows of the S table
-            size_t i = 0;
-            while (i < gr.kfvs.size()) {
-                size_t jn = i + 1;
-                while (jn < gr.kfvs.size() && gr.kfvs[jn] == gr.kfvs[jn - 1] + 1) jn++;
-                GroupParams gp;
-                memset(&gp, 0, sizeof gp);
-                ScanArgs a;
-                memset(&a, 0, sizeof a);
-                gp.n_kfv = (int32_t)(jn - i);
-                gp.k = k;
-                gp.nk = (int32_t)(gr.W - k + 1);
-                gp.nblocks = scan_nblocks(gp.nk);
-                if (const char *ds = getenv("KGMA_DEBUG_SKIP")) gp.debug_skip = atoi(ds);   // timing experiments only
-                for (size_t u = i; u < jn; u++) {
-                    const int j = gr.kfvs[u];
-                    const KfvInfo &f = ctx->kfv[(size_t)j];
-                    gp.kfv_id[u - i] = j + 1;
-                    gp.N[u - i] = (int32_t)f.N;
-                    gp.T[u - i] = f.T;
-                    gp.sumS2[u - i] = f.sumS2;
-                    gp.inv_scale[u - i] = 2.0 * (double)k * (double)f.N * (double)f.N;
-                    a.dist[u - i] = want_dists ? ctx->d_dist[(size_t)j] : nullptr;
-                }
-                const int j0 = gr.kfvs[i];
-                a.planes = g->d_planes;
-                a.tiles = ctx->d_tiles;
-                a.Stab = ctx->d_Stab + (size_t)j0 * (size_t)NB;
-                a.D0out = d_D0 + (size_t)j0 * (size_t)n_tiles;
-                a.recs = d_recs;
-                a.rec_count = reinterpret_cast<unsigned int *>(d_cnt);
-                a.rec_cap = ctx->rec_cap;
-                a.n_tiles = (int32_t)n_tiles;
-                a.n_att = reinterpret_cast<unsigned long long *>(d_cnt + 8);
-                HIP_TRY(ctx, launch_scan(a, gp, ctx->stream));
-                ctx->stats.n_launches++;
-                i = jn;
+            GroupParams gp;
+            memset(&gp, 0, sizeof gp);
+            ScanArgs a;
+            memset(&a, 0, sizeof a);
+            gp.n_kfv = (int32_t)gr.kfvs.size();
+            gp.k = k;
+            gp.nk = (int32_t)(gr.W - k + 1);                                  // largest window of the launch
+            gp.nk_min = (int32_t)(ctx->kfv[(size_t)gr.kfvs.front()].W - k + 1);
+            gp.nblocks = scan_nblocks(gp.nk);
+            if (const char *ds = getenv("KGMA_DEBUG_SKIP")) gp.debug_skip = atoi(ds);   // timing experiments only
+            for (size_t u = 0; u < gr.kfvs.size(); u++) {
+                const int j = gr.kfvs[u];
+                const KfvInfo &f = ctx->kfv[(size_t)j];
+                const int32_t nkj = (int32_t)(f.W - k + 1);
+                if (gp.n_sizes == 0 || gp.sizes[gp.n_sizes - 1] != nkj) gp.sizes[gp.n_sizes++] = nkj;   // ascending
+                gp.nk_of[u] = nkj;
+                gp.kfv_id[u] = j + 1;
+                gp.N[u] = (int32_t)f.N;
+                gp.T[u] = f.T;
+                gp.sumS2[u] = f.sumS2;
+                gp.inv_scale[u] = 2.0 * (double)k * (double)f.N * (double)f.N;
+                a.dist[u] = want_dists ? ctx->d_dist[(size_t)j] : nullptr;
             }
+            a.planes = g->d_planes;
+            a.tiles = ctx->d_tiles;
+            a.Stab = ctx->d_Stab;                  // all tables; the kernel indexes by KFV id
+            a.D0out = d_D0;                        // [KFV id - 1][tile]
+            a.recs = d_recs;
+            a.rec_count = reinterpret_cast<unsigned int *>(d_cnt);
+            a.rec_cap = ctx->rec_cap;
+            a.n_tiles = (int32_t)n_tiles;
+            a.n_att = reinterpret_cast<unsigned long long *>(d_cnt + 8);
+            HIP_TRY(ctx, launch_scan(a, gp, ctx->stream));
+            ctx->stats.n_launches++;
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         // everything the host needs comes back behind ONE synchronisation (records beyond the

@@ -29,11 +29,19 @@ struct TileDesc {
     int32_t pad;
 };
 
-// Per-KFV parameters of one launch group (all KFVs of the group share the window size).
+constexpr int KGMA_MAX_SIZES = 4;                              // distinct window sizes per launch
+constexpr int KGMA_MAX_DW = 8;                                 // max spread of k-mers-per-window within a launch
+
+// Parameters of one launch: up to KGMA_MAX_GROUP KFVs whose window sizes differ by <= KGMA_MAX_DW
+// (<= KGMA_MAX_SIZES distinct values).  The match loop runs once, for the largest size.
 struct GroupParams {
-    int32_t n_kfv;                       // KFVs in this group (<= KGMA_MAX_GROUP)
+    int32_t n_kfv;                       // KFVs in this launch (<= KGMA_MAX_GROUP)
     int32_t k;                           // k-mer length
-    int32_t nk;                          // k-mers per window = W - k + 1
+    int32_t nk;                          // k-mers per window (W - k + 1) of the LARGEST window of the launch
+    int32_t nk_min;                      // ... of the smallest
+    int32_t n_sizes;                     // distinct sizes
+    int32_t sizes[KGMA_MAX_SIZES];       // distinct k-mers-per-window values, ascending
+    int32_t nk_of[KGMA_MAX_GROUP];       // k-mers per window of each KFV
     int32_t nblocks;                     // 16-offset blocks of the match loop
     int32_t debug_skip;                  // timing experiments only (bit 0: no match loop, bit 1: no position phase); 0 in product use
     int32_t pad0;

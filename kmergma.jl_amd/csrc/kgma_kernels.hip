@@ -432,7 +432,8 @@ __device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t *sRed, int t
 
 // The S tables stay in global memory: the two gathers per window of the position phase are served
 // by L1/L2 (16 KiB per KFV at k=6) as fast as from LDS, without a per-tile copy or LDS footprint.
-template <int K, int R, int NP>
+// MULTI: the launch holds more than one window size (correction masks, per-size counts).
+template <int K, int R, int NP, bool MULTI>
 __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupParams gp)
 {
     constexpr bool HIST = K <= 6;                // first-window D from an LDS histogram (else by pair counting)
@@ -452,7 +453,6 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
     const int nblocks = gp.nblocks;
     const int np = 16 * nblocks - 1;
     const int nblocks_run = (gp.debug_skip & 1) ? 0 : nblocks;
-    const int delta = np - nk;                   // 0..15
     const int NW = TW + scan_pad_words(nk);
 
     uint32_t *sH = smem;
@@ -463,7 +463,12 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
     int32_t *sMisc = reinterpret_cast<int32_t *>(sX + XSIZE);
     int64_t *sRed = reinterpret_cast<int64_t *>(sMisc + 16 + KGMA_THREADS);
     int64_t *sD0 = sRed + 4;
-    const int32_t *__restrict__ Sbase = a.Stab;  // table of KFV slot j at Sbase + j*NB (global memory)
+    // offsets o in [nk_min, nk): masks of the largest window that the smaller windows must not count
+    constexpr int CW = TW + 8;
+    const int nk_min = gp.nk_min;
+    const int DW = MULTI ? nk - nk_min : 0;      // 0 for single-size launches (no correction storage)
+    uint32_t *sC = reinterpret_cast<uint32_t *>(sD0 + KGMA_MAX_GROUP);     // [2][DW][CW]
+    const int32_t *__restrict__ Stab = a.Stab;   // table of KFV id at Stab + (id-1)*NB (global memory)
 
     // ---- stage planes (starting LH words before the first output word) ------------------------------
     {
@@ -481,41 +486,66 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
     // ---- D of the tile's first window (Kmers.jl:33-44 kmer_count! + the sqeuclidean call sites
     //      GenomeMiner.jl:46-47 / OmnGenomeMiner.jl:73-74, in exact integers) ---------------------
     if constexpr (HIST) {
-        // D = sum_x (S[x] - N c[x])^2 over a 4^k-bin histogram of the window's nk k-mers
+        // D = sum_x (S[x] - N c[x])^2 over a 4^k-bin histogram of the window's first nk_j k-mers;
+        // sizes ascending: the histogram grows by the few extra k-mers of the next size
         int32_t *sHist = reinterpret_cast<int32_t *>(sX);
-        for (int q = tid; q < nk; q += KGMA_THREADS) atomicAdd(&sHist[kmer_index_at<K>(sH, sL, 32 * LH + q)], 1);
-        __syncthreads();
-        for (int j = 0; j < gp.n_kfv; j++) {
-            int64_t acc = 0;
-            const int64_t Nj = gp.N[j];
-            for (int x = tid; x < NB; x += KGMA_THREADS) {
-                const int64_t d = (int64_t)Sbase[j * NB + x] - Nj * (int64_t)sHist[x];
-                acc += d * d;
+        int done = 0;
+        for (int zi = 0; zi < gp.n_sizes; zi++) {
+            const int nz = gp.sizes[zi];
+            for (int q = done + tid; q < nz; q += KGMA_THREADS) atomicAdd(&sHist[kmer_index_at<K>(sH, sL, 32 * LH + q)], 1);
+            done = nz;
+            __syncthreads();
+            for (int j = 0; j < gp.n_kfv; j++) {
+                if (gp.nk_of[j] != nz) continue;
+                const int32_t *S = Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
+                int64_t acc = 0;
+                const int64_t Nj = gp.N[j];
+                for (int x = tid; x < NB; x += KGMA_THREADS) {
+                    const int64_t d = (int64_t)S[x] - Nj * (int64_t)sHist[x];
+                    acc += d * d;
+                }
+                const int64_t D0 = block_sum_i64(acc, sRed, tid);
+                if (tid == 0) { a.D0out[(size_t)(gp.kfv_id[j] - 1) * a.n_tiles + tile] = D0; sD0[j] = D0; }
             }
-            const int64_t D0 = block_sum_i64(acc, sRed, tid);
-            if (tid == 0) { a.D0out[(size_t)j * a.n_tiles + tile] = D0; sD0[j] = D0; }
+            __syncthreads();
         }
     } else {
-        // no 4^k table: D = sum S^2 - 2N sum_q S[K_q] + N^2 (nk + 2 #{q < q' : K_q == K_q'})
+        // no 4^k table: D = sum S^2 - 2N sum_q S[K_q] + N^2 (nk_j + 2 #{q < q' < nk_j : K_q == K_q'})
         uint32_t *sK = sX;
         for (int q = tid; q < nk; q += KGMA_THREADS) sK[q] = kmer_index_at<K>(sH, sL, 32 * LH + q);
         __syncthreads();
-        int64_t pairs = 0;
+        int64_t pairs[KGMA_MAX_SIZES] = {0, 0, 0, 0};
         {
             const int pa = tid >> 4, pb = tid & 15;
             for (int i = pa; i < nk; i += 16) {
                 const uint32_t ki = sK[i];
-                for (int jj = i + 1 + ((pb - (i + 1)) & 15); jj < nk; jj += 16) pairs += sK[jj] == ki;
+                for (int jj = i + 1 + ((pb - (i + 1)) & 15); jj < nk; jj += 16) {
+                    if (sK[jj] == ki) {            // rare
+                        if constexpr (MULTI) {
+#pragma unroll
+                            for (int zi = 0; zi < KGMA_MAX_SIZES; zi++) pairs[zi] += (zi < gp.n_sizes && jj < gp.sizes[zi]) ? 1 : 0;
+                        } else {
+                            pairs[0] += 1;
+                        }
+                    }
+                }
             }
         }
-        pairs = block_sum_i64(pairs, sRed, tid);
+#pragma unroll
+        for (int zi = 0; zi < (MULTI ? KGMA_MAX_SIZES : 1); zi++)
+            if (zi < gp.n_sizes) pairs[zi] = block_sum_i64(pairs[zi], sRed, tid);
         for (int j = 0; j < gp.n_kfv; j++) {
+            const int32_t *S = Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
+            const int nj = gp.nk_of[j];
             int64_t acc = 0;
-            for (int q = tid; q < nk; q += KGMA_THREADS) acc += Sbase[j * NB + sK[q]];
+            for (int q = tid; q < nj; q += KGMA_THREADS) acc += S[sK[q]];
             const int64_t sumS = block_sum_i64(acc, sRed, tid);
+            int64_t pr = 0;
+#pragma unroll
+            for (int zi = 0; zi < KGMA_MAX_SIZES; zi++) pr = (zi < gp.n_sizes && gp.sizes[zi] == nj) ? pairs[zi] : pr;
             const int64_t Nj = gp.N[j];
-            const int64_t D0 = gp.sumS2[j] - 2 * Nj * sumS + Nj * Nj * ((int64_t)nk + 2 * pairs);
-            if (tid == 0) { a.D0out[(size_t)j * a.n_tiles + tile] = D0; sD0[j] = D0; }
+            const int64_t D0 = gp.sumS2[j] - 2 * Nj * sumS + Nj * Nj * ((int64_t)nj + 2 * pr);
+            if (tid == 0) { a.D0out[(size_t)(gp.kfv_id[j] - 1) * a.n_tiles + tile] = D0; sD0[j] = D0; }
         }
     }
     __syncthreads();
@@ -569,9 +599,18 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
             }                                                                              \
             F[R] = from_next_lane(F[0]);                                                   \
             const uint32_t sb = sb0 - (I);                                                 \
+            uint32_t G[R];                                                                 \
             _Pragma("unroll") for (int w = 0; w < R; w++) {                                \
+                G[w] = alignbit(F[w + 1], F[w], sb);                                       \
                 counter_add<I, NP>(cf[w], F[w]);                                           \
-                counter6_add<I>(cg[w], alignbit(F[w + 1], F[w], sb));                      \
+                counter6_add<I>(cg[w], G[w]);                                              \
+            }                                                                              \
+            if (MULTI && FORCE && (obase + (I)) >= nk_min && (obase + (I)) < nk && !dup) { \
+                const int dd = obase + (I) - nk_min;   /* smaller windows exclude this offset */ \
+                _Pragma("unroll") for (int w = 0; w < R; w++) {                            \
+                    sC[(0 * DW + dd) * CW + w0 + w] = F[w];                                \
+                    sC[(1 * DW + dd) * CW + w0 + w] = G[w];                                \
+                }                                                                          \
             }                                                                              \
         }
         KGMA_STEP2(0) KGMA_STEP2(1) KGMA_STEP2(2) KGMA_STEP2(3)
@@ -620,11 +659,63 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
         for (; blk < nblocks_run; blk++) run_block(blk, std::true_type{});
     }
 
-    // ---- bring TB from coordinates v = q - delta to window coordinates q ------------------------
-    __syncthreads();
+    const int n_valid = td.n_valid;
+    const int first_test = td.first_test;
+    const int lim = n_valid - 1;
+    const int qa = 32 * (w0 - LH);
+    const int qb = qa + 32 * R - 1;
+    int32_t *sScan = sMisc;
+    int32_t *sPrev = sMisc + 16;
+    // record staging reuses the exchange buffer (free while the window-coordinate counts are in registers)
+    DevRecord *sStage = reinterpret_cast<DevRecord *>(sX);
+    constexpr unsigned int STAGE_CAP = (unsigned int)((size_t)XSIZE * 4 / sizeof(DevRecord));
+    unsigned int *sStageCount = reinterpret_cast<unsigned int *>(sMisc + 8);
+    unsigned int *sStageBase = reinterpret_cast<unsigned int *>(sMisc + 9);
+    // leaving-k-mer anchor as a 2-bit interleaved stream (12 index bits = one alignbit + one and)
+    uint32_t IL[R + 1][2];
+#pragma unroll
+    for (int w = 0; w < R; w++) interleave32(A0h[w], A0l[w], IL[w][0], IL[w][1]);
+    IL[R][0] = from_next_lane(IL[0][0]); IL[R][1] = 0;
+
+  for (int zi = 0; zi < ((gp.debug_skip & 2) ? 0 : gp.n_sizes); zi++) {
+    // ======== one window size of the launch: nz k-mers per window ==================================
+    const int nz = gp.sizes[zi];
+    const int dz = nz - nk_min;                   // correction masks dz .. DW-1 belong to larger windows only
+    const int delta = np - nz;                    // v = q - delta
+    // ---- counts for THIS size: subtract the masks of offsets >= nz; bring TB to window coordinates
+    uint32_t TBz[R][NP], CFz[R][NP];
+#pragma unroll
+    for (int w = 0; w < R; w++) {
+        if constexpr (!MULTI) {
+#pragma unroll
+            for (int p = 0; p < NP; p++) { CFz[w][p] = cf[w].c[p]; TBz[w][p] = TB[w][p]; }
+        } else {
+            uint32_t fs[4] = {0, 0, 0, 0}, bs[4] = {0, 0, 0, 0};      // bit-sliced sums of <= 8 masks
+            for (int dd = dz; dd < DW; dd++) {
+                uint32_t cy = sC[(0 * DW + dd) * CW + w0 + w];
+#pragma unroll
+                for (int p = 0; p < 4; p++) { const uint32_t t = fs[p] & cy; fs[p] ^= cy; cy = t; }
+                cy = sC[(1 * DW + dd) * CW + w0 + w];
+#pragma unroll
+                for (int p = 0; p < 4; p++) { const uint32_t t = bs[p] & cy; bs[p] ^= cy; cy = t; }
+            }
+            uint32_t bwf = 0, bwb = 0;
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const uint32_t yf = p < 4 ? fs[p] : 0u, yb = p < 4 ? bs[p] : 0u;
+                const uint32_t xf = cf[w].c[p], xb = TB[w][p];
+                const uint32_t uf = xf ^ yf, ub = xb ^ yb;
+                CFz[w][p] = uf ^ bwf;
+                TBz[w][p] = ub ^ bwb;
+                bwf = (yf & uf) | (bwf & ~uf);
+                bwb = (yb & ub) | (bwb & ~ub);
+            }
+        }
+    }
+    __syncthreads();                              // staging / previous exchange readers are done
     if (!dup) {
 #pragma unroll
-        for (int p = 0; p < NP; p++) sX[p * XW + slot] = TB[R - 1][p];
+        for (int p = 0; p < NP; p++) sX[p * XW + slot] = TBz[R - 1][p];
     }
     __syncthreads();
     uint32_t dpl[R][NP + 1];
@@ -635,9 +726,9 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
             uint32_t bw = 0;
 #pragma unroll
             for (int p = 0; p < NP; p++) {
-                const uint32_t prev = w > 0 ? TB[w - 1][p] : (slot > 0 ? sX[p * XW + slot - 1] : 0u);
-                const uint32_t x = delta ? alignbit(TB[w][p], prev, sh) : TB[w][p];   // back mismatches at q
-                const uint32_t y = cf[w].c[p];                                         // fwd mismatches at q
+                const uint32_t prev = w > 0 ? TBz[w - 1][p] : (slot > 0 ? sX[p * XW + slot - 1] : 0u);
+                const uint32_t x = delta ? alignbit(TBz[w][p], prev, sh) : TBz[w][p];   // back mismatches at q
+                const uint32_t y = CFz[w][p];                                            // fwd mismatches at q
                 const uint32_t u = x ^ y;
                 dpl[w][p] = u ^ bw;
                 bw = (y & u) | (bw & ~u);
@@ -645,36 +736,21 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
             dpl[w][NP] = bw;
         }
     }
+    __syncthreads();                              // everyone has read the exchange buffer: staging may reuse it
 
-    // ---- position phase; local window q = 32*(R*slot - LH + w) + b -----------------------------
-    // k-mer indices come from 2-bit interleaved copies of the two anchors (offset 0: leaving
-    // k-mer, offset nk: entering k-mer): 12 index bits = one alignbit + one and.
-    uint32_t IL[R + 1][2], IR[R + 1][2];
+    // entering-k-mer anchor (offset nz) as an interleaved stream
+    uint32_t IR[R + 1][2];
     {
-        const int jn = nk >> 5;
-        const uint32_t sn = (uint32_t)(nk & 31);
+        const int jn = nz >> 5;
+        const uint32_t sn = (uint32_t)(nz & 31);
 #pragma unroll
         for (int w = 0; w < R; w++) {
-            interleave32(A0h[w], A0l[w], IL[w][0], IL[w][1]);
             const uint32_t anh = alignbit(sH[w0 + jn + w + 1], sH[w0 + jn + w], sn);
             const uint32_t anl = alignbit(sL[w0 + jn + w + 1], sL[w0 + jn + w], sn);
             interleave32(anh, anl, IR[w][0], IR[w][1]);
         }
-        IL[R][0] = from_next_lane(IL[0][0]); IL[R][1] = 0;
         IR[R][0] = from_next_lane(IR[0][0]); IR[R][1] = 0;
     }
-    const int n_valid = td.n_valid;
-    const int first_test = td.first_test;
-    const int lim = n_valid - 1;
-    const int qa = 32 * (w0 - LH);
-    const int qb = qa + 32 * R - 1;
-    int32_t *sScan = sMisc;
-    int32_t *sPrev = sMisc + 16;
-    // record staging reuses the exchange buffer (free once the window-coordinate counts are in registers)
-    DevRecord *sStage = reinterpret_cast<DevRecord *>(sX);
-    constexpr unsigned int STAGE_CAP = (unsigned int)((size_t)XSIZE * 4 / sizeof(DevRecord));
-    unsigned int *sStageCount = reinterpret_cast<unsigned int *>(sMisc + 8);
-    unsigned int *sStageBase = reinterpret_cast<unsigned int *>(sMisc + 9);
 
     // wave-uniform fast paths: every |fwd-back| < 8 (4 planes instead of NP+1), and every lane of
     // the wave strictly inside the tested range (no per-position validity predicates)
@@ -696,7 +772,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
         constexpr bool SMALL = decltype(small_tag)::value;
         constexpr bool INTERIOR = decltype(interior_tag)::value;
         constexpr uint32_t IM = (1u << (2 * K)) - 1u;
-        const int32_t *S = Sbase + j * NB;
+        const int32_t *S = Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
         const int32_t Nj = gp.N[j];
 #pragma unroll
         for (int w = 0; w < R; w++) {
@@ -731,7 +807,8 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
         }
     };
 
-    for (int j = 0; j < ((gp.debug_skip & 2) ? 0 : gp.n_kfv); j++) {
+    for (int j = 0; j < gp.n_kfv; j++) {
+        if (gp.nk_of[j] != nz) continue;
         const int64_t D0 = sD0[j];
         const int64_t twoN = 2 * (int64_t)gp.N[j];
         int64_t TE64;
@@ -860,12 +937,13 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
             __syncthreads();
         }
     }
+  }   // window sizes
 }
 
 // ------------------------------------------------------------------------------------------
 // launch wrappers (called from kgma_api.cpp)
 // ------------------------------------------------------------------------------------------
-size_t scan_lds_bytes(int k, int nk, int n_kfv, int R, int NP)
+size_t scan_lds_bytes(int k, int nk, int n_kfv, int R, int NP, int dw)
 {
     const size_t TW = (size_t)V2_SLOTS * R;
     const size_t NW = TW + scan_pad_words(nk);
@@ -874,7 +952,8 @@ size_t scan_lds_bytes(int k, int nk, int n_kfv, int R, int NP)
     const size_t fws = k <= 6 ? NB : (size_t)KGMA_MAX_NK + 1;
     const size_t xsize = (((size_t)NP * XW > fws ? (size_t)NP * XW : fws) + 1) & ~(size_t)1;
     (void)n_kfv;
-    return (2 * NW + xsize + 16 + KGMA_THREADS) * 4 + (4 + KGMA_MAX_GROUP) * 8 + 64;
+    return (2 * NW + xsize + 16 + KGMA_THREADS) * 4 + (4 + KGMA_MAX_GROUP) * 8 + 64 +
+           (size_t)2 * (size_t)dw * (TW + 8) * 4;
 }
 
 int scan_tile_stride_words(int nk) { return v2_stride_words(nk, KGMA_R); }
@@ -924,11 +1003,18 @@ template <int K, int NP>
 static hipError_t launch_scan_kn(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
 {
     constexpr int R = KGMA_R;
-    const size_t lds = scan_lds_bytes(K, gp.nk, gp.n_kfv, R, NP);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K, R, NP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((scan_kernel<K, R, NP>), dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
+    const size_t lds = scan_lds_bytes(K, gp.nk, gp.n_kfv, R, NP, gp.nk - gp.nk_min);
+    if (gp.n_sizes > 1) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K, R, NP, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((scan_kernel<K, R, NP, true>), dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
+    } else {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K, R, NP, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((scan_kernel<K, R, NP, false>), dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
+    }
     return hipGetLastError();
 }
 
