@@ -468,6 +468,10 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
     const int nk_min = gp.nk_min;
     const int DW = MULTI ? nk - nk_min : 0;      // 0 for single-size launches (no correction storage)
     uint32_t *sC = reinterpret_cast<uint32_t *>(sD0 + KGMA_MAX_GROUP);     // [2][DW][CW]
+    // one S table at a time in LDS for the position phase (k <= 6): a random 4-byte gather costs a wave
+    // ~8 LDS cycles but ~64 L1 cycles, which is what limits the cluster engine with its m passes
+    constexpr bool TLDS = K <= 6;
+    int32_t *sTab = reinterpret_cast<int32_t *>(sC + 2 * DW * CW);
     const int32_t *__restrict__ Stab = a.Stab;   // table of KFV id at Stab + (id-1)*NB (global memory)
 
     // ---- stage planes (starting LH words before the first output word) ------------------------------
@@ -772,7 +776,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
         constexpr bool SMALL = decltype(small_tag)::value;
         constexpr bool INTERIOR = decltype(interior_tag)::value;
         constexpr uint32_t IM = (1u << (2 * K)) - 1u;
-        const int32_t *S = Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
+        const int32_t *S = TLDS ? sTab : Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
         const int32_t Nj = gp.N[j];
 #pragma unroll
         for (int w = 0; w < R; w++) {
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
             for (int half = 0; half < 2; half++) {
                 const uint32_t l0 = half ? IL[w][1] : IL[w][0], l1 = half ? IL[w + 1][0] : IL[w][1];
                 const uint32_t r0 = half ? IR[w][1] : IR[w][0], r1 = half ? IR[w + 1][0] : IR[w][1];
-#pragma unroll 1
+#pragma unroll 4
                 for (uint32_t bb = 0; bb < 16; bb++) {
                     const uint32_t b = 16u * half + bb;
                     const uint32_t il = alignbit(l1, l0, 2u * bb) & IM;
@@ -809,18 +813,26 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
 
     for (int j = 0; j < gp.n_kfv; j++) {
         if (gp.nk_of[j] != nz) continue;
+        if constexpr (TLDS) {
+            const int32_t *Sg = Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
+            for (int i = tid; i < NB; i += KGMA_THREADS) sTab[i] = Sg[i];
+            __syncthreads();      // (the previous KFV's readers passed the barrier that ends its iteration)
+        }
         const int64_t D0 = sD0[j];
         const int64_t twoN = 2 * (int64_t)gp.N[j];
-        int64_t TE64;
-        bool t_exact;
-        {
+        // E_q < TE  <=>  D0 + 2N E_q < T   (64-bit division once per workgroup, by lane 0)
+        if (tid == 0) {
             const int64_t num = gp.T[j] - D0;
-            TE64 = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
-            t_exact = (num % twoN) == 0;
-            if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; t_exact = false; }
-            if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; t_exact = false; }
+            int64_t TE64 = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
+            int32_t ex = (num % twoN) == 0;
+            if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; ex = 0; }
+            if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; ex = 0; }
+            sMisc[10] = (int32_t)TE64;
+            sMisc[11] = ex;
         }
-        const int32_t TE = (int32_t)TE64;
+        __syncthreads();
+        const int32_t TE = sMisc[10];
+        const bool t_exact = sMisc[11] != 0;
 
         // pass A: lane-local prefix, its minimum over tested positions, and the lane total
         int32_t r = 0, rmin = 0x7FFFFFFF, rlast = 0;
@@ -953,7 +965,7 @@ size_t scan_lds_bytes(int k, int nk, int n_kfv, int R, int NP, int dw)
     const size_t xsize = (((size_t)NP * XW > fws ? (size_t)NP * XW : fws) + 1) & ~(size_t)1;
     (void)n_kfv;
     return (2 * NW + xsize + 16 + KGMA_THREADS) * 4 + (4 + KGMA_MAX_GROUP) * 8 + 64 +
-           (size_t)2 * (size_t)dw * (TW + 8) * 4;
+           (size_t)2 * (size_t)dw * (TW + 8) * 4 + (k <= 6 ? NB * 4 : 0);
 }
 
 int scan_tile_stride_words(int nk) { return v2_stride_words(nk, KGMA_R); }
