@@ -69,7 +69,10 @@ enum {
     KGMA_HIT_TIE = 1u << 0,        /* the dip's minimum is attained at >=2 positions that are not one
                                       contiguous plateau: exact arithmetic reports the FIRST; the
                                       reference's choice there depends on Float64 rounding noise     */
-    KGMA_HIT_AT_THRESHOLD = 1u << 1,/* some window of the dip (or its exit) has D == T exactly        */
+    KGMA_HIT_AT_THRESHOLD = 1u << 1,/* the window before the dip, or its exit window, has a distance
+                                      within a relative 2^-30 of thr (the guard band described at
+                                      kgma_set_refs): whether the reference sees it below thr is
+                                      Float64 rounding noise; the library counts it as NOT below       */
     KGMA_HIT_TIE_RESOLVED = 1u << 2 /* a tie of the kind above, decided the way the reference's Float64
                                       update decides it (host replay over the tied stretch; the order is
                                       independent of the chain's history, see kgma_api.cpp)           */
@@ -111,7 +114,9 @@ typedef struct {
 typedef struct {
     int64_t bases_scanned;     /* sum of contig lengths handed to the last scan                 */
     int64_t windows_scanned;   /* windows evaluated (all KFVs)                                  */
-    int64_t n_dips, n_hits, n_tie_flagged, n_at_threshold;
+    int64_t n_dips, n_hits;
+    int64_t n_tie_flagged;     /* dips left with KGMA_HIT_TIE (rounding-ambiguous, unresolved)      */
+    int64_t n_at_threshold;    /* tested windows inside the threshold guard band (all KFVs)         */
     double pack_ms, scan_ms;   /* device time of the last pack / scan kernels (hipEvents)       */
     double replay_ms;          /* host time of the hit state machine                            */
     int64_t device_bytes;      /* device memory held by the context + current genome            */
@@ -140,7 +145,12 @@ void kgma_destroy(kgma_ctx *ctx);
  * device computes in exact integers with S = round(ref*N).  n_refs == NULL: N is inferred
  * (smallest N <= 2^20 making ref*N integral to 1e-9); KGMA_E_UNSUPPORTED if none exists.
  * Requires 2 <= k <= 10, k < min(windowsizes) (src/API.jl:70,177) and at
- * most 2031 k-mers per window (windowsize - k + 1); KGMA_E_UNSUPPORTED otherwise. */
+ * most 2031 k-mers per window (windowsize - k + 1); KGMA_E_UNSUPPORTED otherwise.
+ * Threshold semantics: with D the exact integer form of the distance (d = D / (2 k N^2)) a window
+ * is below thr iff D < T, T = ceil(thr * 2kN^2 * (1 - 2^-30)).  The 2^-30 guard band stands for the
+ * rounding noise of the reference's rolling Float64 chain (GenomeMiner.jl:77): windows whose exact
+ * distance is that close to thr count as NOT below and are reported (KGMA_HIT_AT_THRESHOLD,
+ * kgma_stats.n_at_threshold).  Away from the distance lattice T = ceil(thr * 2kN^2) exactly. */
 int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const int64_t *windowsizes,
                   const double *thr, const int64_t *n_refs);
 

@@ -42,6 +42,7 @@ hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int
                         uint64_t seed, hipStream_t st);
 hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 hipError_t launch_fasta_count(const uint8_t *raw, int64_t n, uint32_t *counts, hipStream_t st);
+hipError_t launch_gather_ranges(const uint8_t *src, const int64_t *desc, int n, uint8_t *dst, hipStream_t st);
 hipError_t launch_fasta_scatter(const uint8_t *raw, int64_t n, const int64_t *block_base, const int64_t *rec_start,
                                 const ContigDesc *cd, int n_rec, uint8_t *ascii, hipStream_t st);
 int scan_tile_stride_words(int nk);
@@ -61,7 +62,8 @@ struct KfvInfo {
     int64_t W = 0;
     int64_t N = 0;
     double thr = 0;
-    int64_t T = 0;
+    int64_t T = 0;       // below thr  <=>  D < T
+    int64_t T_hi = -1;   // T <= D <= T_hi: at threshold (guard band, usually empty)
     int64_t sumS2 = 0;
     std::vector<int64_t> S;   // natural k-mer order
     std::vector<double> ref;  // the KFV as given (Float64), for the tie resolver
@@ -178,27 +180,38 @@ uint32_t device_index_of(uint32_t v, int k)
     return idx;
 }
 
-// smallest integer T with (D < T) <=> (D / (2 k N^2) < thr) in exact arithmetic
-int64_t int_threshold(double thr, int k, int64_t N)
+// Integer thresholds of one KFV.  thr * 2kN^2 is formed exactly (thr is a dyadic rational); windows
+// whose exact distance lies within a relative 2^-30 of thr are decided by accumulated rounding noise
+// in the reference's rolling Float64 chain (GenomeMiner.jl:77), so they form a guard band:
+//   T    = ceil (thr * 2kN^2 * (1 - 2^-30))   a window is below thr  <=>  D < T
+//   T_hi = floor(thr * 2kN^2 * (1 + 2^-30))   T <= D <= T_hi  <=>  "at threshold" (flagged)
+// For thresholds away from the distance lattice the band is empty (T_hi = T - 1) and T is exactly
+// ceil(thr * 2kN^2).
+void threshold_band(double thr, int k, int64_t N, int64_t *T_lo, int64_t *T_hi)
 {
-    if (!(thr > 0.0)) return 0;
-    if (thr >= 4.0e18) return INT64_MAX;
+    *T_lo = 0; *T_hi = -1;
+    if (!(thr > 0.0)) return;
+    if (thr >= 4.0e18) { *T_lo = INT64_MAX; return; }
     int e;
     const double fr = std::frexp(thr, &e);
     const int64_t mant = (int64_t)std::ldexp(fr, 53);
     e -= 53;
     const __int128 scale = (__int128)2 * k * N * N;
     const __int128 prod = (__int128)mant * scale;
+    const __int128 lo = prod - (prod >> 30), hi = prod + (prod >> 30);
+    auto clamp = [](__int128 v) { return v > (__int128)INT64_MAX ? INT64_MAX : (int64_t)v; };
     if (e >= 0) {
-        if (e > 60) return INT64_MAX;
-        const __int128 v = prod << e;
-        return v > (__int128)INT64_MAX ? INT64_MAX : (int64_t)v;
+        if (e > 60) { *T_lo = INT64_MAX; return; }
+        *T_lo = clamp(lo << e);
+        *T_hi = *T_lo == INT64_MAX ? -1 : clamp(hi << e);
+        return;
     }
     const int sh = -e;
-    if (sh >= 126) return 1;
-    __int128 q = prod >> sh;
-    if (prod - (q << sh) != 0) q += 1;
-    return q > (__int128)INT64_MAX ? INT64_MAX : (int64_t)q;
+    if (sh >= 126) { *T_lo = 1; *T_hi = 0; return; }
+    __int128 q = lo >> sh;
+    if (lo - (q << sh) != 0) q += 1;
+    *T_lo = clamp(q);
+    *T_hi = *T_lo == INT64_MAX ? -1 : clamp(hi >> sh);
 }
 
 // Launch groups: KFVs sorted by window size; a launch takes up to KGMA_MAX_GROUP KFVs whose sizes
@@ -313,7 +326,7 @@ int kgma_set_thresholds(kgma_ctx *ctx, const double *thr)
     if (ctx->m == 0) return fail(ctx, KGMA_E_STATE, "kgma_set_refs has not been called");
     for (int j = 0; j < ctx->m; j++) {
         ctx->kfv[j].thr = thr[j];
-        ctx->kfv[j].T = int_threshold(thr[j], ctx->k, ctx->kfv[j].N);
+        threshold_band(thr[j], ctx->k, ctx->kfv[j].N, &ctx->kfv[j].T, &ctx->kfv[j].T_hi);
     }
     return KGMA_OK;
 }
@@ -372,7 +385,7 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
                         (long long)N, (long long)nk);
         f.sumS2 = (int64_t)s2;
         f.thr = thr[j];
-        f.T = int_threshold(thr[j], k, N);
+        threshold_band(thr[j], k, N, &f.T, &f.T_hi);
     }
     // upload the plane-index permuted tables
     std::vector<int32_t> tab((size_t)m * (size_t)NB);
@@ -834,8 +847,12 @@ int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
                 d.D_exit = ctx->D0[(size_t)cur.kfv * (size_t)n_tiles + (size_t)t];
             }
         }
-        if (cur.nmin != cur.argl - cur.argf + 1) { d.flags |= KGMA_HIT_TIE; n_tie++; }
-        if ((d.exit_pos && d.D_exit == ctx->kfv[(size_t)cur.kfv].T) || att_at(cur.contig, cur.kfv, cur.start - 1))
+        // several windows attain the minimum: separated ones always need the Float64 replay; a contiguous
+        // plateau only when N is not a power of two (ref = S/N is then inexact and the reference's
+        // mathematically-zero increments are +-1 ulp noise; with dyadic ref they are exactly 0)
+        const int64_t Nk = ctx->kfv[(size_t)cur.kfv].N;
+        if (cur.nmin > 1 && (cur.nmin != cur.argl - cur.argf + 1 || (Nk & (Nk - 1)) != 0)) { d.flags |= KGMA_HIT_TIE; n_tie++; }
+        if ((d.exit_pos && d.D_exit <= ctx->kfv[(size_t)cur.kfv].T_hi) || att_at(cur.contig, cur.kfv, cur.start - 1))
             d.flags |= KGMA_HIT_AT_THRESHOLD;
         ctx->dips.push_back(d);
         ctx->dip_argl.push_back(cur.argl);
@@ -1035,6 +1052,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
                 gp.kfv_id[u] = j + 1;
                 gp.N[u] = (int32_t)f.N;
                 gp.T[u] = f.T;
+                gp.T_hi[u] = f.T_hi;
                 gp.sumS2[u] = f.sumS2;
                 gp.inv_scale[u] = 2.0 * (double)k * (double)f.N * (double)f.N;
                 a.dist[u] = want_dists ? ctx->d_dist[(size_t)j] : nullptr;
@@ -1128,8 +1146,54 @@ struct TieResolver {
     const kgma_genome *g;
     std::vector<int32_t> cnt;
     std::vector<uint32_t> touched;
-    std::vector<uint8_t> seq;
+    std::vector<uint8_t> seqbuf;
+    std::vector<uint8_t> pre;            // residues under the tied stretch of every TIE-flagged dip (one gather)
+    std::vector<int64_t> pre_off;        // per dip: offset into `pre`, or -1
     static constexpr int64_t MAX_SPAN = 1 << 22;
+    static constexpr int64_t MAX_PREFETCH = (int64_t)256 << 20;
+
+    // One gather launch + one download for all case-(A) dips (instead of a blocking copy per dip).
+    void prefetch()
+    {
+        const size_t nd = ctx->dips.size();
+        pre_off.assign(nd, -1);
+        std::vector<int64_t> desc;
+        int64_t total = 0;
+        for (size_t i = 0; i < nd; i++) {
+            const kgma_dip &d = ctx->dips[i];
+            if (!(d.flags & KGMA_HIT_TIE)) continue;
+            const int64_t W = ctx->kfv[(size_t)(d.kfv - 1)].W;
+            const int64_t span = ctx->dip_argl[i] - d.argmin;
+            if (d.argmin < 1 || span < 0 || span > MAX_SPAN) continue;
+            const int64_t nb = span + W;
+            if (d.argmin - 1 + nb > g->cd[(size_t)d.contig].len || total + nb > MAX_PREFETCH) continue;
+            desc.push_back(g->cd[(size_t)d.contig].ascii_off + (d.argmin - 1));
+            desc.push_back(total);
+            desc.push_back(nb);
+            pre_off[i] = total;
+            total += nb;
+        }
+        if (desc.empty()) return;
+        (void)hipSetDevice(ctx->device);
+        int64_t *d_desc = nullptr;
+        uint8_t *d_dst = nullptr;
+        bool ok = hipMalloc(reinterpret_cast<void **>(&d_desc), desc.size() * sizeof(int64_t)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void **>(&d_dst), (size_t)total) == hipSuccess;
+        if (ok) {
+            pre.resize((size_t)total);
+            ok = hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                 launch_gather_ranges(g->d_ascii, d_desc, (int)(desc.size() / 3), d_dst, ctx->stream) == hipSuccess &&
+                 hipMemcpyAsync(pre.data(), d_dst, (size_t)total, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                 hipStreamSynchronize(ctx->stream) == hipSuccess;
+        }
+        if (d_desc) (void)hipFree(d_desc);
+        if (d_dst) (void)hipFree(d_dst);
+        if (!ok) pre_off.assign(nd, -1);       // replay() falls back to its own copies
+    }
+    const uint8_t *prefetched(size_t dip_index) const
+    {
+        return dip_index < pre_off.size() && pre_off[dip_index] >= 0 ? pre.data() + pre_off[dip_index] : nullptr;
+    }
 
     struct Result { bool ok, sensitive, improved; int64_t pos; };
 
@@ -1138,7 +1202,7 @@ struct TieResolver {
     // [cand_lo, cand_hi] whose exact D equals Dmin.  With include_start the candidates must beat the
     // value at p_from (case B); otherwise p_from == cand_lo is itself the first candidate (case A).
     Result replay(int kfv, int64_t contig, int64_t p_from, int64_t D_from, int64_t cand_lo, int64_t cand_hi,
-                  int64_t Dmin, bool include_start)
+                  int64_t Dmin, bool include_start, const uint8_t *residues = nullptr)
     {
         Result r{false, true, false, cand_lo};
         const KfvInfo &f = ctx->kfv[(size_t)kfv];
@@ -1149,10 +1213,14 @@ struct TieResolver {
         if (p_from < 1 || cand_hi < p_from || cand_hi - p_from > MAX_SPAN) return r;
         const int64_t nbases = (cand_hi - p_from) + W;
         if (p_from - 1 + nbases > g->cd[(size_t)contig].len) return r;
-        seq.resize((size_t)nbases);
-        (void)hipSetDevice(ctx->device);
-        if (hipMemcpy(seq.data(), g->d_ascii + g->cd[(size_t)contig].ascii_off + (p_from - 1), (size_t)nbases,
-                      hipMemcpyDeviceToHost) != hipSuccess) return r;
+        const uint8_t *seq = residues;
+        if (!seq) {
+            seqbuf.resize((size_t)nbases);
+            (void)hipSetDevice(ctx->device);
+            if (hipMemcpy(seqbuf.data(), g->d_ascii + g->cd[(size_t)contig].ascii_off + (p_from - 1), (size_t)nbases,
+                          hipMemcpyDeviceToHost) != hipSuccess) return r;
+            seq = seqbuf.data();
+        }
         if (cnt.empty()) cnt.assign((size_t)NB, 0);
         touched.clear();
         uint64_t km = 0;
@@ -1224,7 +1292,8 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
     if (rc) return rc;
     if (buff < 0) return fail(ctx, KGMA_E_ARG, "buff < 0");
     const bool resolve = !(flags & KGMA_F_NO_TIE_RESOLVE);
-    TieResolver tr{ctx, g, {}, {}, {}};
+    TieResolver tr{ctx, g, {}, {}, {}, {}, {}};
+    if (resolve) tr.prefetch();
     int64_t n_resolved = 0, n_ambiguous = 0;
     const double t0 = now_ms();
     const int k = ctx->k;
@@ -1253,7 +1322,7 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
                 uint32_t dflags = d.flags;
                 if (resolve && improved && (d.flags & KGMA_HIT_TIE)) {
                     // (A) several separated windows attain the dip's minimum
-                    const TieResolver::Result r = tr.replay(0, c, d.argmin, d.D_min, d.argmin, ctx->dip_argl[di], d.D_min, false);
+                    const TieResolver::Result r = tr.replay(0, c, d.argmin, d.D_min, d.argmin, ctx->dip_argl[di], d.D_min, false, tr.prefetched(di));
                     if (r.ok && !r.sensitive) {
                         best_pos = r.pos;
                         dflags = (dflags & ~(uint32_t)KGMA_HIT_TIE) | KGMA_HIT_TIE_RESOLVED;
@@ -1336,7 +1405,7 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
                     int64_t best_pos = d.argmin;
                     uint32_t dflags = d.flags;
                     if (resolve && improved && (d.flags & KGMA_HIT_TIE)) {
-                        const TieResolver::Result r = tr.replay(j, c, d.argmin, d.D_min, d.argmin, ctx->dip_argl[dix], d.D_min, false);
+                        const TieResolver::Result r = tr.replay(j, c, d.argmin, d.D_min, d.argmin, ctx->dip_argl[dix], d.D_min, false, tr.prefetched(dix));
                         if (r.ok && !r.sensitive) {
                             best_pos = r.pos;
                             dflags = (dflags & ~(uint32_t)KGMA_HIT_TIE) | KGMA_HIT_TIE_RESOLVED;

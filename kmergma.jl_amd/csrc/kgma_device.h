@@ -47,7 +47,8 @@ struct GroupParams {
     int32_t pad0;
     int32_t kfv_id[KGMA_MAX_GROUP];      // 1-based KFV index reported in records
     int32_t N[KGMA_MAX_GROUP];           // reference count of each KFV
-    int64_t T[KGMA_MAX_GROUP];           // integer threshold: d < thr  <=>  D < T
+    int64_t T[KGMA_MAX_GROUP];           // integer threshold: window below thr  <=>  D < T
+    int64_t T_hi[KGMA_MAX_GROUP];        // T <= D <= T_hi: at threshold (ATT records); T_hi < T: no band
     int64_t sumS2[KGMA_MAX_GROUP];       // sum_x S[x]^2
     double inv_scale[KGMA_MAX_GROUP];    // 2 k N^2 as a double (distance = D / that)
 };

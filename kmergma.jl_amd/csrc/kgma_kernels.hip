@@ -820,23 +820,30 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
         }
         const int64_t D0 = sD0[j];
         const int64_t twoN = 2 * (int64_t)gp.N[j];
-        // E_q < TE  <=>  D0 + 2N E_q < T   (64-bit division once per workgroup, by lane 0)
+        // E_q < TE  <=>  D0 + 2N E_q < T; windows with TE <= E_q < TE + natt are at threshold
+        // (64-bit divisions once per workgroup, by lane 0)
         if (tid == 0) {
             const int64_t num = gp.T[j] - D0;
             int64_t TE64 = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
-            int32_t ex = (num % twoN) == 0;
-            if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; ex = 0; }
-            if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; ex = 0; }
+            const int64_t numh = gp.T_hi[j] - D0;
+            const int64_t TH64 = numh >= 0 ? numh / twoN : -((-numh + twoN - 1) / twoN);   // floor
+            int64_t na = gp.T_hi[j] >= gp.T[j] ? TH64 - TE64 + 1 : 0;
+            if (na < 0) na = 0;
+            if (na > 0x3FFFFFFF) na = 0x3FFFFFFF;
+            if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; na = 0; }
+            if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; na = 0; }
             sMisc[10] = (int32_t)TE64;
-            sMisc[11] = ex;
+            sMisc[11] = (int32_t)na;
         }
         __syncthreads();
         const int32_t TE = sMisc[10];
-        const bool t_exact = sMisc[11] != 0;
+        const int32_t natt = sMisc[11];
 
         // pass A: lane-local prefix, its minimum over tested positions, and the lane total
         int32_t r = 0, rmin = 0x7FFFFFFF, rlast = 0;
-        if (interior_w) {
+        if (gp.debug_skip & 4) {
+            // timing experiment: no pass A walk
+        } else if (interior_w) {
             auto bodyA = [&](int, int32_t e) { rmin = r < rmin ? r : rmin; rlast = r; r += e; };
             if (small_w) walk(j, std::true_type{}, std::true_type{}, bodyA);
             else walk(j, std::false_type{}, std::true_type{}, bodyA);
@@ -871,7 +878,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
         __syncthreads();
         const bool prev_under = slot > 0 && sPrev[slot - 1] != 0;
         double *dist = a.dist[j];
-        const bool any_under = rmin != 0x7FFFFFFF && (offset + rmin < TE + (t_exact ? 1 : 0));
+        const bool any_under = rmin != 0x7FFFFFFF && (offset + rmin < TE + natt);
         const bool need = !dup && (any_under || prev_under || dist != nullptr) && qb >= 0 && qa < n_valid;
 
         if (need) {
@@ -910,7 +917,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
                         rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 1;
                         emit_record(sStage, sStageCount, STAGE_CAP, a.recs, a.rec_count, a.rec_cap, rec);
                     }
-                    if (t_exact && testable && E == TE) {
+                    if (natt && testable && E - TE < natt) {
                         DevRecord rec;
                         rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8);
                         rec.start = q; rec.end = q; rec.minE = E;
@@ -970,6 +977,23 @@ size_t scan_lds_bytes(int k, int nk, int n_kfv, int R, int NP, int dw)
 
 int scan_tile_stride_words(int nk) { return v2_stride_words(nk, KGMA_R); }
 int scan_nblocks(int nk) { return v2_nblocks(nk); }
+
+// Gathers byte ranges of the resident residue text into one contiguous block (tie resolution on
+// the host needs the residues under a few hundred short stretches: one launch + one download instead
+// of one blocking copy per stretch).  desc[3i..3i+2] = {source offset, destination offset, length}.
+__global__ __launch_bounds__(256) void gather_ranges_kernel(const uint8_t *__restrict__ src, const int64_t *__restrict__ desc,
+                                                            uint8_t *__restrict__ dst)
+{
+    const int64_t so = desc[3 * (int64_t)blockIdx.x], dof = desc[3 * (int64_t)blockIdx.x + 1], len = desc[3 * (int64_t)blockIdx.x + 2];
+    for (int64_t i = threadIdx.x; i < len; i += 256) dst[dof + i] = src[so + i];
+}
+
+hipError_t launch_gather_ranges(const uint8_t *src, const int64_t *desc, int n, uint8_t *dst, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_ranges_kernel, dim3((unsigned)n), dim3(256), 0, st, src, desc, dst);
+    return hipGetLastError();
+}
 
 hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc *cd, int n_contigs,
                        int64_t total_words, unsigned long long *first_bad, hipStream_t st)

@@ -380,7 +380,7 @@ done:
  * (the integer sum of the N reference histograms) D_s = sum_x (S[x] - N*c_s[x])^2 is an integer
  * and d_s = D_s / (2*k*N^2).  The device path computes D_s; this function is the sequential
  * integer oracle it must match bit for bit (including the D of every window when Dout != NULL).
- * `T` is the integer threshold: d < thr  <=>  D < T  (see orc_int_threshold).
+ * `T` is the integer threshold: a window is below thr iff D < T  (see orc_int_threshold).
  * first-window D (per contig) goes to D1[r] (or -1 for skipped records).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
@@ -389,7 +389,12 @@ typedef struct {
     int64_t D;          /* integer squared distance of the reported minimum */
 } orc_hit_int;
 
-/* smallest integer T with  (D < T)  <=>  (D / (2kN^2) < thr)  in exact arithmetic. */
+/* Integer threshold of the exact restatement: a window counts as "below thr" iff D < T with
+ * T = ceil(thr * 2kN^2 * (1 - 2^-30)).  The 2^-30 guard band is the rounding noise the reference's
+ * rolling Float64 chain can carry (GenomeMiner.jl:77: one rounding per window, millions of windows):
+ * a window whose exact distance is within that band of thr is decided by noise in the reference, and
+ * the restatement (like a directly computed, correctly rounded distance that equals thr) counts it as
+ * "not below".  For thr values away from the distance lattice this is ceil(thr * 2kN^2) exactly. */
 int64_t orc_int_threshold(double thr, int32_t k, int64_t N)
 {
     if (!(thr > 0.0)) return 0;
@@ -401,6 +406,7 @@ int64_t orc_int_threshold(double thr, int32_t k, int64_t N)
     e -= 53;
     __int128 scale = (__int128)2 * k * N * N;
     __int128 prod = (__int128)mant * scale;     /* thr * 2kN^2 = prod * 2^e */
+    prod -= prod >> 30;                         /* lower edge of the guard band */
     if (e >= 0) {
         if (e > 60) return INT64_MAX;
         __int128 v = prod << e;

@@ -88,15 +88,19 @@ def test_exact_integer_restatement_matches_float(alp_ref, loci):
         assert abs(a["dist"] - b["D"] / (2.0 * k * N * N)) < 1e-6 * a["dist"]
 
 
-def test_int_threshold_is_exact():
-    # strictness at lattice points and between them
+def test_int_threshold_guard_band():
+    # T = ceil(thr * 2kN^2 * (1 - 2^-30)): exact away from the distance lattice, and a window whose
+    # distance is within rounding noise of thr counts as "not below"
     k, N = 6, 84
     s = 2 * k * N * N
-    assert orc.int_threshold(30.0, k, N) == 30 * s
-    assert orc.int_threshold(np.nextafter(30.0, 31), k, N) == 30 * s + 1
+    assert orc.int_threshold(30.0, k, N) == 30 * s                       # d == thr is not below
+    assert orc.int_threshold(np.nextafter(30.0, 31), k, N) == 30 * s     # 1 ulp above a lattice value: noise
     assert orc.int_threshold(np.nextafter(30.0, 0), k, N) == 30 * s
+    assert orc.int_threshold(30.0 * (1 + 2.0 ** -29), k, N) == 30 * s + 1
     assert orc.int_threshold(0.0, k, N) == 0
     assert orc.int_threshold(33.5, k, N) == int(33.5 * s)
+    assert orc.int_threshold(6.4, 5, 1) == 64                            # 6.4 > 64/10 exactly, but only by rounding
+    assert orc.int_threshold(33.3, k, N) == int(np.ceil(33.3 * s))
 
 
 def test_short_contig_genome_pos_quirk(alp_ref):

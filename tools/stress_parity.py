@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the HIP path against the CPU oracle (run on a GPU box):
+random k, window sizes, numbers of KFVs, thresholds, genomes with repeats / N runs / planted genes.
+Exact-arithmetic mode must equal the integer oracle bit for bit; default mode must equal the
+reference-order Float64 oracle except on hits flagged rounding-history dependent.
+
+usage: python tools/stress_parity.py [--seconds 300] [--seed 1]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "kmergma.jl_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from kmergma_amd import _lib, refprep  # noqa: E402
+from kmergma_amd.fasta import Record  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+B = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def rdna(rng, n):
+    return B[rng.integers(0, 4, size=n)].tobytes()
+
+
+def mutate(rng, s, rate):
+    a = np.frombuffer(s, dtype=np.uint8).copy()
+    hit = rng.random(a.size) < rate
+    a[hit] = B[rng.integers(0, 4, size=int(hit.sum()))]
+    return a.tobytes()
+
+
+def key(h):
+    return (h["contig"], h["kfv"], h["cmi"], h["lo"], h["hi"], h["genome_pos"])
+
+
+def one_case(ctx, rng, case):
+    k = int(rng.integers(2, 11))
+    base_len = int(rng.choice([rng.integers(k + 2, 60), rng.integers(60, 400), rng.integers(400, 2030 + k)]))
+    m = int(rng.choice([1, 1, 2, 3, 5, 8]))
+    # reference sets: m clusters of mutated copies of related genes, lengths spread by up to +-6
+    root = rdna(rng, base_len + 8)
+    KFVs, ws, Ss, Ns, genes = [], [], [], [], []
+    for j in range(m):
+        L = max(k + 1, base_len + int(rng.integers(-3, 4)) + (int(rng.integers(0, 3)) if rng.random() < 0.3 else 0))
+        g = mutate(rng, root[:L], 0.05)
+        n = int(rng.integers(1, 9))
+        recs = [Record(f"r{j}_{i}", mutate(rng, g, 0.03)) for i in range(n)]
+        RV, W, cons, (S, N) = refprep.gen_ref_ws_cons(recs, k, return_int=True)
+        if W <= k or W - k + 1 > 2031:
+            return None
+        KFVs.append(RV); ws.append(W); Ss.append(S); Ns.append(N); genes.append(g)
+    # genome
+    contigs = []
+    for c in range(int(rng.integers(1, 5))):
+        L = int(rng.choice([rng.integers(1, 3 * base_len + 10), rng.integers(1000, 60000)]))
+        a = bytearray(rdna(rng, L))
+        for _ in range(int(rng.integers(0, 6))):
+            g = mutate(rng, genes[int(rng.integers(0, m))], float(rng.random()) * 0.2)
+            if len(g) < L:
+                p = int(rng.integers(0, L - len(g))); a[p:p + len(g)] = g
+        if L > 500 and rng.random() < 0.5:
+            p = int(rng.integers(0, L - 300)); n = int(rng.integers(1, 300))
+            a[p:p + n] = rng.choice([b"N", b"A", b"AC", b"ACG"]) * n
+            del a[L:]
+        if rng.random() < 0.3:
+            a = bytearray(bytes(a).lower())
+        contigs.append(bytes(a[:L]))
+    mode_single = m == 1 and rng.random() < 0.7
+    # thresholds around the distance of a random sequence (so that dips exist)
+    thr = []
+    for j in range(m):
+        probe = orc.kmer_dist_kfv(rdna(rng, ws[j]), KFVs[j], k)
+        thr.append(float(np.round(probe * float(rng.choice([0.3, 0.7, 0.95, 1.0, 1.3])), 2)))
+    buff = int(rng.choice([0, 5, 50, 200]))
+    gp0 = int(rng.integers(0, 1000))
+    try:
+        ctx.set_refs(k, KFVs, ws, thr, Ns)
+    except _lib.KgmaError as e:
+        if e.status == _lib.KGMA_E_UNSUPPORTED:
+            return None
+        raise
+    gen = ctx.genome_from_host(contigs)
+    try:
+        if mode_single:
+            ctx.scan(gen, _lib.MODE_SINGLE, buff, 0, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
+            hits, d = ctx.hits(), ctx.dists(1)
+            ctx.scan(gen, _lib.MODE_SINGLE, buff, 0, 0, None)
+            hits_f = ctx.hits()
+            T = orc.int_threshold(thr[0], k, Ns[0])
+            ohi, oD, _ = orc.single_scan_int(contigs, Ss[0], Ns[0], k, ws[0], T, buff, return_D=True)
+            ohf, _ = orc.single_scan(contigs, KFVs[0], k, ws[0], thr[0], buff)
+            assert np.array_equal(d, oD / (2.0 * k * Ns[0] ** 2)), "dists"
+        else:
+            if any(len(c) < k - 1 for c in contigs):
+                return None
+            ctx.scan(gen, _lib.MODE_OMN, buff, gp0, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
+            hits = ctx.hits()
+            dl = [ctx.dists(j + 1) for j in range(m)]
+            ctx.scan(gen, _lib.MODE_OMN, buff, gp0, 0, None)
+            hits_f = ctx.hits()
+            T = [orc.int_threshold(t, k, n) for t, n in zip(thr, Ns)]
+            ohi, oD = orc.omn_scan_int(contigs, Ss, Ns, k, ws, T, buff, gp0, return_D=True)
+            ohf, _ = orc.omn_scan(contigs, KFVs, k, ws, thr, buff, gp0)
+            for j in range(m):
+                assert np.array_equal(dl[j], oD[j] / (2.0 * k * Ns[j] ** 2)), f"dists kfv {j}"
+        assert [key(h) for h in hits] == [key(h) for h in ohi], "hits vs integer oracle"
+        assert [h["D"] for h in hits] == [h["D"] for h in ohi], "D vs integer oracle"
+        nflag = 0
+        if [key(h) for h in hits_f] != [key(h) for h in ohf]:
+            # Float64 rounding decided something exact arithmetic cannot: legitimate only downstream
+            # (same record) of a dip the library flagged as ambiguous (unresolved tie / at threshold).
+            first = next((i for i, (a, b) in enumerate(zip(hits_f, ohf)) if key(a) != key(b)),
+                         min(len(hits_f), len(ohf)))
+            cands = [h for h in (hits_f[first:first + 1] + ohf[first:first + 1])]
+            c0, p0 = min((h["contig"], h["cmi"]) for h in cands)
+            flagged = [d for d in ctx.dips() if d["contig"] == c0 and (d["flags"] & 3) and d["start"] <= p0 + max(ws)]
+            assert flagged or ctx.stats()["n_at_threshold"] > 0, "float oracle: difference with no flagged dip upstream"
+            nflag = 1
+        return dict(k=k, m=m, ws=ws, single=mode_single, hits=len(hits), amb=nflag)
+    finally:
+        gen.free()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    ctx = _lib.Context(0)
+    t0 = time.time()
+    n = skipped = total_hits = amb = 0
+    case = 0
+    while time.time() - t0 < args.seconds:
+        rng = np.random.default_rng([args.seed, case])
+        try:
+            r = one_case(ctx, rng, case)
+        except AssertionError as e:
+            print(f"FAIL seed={args.seed} case={case}: {e}", flush=True)
+            raise
+        case += 1
+        if r is None:
+            skipped += 1
+            continue
+        n += 1; total_hits += r["hits"]; amb += r["amb"]
+        if n % 50 == 0:
+            print(f"{n} cases ok ({skipped} skipped), {total_hits} hits, {amb} cases with flagged float differences, "
+                  f"{time.time() - t0:.0f}s", flush=True)
+    print(f"DONE {n} cases ok, {skipped} skipped, {total_hits} hits compared, {amb} cases with flagged differences")
+
+
+if __name__ == "__main__":
+    main()
