@@ -24,23 +24,13 @@
 #include "kgma_device.h"
 
 namespace kgma {
-struct ScanArgs {
-    const uint32_t *planes;
-    const TileDesc *tiles;
-    const int32_t *Stab;
-    int64_t *D0out;
-    DevRecord *recs;
-    unsigned int *rec_count;
-    unsigned int rec_cap;
-    int32_t n_tiles;
-    double *dist[KGMA_MAX_GROUP];
-    unsigned long long *n_att;
-};
 hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc *cd, int n_contigs,
                        int64_t total_words, unsigned long long *first_bad, hipStream_t st);
 hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int64_t total_words,
                         uint64_t seed, hipStream_t st);
 hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
+hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
+int stream_waves(int k, int nk, int n_kfv, int n_sizes);
 hipError_t launch_fasta_count(const uint8_t *raw, int64_t n, uint32_t *counts, hipStream_t st);
 hipError_t launch_gather_ranges(const uint8_t *src, const int64_t *desc, int n, uint8_t *dst, hipStream_t st);
 hipError_t launch_fasta_scatter(const uint8_t *raw, int64_t n, const int64_t *block_base, const int64_t *rec_start,
@@ -99,14 +89,15 @@ struct kgma_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evp0 = nullptr, evp1 = nullptr;
     std::string err;
     uint8_t *h_pin = nullptr; size_t h_pin_cap = 0;     // pinned result staging
+    uint8_t *d_gath = nullptr, *h_gath = nullptr; size_t gath_cap = 0;   // tie-replay residue gather: [desc | residues]
     uint64_t next_uid = 1;
     // key of the tile table currently on the device
     uint64_t tk_uid = 0; int tk_mode = -1, tk_version = 0, tk_k = 0; int64_t tk_maxws = 0;
     // references
     int k = 0, m = 0;
-    int kernel_version = 1;   // bumped when the tile geometry changes (part of the tile-cache key)
     std::vector<KfvInfo> kfv;
     int32_t *d_Stab = nullptr;        // m x 4^k, device index order (first base least significant)
+    int32_t *d_StabC = nullptr;       // the same tables in the stream kernel's index order ((hi bits << k) | lo bits)
     // scan scratch
     TileDesc *d_tiles = nullptr; int64_t tiles_cap = 0;
     // one device block: [counters 16 B: rec_count u32 @0, n_att u64 @8][D0: res_d0_slots int64][records]
@@ -178,6 +169,19 @@ uint32_t device_index_of(uint32_t v, int k)
         idx |= code << (2 * j);
     }
     return idx;
+}
+
+// Index of natural k-mer value v in the stream kernel's tables: bit i of the low half is the low code
+// bit of base i (first base = bit 0), bit k+i the high code bit.
+uint32_t stream_index_of(uint32_t v, int k)
+{
+    uint32_t H = 0, L = 0;
+    for (int j = 0; j < k; j++) {
+        const uint32_t code = (v >> (2 * (k - 1 - j))) & 3u;
+        H |= (code >> 1) << j;
+        L |= (code & 1u) << j;
+    }
+    return (H << k) | L;
 }
 
 // Integer thresholds of one KFV.  thr * 2kN^2 is formed exactly (thr is a dyadic rational); windows
@@ -306,9 +310,12 @@ void kgma_destroy(kgma_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (double *p : ctx->d_dist) if (p) (void)hipFree(p);
     if (ctx->d_Stab) (void)hipFree(ctx->d_Stab);
+    if (ctx->d_StabC) (void)hipFree(ctx->d_StabC);
     if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
     if (ctx->d_res) (void)hipFree(ctx->d_res);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->h_gath) (void)hipHostFree(ctx->h_gath);
+    if (ctx->d_gath) (void)hipFree(ctx->d_gath);
     if (ctx->evp0) (void)hipEventDestroy(ctx->evp0);
     if (ctx->evp1) (void)hipEventDestroy(ctx->evp1);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -395,6 +402,14 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
     if (ctx->d_Stab) { (void)hipFree(ctx->d_Stab); ctx->d_Stab = nullptr; }
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_Stab), tab.size() * sizeof(int32_t)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_Stab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (ctx->d_StabC) { (void)hipFree(ctx->d_StabC); ctx->d_StabC = nullptr; }
+    if (k <= KGMA_STREAM_MAX_K) {
+        for (int j = 0; j < m; j++)
+            for (int64_t v = 0; v < NB; v++)
+                tab[(size_t)j * (size_t)NB + stream_index_of((uint32_t)v, k)] = (int32_t)kv[(size_t)j].S[(size_t)v];
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_StabC), tab.size() * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_StabC, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     ctx->k = k;
     ctx->m = m;
     ctx->kfv.swap(kv);
@@ -877,27 +892,42 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     const int k = ctx->k, m_used = mode == KGMA_MODE_SINGLE ? 1 : ctx->m;
     int64_t maxws = 0;
     for (int j = 0; j < m_used; j++) maxws = std::max(maxws, ctx->kfv[(size_t)j].W);
-    const int64_t stride_words = scan_tile_stride_words((int)(maxws - k + 1));
-    const int64_t P = stride_words * 32;
+    // ---- which kernel: the count-table stream kernel for k <= 7 (one wave per stream), the bit-sliced
+    //      kernel for longer k-mers (their 4^k counters do not fit a wave's share of the LDS)
+    const std::vector<Group> groups = make_groups(ctx, mode);
+    bool use_stream = k <= KGMA_STREAM_MAX_K;
+    if (const char *kv = getenv("KGMA_KERNEL")) {      // testing only: run the other kernel where both apply
+        if (!strcmp(kv, "bitslice")) use_stream = false;
+    }
+    int stream_nw = 16;
+    if (use_stream)
+        for (const Group &gr : groups) {
+            int n_sizes = 0;
+            int64_t prev = -1;
+            for (int j : gr.kfvs) { if (ctx->kfv[(size_t)j].W != prev) n_sizes++; prev = ctx->kfv[(size_t)j].W; }
+            const int nw = stream_waves(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), n_sizes);
+            if (nw < 1) use_stream = false;
+            stream_nw = std::min(stream_nw, nw);
+        }
     const int64_t nc = g->n_contigs;
     const bool want_dists = (flags & KGMA_F_RETURN_DISTS) != 0;
+    const int geom_version = use_stream ? 2 : 1;
 
     ctx->dips.clear();
     ctx->hits.clear();
     ctx->have_dists = false;
     ctx->last_mode = -1;
 
-    // ---- which windows each record evaluates (tile table), cached per (genome, mode, W, k) ----
+    // ---- which windows each record evaluates (tile table), cached per (genome, mode, W, k, kernel) ----
     const bool tiles_cached = ctx->tk_uid == g->uid && ctx->tk_mode == mode && ctx->tk_maxws == maxws &&
-                              ctx->tk_k == k && ctx->tk_version == ctx->kernel_version;
+                              ctx->tk_k == k && ctx->tk_version == geom_version;
     if (!tiles_cached) {
-        ctx->tile_windows = P;
         ctx->contig_len.resize((size_t)nc);
         ctx->contig_nwin.assign((size_t)nc, 0);
         ctx->contig_looked.assign((size_t)nc, 0);
         ctx->contig_tile_base.assign((size_t)nc, -1);
         ctx->tiles.clear();
-        int64_t dist_total = 0, bases = 0, windows = 0;
+        int64_t dist_total = 0, bases = 0, windows = 0, total_nwin = 0;
         for (int64_t c = 0; c < nc; c++) {
             const int64_t L = g->cd[(size_t)c].len;
             ctx->contig_len[(size_t)c] = L;
@@ -919,6 +949,25 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             }
             ctx->contig_looked[(size_t)c] = looked;
             ctx->contig_nwin[(size_t)c] = nwin;
+            total_nwin += nwin;
+        }
+        // windows per tile: fixed by the workgroup geometry for the bit-sliced kernel; for the stream
+        // kernel one wave owns one stream, so the stream length is chosen to give every wave slot of the
+        // chip (256 CUs x waves per workgroup) a whole number of equally long streams
+        int64_t P;
+        if (use_stream) {
+            const int64_t slots = (int64_t)256 * stream_nw;
+            const int64_t rounds = std::max<int64_t>(1, (total_nwin + slots * KGMA_STREAM_MAX_WINDOWS - 1) / (slots * KGMA_STREAM_MAX_WINDOWS));
+            P = (total_nwin + slots * rounds - 1) / (slots * rounds);
+            P = ((P + 63) / 64) * 64;
+            P = std::min<int64_t>(std::max<int64_t>(P, KGMA_STREAM_MIN_WINDOWS), KGMA_STREAM_MAX_WINDOWS);
+        } else {
+            P = (int64_t)scan_tile_stride_words((int)(maxws - k + 1)) * 32;
+        }
+        const int64_t stride_words = P / 32;
+        ctx->tile_windows = P;
+        for (int64_t c = 0; c < nc; c++) {
+            const int64_t nwin = ctx->contig_nwin[(size_t)c];
             if (nwin > 0) {
                 ctx->contig_tile_base[(size_t)c] = (int64_t)ctx->tiles.size();
                 const int64_t nt = (nwin + P - 1) / P;
@@ -1020,10 +1069,9 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     if (!tiles_cached) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tiles, ctx->tiles.data(), (size_t)n_tiles * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
         // the vector is pageable memory: the runtime stages it before returning, so it may be reused
-        ctx->tk_uid = g->uid; ctx->tk_mode = mode; ctx->tk_maxws = maxws; ctx->tk_k = k; ctx->tk_version = ctx->kernel_version;
+        ctx->tk_uid = g->uid; ctx->tk_mode = mode; ctx->tk_maxws = maxws; ctx->tk_k = k; ctx->tk_version = geom_version;
     }
 
-    const std::vector<Group> groups = make_groups(ctx, mode);
     unsigned int n_recs = 0;
     for (int attempt = 0;; attempt++) {
         uint8_t *d_cnt = ctx->d_res;
@@ -1059,14 +1107,14 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             }
             a.planes = g->d_planes;
             a.tiles = ctx->d_tiles;
-            a.Stab = ctx->d_Stab;                  // all tables; the kernel indexes by KFV id
+            a.Stab = use_stream ? ctx->d_StabC : ctx->d_Stab;   // all tables; the kernel indexes by KFV id
             a.D0out = d_D0;                        // [KFV id - 1][tile]
             a.recs = d_recs;
             a.rec_count = reinterpret_cast<unsigned int *>(d_cnt);
             a.rec_cap = ctx->rec_cap;
             a.n_tiles = (int32_t)n_tiles;
             a.n_att = reinterpret_cast<unsigned long long *>(d_cnt + 8);
-            HIP_TRY(ctx, launch_scan(a, gp, ctx->stream));
+            HIP_TRY(ctx, use_stream ? launch_stream(a, gp, ctx->stream) : launch_scan(a, gp, ctx->stream));
             ctx->stats.n_launches++;
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -1147,7 +1195,7 @@ struct TieResolver {
     std::vector<int32_t> cnt;
     std::vector<uint32_t> touched;
     std::vector<uint8_t> seqbuf;
-    std::vector<uint8_t> pre;            // residues under the tied stretch of every TIE-flagged dip (one gather)
+    const uint8_t *pre = nullptr;        // residues under the tied stretch of every TIE-flagged dip (one gather)
     std::vector<int64_t> pre_off;        // per dip: offset into `pre`, or -1
     static constexpr int64_t MAX_SPAN = 1 << 22;
     static constexpr int64_t MAX_PREFETCH = (int64_t)256 << 20;
@@ -1175,24 +1223,32 @@ struct TieResolver {
         }
         if (desc.empty()) return;
         (void)hipSetDevice(ctx->device);
-        int64_t *d_desc = nullptr;
-        uint8_t *d_dst = nullptr;
-        bool ok = hipMalloc(reinterpret_cast<void **>(&d_desc), desc.size() * sizeof(int64_t)) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void **>(&d_dst), (size_t)total) == hipSuccess;
+        const size_t desc_bytes = (desc.size() * sizeof(int64_t) + 255) & ~(size_t)255;
+        const size_t need = desc_bytes + (size_t)total;
+        bool ok = true;
+        if (need > ctx->gath_cap) {
+            if (ctx->h_gath) (void)hipHostFree(ctx->h_gath);
+            if (ctx->d_gath) (void)hipFree(ctx->d_gath);
+            ctx->h_gath = ctx->d_gath = nullptr; ctx->gath_cap = 0;
+            const size_t cap = need + (need >> 1) + 65536;
+            ok = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_gath), cap, hipHostMallocDefault) == hipSuccess &&
+                 hipMalloc(reinterpret_cast<void **>(&ctx->d_gath), cap) == hipSuccess;
+            if (ok) ctx->gath_cap = cap;
+        }
         if (ok) {
-            pre.resize((size_t)total);
-            ok = hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
-                 launch_gather_ranges(g->d_ascii, d_desc, (int)(desc.size() / 3), d_dst, ctx->stream) == hipSuccess &&
-                 hipMemcpyAsync(pre.data(), d_dst, (size_t)total, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+            memcpy(ctx->h_gath, desc.data(), desc.size() * sizeof(int64_t));
+            ok = hipMemcpyAsync(ctx->d_gath, ctx->h_gath, desc_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                 launch_gather_ranges(g->d_ascii, reinterpret_cast<const int64_t *>(ctx->d_gath), (int)(desc.size() / 3),
+                                      ctx->d_gath + desc_bytes, ctx->stream) == hipSuccess &&
+                 hipMemcpyAsync(ctx->h_gath + desc_bytes, ctx->d_gath + desc_bytes, (size_t)total, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
                  hipStreamSynchronize(ctx->stream) == hipSuccess;
         }
-        if (d_desc) (void)hipFree(d_desc);
-        if (d_dst) (void)hipFree(d_dst);
+        pre = ok ? ctx->h_gath + desc_bytes : nullptr;
         if (!ok) pre_off.assign(nd, -1);       // replay() falls back to its own copies
     }
     const uint8_t *prefetched(size_t dip_index) const
     {
-        return dip_index < pre_off.size() && pre_off[dip_index] >= 0 ? pre.data() + pre_off[dip_index] : nullptr;
+        return dip_index < pre_off.size() && pre_off[dip_index] >= 0 && pre ? pre + pre_off[dip_index] : nullptr;
     }
 
     struct Result { bool ok, sensitive, improved; int64_t pos; };
@@ -1292,7 +1348,7 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
     if (rc) return rc;
     if (buff < 0) return fail(ctx, KGMA_E_ARG, "buff < 0");
     const bool resolve = !(flags & KGMA_F_NO_TIE_RESOLVE);
-    TieResolver tr{ctx, g, {}, {}, {}, {}, {}};
+    TieResolver tr{ctx, g, {}, {}, {}, nullptr, {}};
     if (resolve) tr.prefetch();
     int64_t n_resolved = 0, n_ambiguous = 0;
     const double t0 = now_ms();

@@ -70,6 +70,25 @@ struct DevRecord {
     int32_t has_exit;     // RUN: 1 if end+1 lies inside the same lane span and was evaluated
 };
 
+// Arguments of one scan launch (either kernel).
+struct ScanArgs {
+    const uint32_t *planes;
+    const TileDesc *tiles;
+    const int32_t *Stab;        // all KFVs' tables, 4^k int32 each, in the launching kernel's index order
+    int64_t *D0out;             // [KFV id - 1][n_tiles]
+    DevRecord *recs;
+    unsigned int *rec_count;
+    unsigned int rec_cap;
+    int32_t n_tiles;
+    double *dist[KGMA_MAX_GROUP];   // per-KFV distance arrays or nullptr
+    unsigned long long *n_att;      // stats: tested windows inside the threshold guard band
+};
+
+// Count-table stream kernel (kgma_stream.hip): one wave per stream of consecutive window starts.
+constexpr int KGMA_STREAM_MIN_WINDOWS = 2048;                  // shorter streams waste their warm-up (n k-mers)
+constexpr int KGMA_STREAM_MAX_WINDOWS = 1 << 20;
+constexpr int KGMA_STREAM_MAX_K = 7;                           // 4^k 16-bit counters per wave must fit the LDS
+
 // Per-record info for the pack kernel.
 struct ContigDesc {
     int64_t ascii_off;    // byte offset of the record's first residue in the ASCII buffer (32-aligned)

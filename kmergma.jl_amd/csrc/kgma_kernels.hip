@@ -315,18 +315,6 @@ __device__ __forceinline__ void emit_record(DevRecord *stage, unsigned int *stag
     if (idx < rec_cap) recs[idx] = r;
 }
 
-struct ScanArgs {
-    const uint32_t *planes;
-    const TileDesc *tiles;
-    const int32_t *Stab;        // n_kfv x 4^K int32, plane-index order
-    int64_t *D0out;             // [n_kfv][n_tiles]
-    DevRecord *recs;
-    unsigned int *rec_count;
-    unsigned int rec_cap;
-    int32_t n_tiles;
-    double *dist[KGMA_MAX_GROUP];   // per-KFV distance arrays or nullptr
-    unsigned long long *n_att;      // stats: windows with D == T
-};
 
 // ------------------------------------------------------------------------------------------
 // Scan kernel: one mask family for both directions, halo words by DPP.

@@ -1,0 +1,401 @@
+// kgma_stream.hip -- count-table stream kernel for gfx950 (k <= 7).
+//
+// Same quantity as scan_kernel in kgma_kernels.hip (the per-record body of src/GenomeMiner.jl:32-107
+// ac_gma_testing! and src/OmnGenomeMiner.jl:55-160 Omn_KmerGMA!, in exact integers).  With c_s[x] the
+// number of copies of k-mer x among the n = W-k+1 k-mers of window s, l = K_s the k-mer that leaves
+// and r = K_{s+n} the one that enters (the reference's update, GenomeMiner.jl:66-77, times 2kN^2):
+//     D_{s+1} - D_s = 2N [ (S[l] - S[r]) - N (c_s[l] - 1 - c_s[r]) ]   if l != r,   0 otherwise.
+// The reference walks this one window at a time with a 4^k count table per sequence.  Here ONE WAVE
+// owns one STREAM (a contiguous run of window starts of one record) and its own count table in LDS
+// (4^k 16-bit counters, two per dword), and advances 64 windows per step, lane = window:
+//   * every lane reads the counts of its entering and leaving k-mer as they are at the START of the
+//     step, then adds / subtracts its own transition with an LDS atomic that returns the old value;
+//   * if some other lane of the step touched one of its k-mers the returned value differs from the
+//     value read: exactly those k-mers (about two per step on random sequence, one on a homopolymer
+//     run) are corrected in a short wave-uniform loop -- ballots give, for each lane, how many of the
+//     earlier lanes' transitions added or removed a copy (popcount of the lower lanes), so every lane
+//     ends up with the exact counts of ITS window;
+//   * e = S[l] - S[r] - N (c[l] - 1 - c[r]), a DPP prefix sum over the 64 lanes plus the carry gives
+//     E_q = (D_q - D_0) / 2N for 64 consecutive windows, compared against the integer threshold;
+//   * dips (runs of windows under the threshold) are tracked from the 64-bit ballot of that compare
+//     in wave-uniform state; only steps that touch a dip leave the fast path.
+// Cost per 64 windows: ~90 VALU + ~8 LDS instructions, independent of the window length n and of
+// repeats in the sequence (the bit-sliced kernel spends ~20 VALU instructions per offset per 32
+// windows, i.e. ~180 per window).  The D of a stream's first window comes out of the warm-up
+// positions p < n (entries only):  D_0 = sum S^2 - 2N sum_{p<n} S[K_p] + N^2 (n + 2 sum_{p<n} c[K_p]).
+// No MFMA, no global atomics on the fast path; HBM traffic is the 2-bit genome once (0.25 B/base).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kgma_device.h"
+
+namespace kgma {
+
+namespace {
+
+enum : int {
+    ST_CARRY = 0, ST_TE, ST_NATT, ST_INRUN,
+    ST_START, ST_MINE, ST_ARGF, ST_ARGL,
+    ST_NMIN, ST_PAIRS, ST_D0LO, ST_D0HI,
+    ST_SUMLO, ST_SUMHI, ST_PAD0, ST_PAD1,
+    ST_WORDS
+};
+
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// inclusive prefix sum over the 64 lanes (4 row steps + 2 row broadcasts, all DPP)
+__device__ __forceinline__ int32_t wave_incl_scan(int32_t v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ int64_t wave_sum_i64(int64_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        int lo = (int)(uint32_t)v, hi = (int)(uint32_t)((uint64_t)v >> 32);
+        lo = __shfl_xor(lo, d);
+        hi = __shfl_xor(hi, d);
+        v += (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+    }
+    return v;
+}
+
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int32_t o = __shfl_xor(v, d);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void emit_global(const ScanArgs &a, const DevRecord &r)
+{
+    const unsigned int idx = atomicAdd(a.rec_count, 1u);
+    if (idx < a.rec_cap) a.recs[idx] = r;
+}
+
+}  // namespace
+
+// K: k-mer length; MULTI: more than one KFV (state in LDS, loops over KFVs / window sizes);
+// TLDS: the S tables of the launch are staged in LDS (else gathered from global memory / L2).
+template <int K, bool MULTI, bool TLDS>
+__global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp, int ring)
+{
+    constexpr int NB = 1 << (2 * K);
+    constexpr uint32_t KM = (1u << K) - 1u;
+    constexpr int NZ = MULTI ? KGMA_MAX_SIZES : 1;
+    extern __shared__ uint32_t smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int nwaves = (int)(blockDim.x >> 6);
+    const int n_kfv = MULTI ? gp.n_kfv : 1;
+    const int n_sizes = MULTI ? gp.n_sizes : 1;
+    const int RM = ring - 1;
+
+    // ---- LDS carve-up: [S tables (TLDS)] then per wave [count table per size | key ring | state]
+    int32_t *sTab = reinterpret_cast<int32_t *>(smem);
+    const size_t tab_words = TLDS ? (size_t)n_kfv * NB : 0;
+    const size_t per_wave_words = (size_t)(NB / 2) * (size_t)n_sizes + (size_t)(ring / 2) + (MULTI ? KGMA_MAX_GROUP * ST_WORDS : 0);
+    uint32_t *wbase = smem + tab_words + (size_t)wave * per_wave_words;
+    uint32_t *sCnt = wbase;                                           // [n_sizes][NB/2] dwords = 2 x 16-bit counters
+    uint16_t *sKey = reinterpret_cast<uint16_t *>(wbase + (size_t)(NB / 2) * n_sizes);
+    int32_t *sState = reinterpret_cast<int32_t *>(sKey + ring);
+
+    if constexpr (TLDS) {
+        for (int j = 0; j < n_kfv; j++) {
+            const int32_t *Sg = a.Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
+            for (int i = threadIdx.x; i < NB; i += blockDim.x) sTab[(size_t)j * NB + i] = Sg[i];
+        }
+        __syncthreads();
+    }
+    const int tile = (int)blockIdx.x * nwaves + wave;
+    if (tile >= a.n_tiles) return;                                    // (after the only workgroup barrier)
+
+    for (int i = lane; i < (NB / 2) * n_sizes; i += 64) sCnt[i] = 0;
+    int32_t st_local[ST_WORDS];
+#pragma unroll
+    for (int i = 0; i < ST_WORDS; i++) st_local[i] = 0;
+    if constexpr (MULTI) {
+        for (int i = lane; i < KGMA_MAX_GROUP * ST_WORDS; i += 64) sState[i] = 0;
+    }
+
+    const TileDesc td = a.tiles[tile];
+    const int n_valid = td.n_valid, first_test = td.first_test;
+    const int nk = gp.nk;                                             // largest window of the launch
+    const uint2 *g2 = reinterpret_cast<const uint2 *>(a.planes) + td.word_base;
+    const int half = lane >> 5;
+    const uint32_t sh = (uint32_t)(lane & 31);
+    const int n_pos = n_valid + nk - 1;                               // k-mer positions this stream needs
+    const int n_blocks = (n_pos + 63) >> 6;
+    const uint64_t lt_mask = ((uint64_t)1 << lane) - 1u;
+
+    uint2 wlo = g2[half], whi = g2[half + 1];
+    for (int b = 0; b < n_blocks; b++) {
+        const uint2 clo = wlo, chi = whi;
+        wlo = g2[2 * (b + 1) + half];                                 // next step (the plane array is padded)
+        whi = g2[2 * (b + 1) + half + 1];
+        const int p = (b << 6) + lane;                                // position of the entering k-mer
+        const uint32_t hh = __builtin_amdgcn_alignbit(chi.x, clo.x, sh) & KM;
+        const uint32_t ll = __builtin_amdgcn_alignbit(chi.y, clo.y, sh) & KM;
+        const uint32_t kp = (hh << K) | ll;
+        sKey[p & RM] = (uint16_t)kp;
+
+        // ---- per window size: exact counts of the entering / leaving k-mer in THIS lane's window ----
+        uint32_t ksz[NZ];
+        int32_t cPz[NZ], cSz[NZ];
+        bool actz[NZ];
+#pragma unroll
+        for (int z = 0; z < NZ; z++) {
+            ksz[z] = kp; cPz[z] = 0; cSz[z] = 0; actz[z] = false;
+            if (z >= n_sizes) continue;
+            const int nkz = MULTI ? gp.sizes[z] : nk;
+            uint32_t *C = sCnt + (size_t)z * (NB / 2);
+            const int s = p - nkz;                                    // window whose last k-mer is p-1; its first leaves
+            const bool haveL = s >= 0;
+            const uint32_t ks = haveL ? (uint32_t)sKey[s & RM] & (uint32_t)(NB - 1) : kp;
+            const bool actE = !haveL || kp != ks;                     // GenomeMiner.jl:66: nothing happens if left == right
+            const bool actL = haveL && kp != ks;
+            const uint32_t shp = 16u * (kp & 1u), shs = 16u * (ks & 1u);
+            const uint32_t cp = (C[kp >> 1] >> shp) & 0xFFFFu;        // counts at the start of the step
+            const uint32_t cs = (C[ks >> 1] >> shs) & 0xFFFFu;
+            uint32_t oldp = cp, olds = cs;
+            if (actE) oldp = (atomicAdd(&C[kp >> 1], 1u << shp) >> shp) & 0xFFFFu;
+            if (actL) olds = (atomicSub(&C[ks >> 1], 1u << shs) >> shs) & 0xFFFFu;
+            // a returned value that differs from the value read: another lane's transition touched that k-mer
+            uint64_t pendE = __ballot(oldp != cp), pendL = __ballot(olds != cs);
+            int32_t corrP = 0, corrS = 0;
+            while (pendE | pendL) {
+                uint32_t x0;
+                if (pendE) x0 = (uint32_t)__builtin_amdgcn_readlane((int)kp, __builtin_ctzll(pendE));
+                else x0 = (uint32_t)__builtin_amdgcn_readlane((int)ks, __builtin_ctzll(pendL));
+                const uint64_t ME = __ballot(actE && kp == x0), ML = __ballot(actL && ks == x0);
+                // transitions of lower lanes happen before this lane's window
+                const int32_t corr = __builtin_popcountll(ME & lt_mask) - __builtin_popcountll(ML & lt_mask);
+                corrP = kp == x0 ? corr : corrP;
+                corrS = ks == x0 ? corr : corrS;
+                pendE &= ~ME;
+                pendL &= ~ML;
+            }
+            ksz[z] = ks; cPz[z] = (int32_t)cp + corrP; cSz[z] = (int32_t)cs + corrS; actz[z] = actL;
+        }
+
+        // ---- per KFV: close the window whose last k-mer is p ------------------------------------
+        for (int j = 0; j < n_kfv; j++) {
+            int32_t *st = MULTI ? sState + j * ST_WORDS : st_local;
+            const int nkj = MULTI ? gp.nk_of[j] : nk;
+            int zi = 0;
+            if constexpr (MULTI) {
+#pragma unroll
+                for (int z = 1; z < KGMA_MAX_SIZES; z++) zi = (z < n_sizes && gp.sizes[z] == nkj) ? z : zi;
+            }
+            uint32_t ks = ksz[0];
+            int32_t cP = cPz[0], cS = cSz[0];
+            bool act = actz[0];
+            if constexpr (MULTI) {
+#pragma unroll
+                for (int z = 1; z < KGMA_MAX_SIZES; z++) {
+                    ks = zi == z ? ksz[z] : ks; cP = zi == z ? cPz[z] : cP; cS = zi == z ? cSz[z] : cS; act = zi == z ? actz[z] : act;
+                }
+            }
+            const int32_t *S = TLDS ? sTab + (size_t)j * NB : a.Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
+            const int32_t Nj = gp.N[j];
+            const int64_t twoN = 2 * (int64_t)Nj;
+            const int32_t Sv = S[kp];
+            const int32_t Ss = S[ks];
+            const int32_t e = act ? Ss - Sv - Nj * (cS - 1 - cP) : 0;  // GenomeMiner.jl:67-68 times 2kN^2 / 2N
+
+            if ((b << 6) < nkj) {                                     // warm-up blocks: first-window D
+                const bool wu = p < nkj;
+                const int64_t ssum = wave_sum_i64(wu ? (int64_t)Sv : 0);
+                const int64_t psum = wave_sum_i64(wu ? (int64_t)cP : 0);
+                int64_t sumS = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_SUMHI]) << 32) | (uint32_t)uni(st[ST_SUMLO])) + ssum;
+                const int32_t pairs = uni(st[ST_PAIRS]) + (int32_t)psum;
+                st[ST_SUMLO] = (int32_t)(uint32_t)sumS;
+                st[ST_SUMHI] = (int32_t)(uint32_t)((uint64_t)sumS >> 32);
+                st[ST_PAIRS] = pairs;
+                if (nkj - 1 < (b << 6) + 64) {                        // last warm-up position is in this block
+                    const int64_t D0 = gp.sumS2[j] - twoN * sumS + (int64_t)Nj * Nj * ((int64_t)nkj + 2 * (int64_t)pairs);
+                    if (lane == 0) a.D0out[(size_t)(gp.kfv_id[j] - 1) * a.n_tiles + tile] = D0;
+                    st[ST_D0LO] = (int32_t)(uint32_t)D0;
+                    st[ST_D0HI] = (int32_t)(uint32_t)((uint64_t)D0 >> 32);
+                    // E_q < TE  <=>  D0 + 2N E_q < T; windows with TE <= E_q < TE + natt are at threshold
+                    const int64_t num = gp.T[j] - D0;
+                    int64_t TE64 = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
+                    const int64_t numh = gp.T_hi[j] - D0;
+                    const int64_t TH64 = numh >= 0 ? numh / twoN : -((-numh + twoN - 1) / twoN);
+                    int64_t na = gp.T_hi[j] >= gp.T[j] ? TH64 - TE64 + 1 : 0;
+                    if (na < 0) na = 0;
+                    if (na > 0x3FFFFFFF) na = 0x3FFFFFFF;
+                    if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; na = 0; }
+                    if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; na = 0; }
+                    st[ST_TE] = (int32_t)TE64;
+                    st[ST_NATT] = (int32_t)na;
+                }
+            }
+
+            const int32_t E = wave_incl_scan(e) + uni(st[ST_CARRY]);
+            st[ST_CARRY] = __builtin_amdgcn_readlane(E, 63);
+            const int32_t TE = uni(st[ST_TE]);
+            const int32_t natt = uni(st[ST_NATT]);
+            const int q = p - nkj + 1;                                // window start (local) whose last k-mer is p
+            const bool tested = q >= first_test && q < n_valid;
+            const bool under = tested && E < TE;
+            double *dist = a.dist[j];
+            if (dist != nullptr && tested) {
+                const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
+                dist[td.dist_base + q] = (double)(D0 + twoN * (int64_t)E) / gp.inv_scale[j];
+            }
+            const bool att = natt != 0 && tested && !under && E - TE < natt;
+            const uint64_t U = __ballot(under);
+            const uint64_t A = __ballot(att);
+            int in_run = uni(st[ST_INRUN]);
+            if ((U | A) == 0 && !in_run) continue;                    // fast path: nothing near the threshold
+
+            // ---- a dip touches this block: walk its runs (wave-uniform) ----------------------------
+            const int kid = gp.kfv_id[j];
+            const int q0 = (b << 6) - nkj + 1;                        // window of lane 0
+            if (att) {
+                DevRecord rec;
+                rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8);
+                rec.start = q; rec.end = q; rec.minE = E;
+                rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
+                emit_global(a, rec);
+                atomicAdd(a.n_att, 1ull);
+            }
+            int run_start = uni(st[ST_START]), minE = uni(st[ST_MINE]), argf = uni(st[ST_ARGF]), argl = uni(st[ST_ARGL]),
+                nmin = uni(st[ST_NMIN]);
+            int cursor = 0;
+            while (cursor < 64) {
+                const uint64_t rem = ~(uint64_t)0 << cursor;
+                if (in_run) {
+                    const uint64_t nz = ~U & rem;
+                    const int end_lane = nz ? __builtin_ctzll(nz) : 64;
+                    if (end_lane > cursor) {
+                        const bool inseg = lane >= cursor && lane < end_lane;
+                        const int32_t segmin = wave_min_i32(inseg ? E : 0x7FFFFFFF);
+                        const uint64_t eq = __ballot(inseg && E == segmin);
+                        const int fl = __builtin_ctzll(eq), ll2 = 63 - __builtin_clzll(eq), pc = __builtin_popcountll(eq);
+                        if (nmin == 0 || segmin < minE) { minE = segmin; argf = q0 + fl; argl = q0 + ll2; nmin = pc; }
+                        else if (segmin == minE) { argl = q0 + ll2; nmin += pc; }
+                    }
+                    if (end_lane < 64) {
+                        const int qe = q0 + end_lane;
+                        const int32_t exitE = __builtin_amdgcn_readlane(E, end_lane);
+                        if (lane == 0) {
+                            DevRecord rec;
+                            rec.tile = tile; rec.kind_kfv = REC_RUN | (kid << 8);
+                            rec.start = run_start; rec.end = qe - 1; rec.minE = minE;
+                            rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
+                            rec.exitE = exitE; rec.has_exit = qe < n_valid ? 1 : 0;
+                            emit_global(a, rec);
+                        }
+                        in_run = 0;
+                        cursor = end_lane;
+                    } else {
+                        cursor = 64;
+                    }
+                } else {
+                    const uint64_t nu = U & rem;
+                    if (!nu) break;
+                    cursor = __builtin_ctzll(nu);
+                    in_run = 1; run_start = q0 + cursor; nmin = 0; minE = 0; argf = argl = run_start;
+                }
+            }
+            st[ST_INRUN] = in_run; st[ST_START] = run_start; st[ST_MINE] = minE; st[ST_ARGF] = argf; st[ST_ARGL] = argl;
+            st[ST_NMIN] = nmin;
+        }
+    }
+
+    // ---- runs still open at the end of the stream (the host joins them with the next stream's) ----
+    for (int j = 0; j < n_kfv; j++) {
+        int32_t *st = MULTI ? sState + j * ST_WORDS : st_local;
+        if (uni(st[ST_INRUN]) && lane == 0) {
+            DevRecord rec;
+            rec.tile = tile; rec.kind_kfv = REC_RUN | (gp.kfv_id[j] << 8);
+            rec.start = st[ST_START]; rec.end = n_valid - 1; rec.minE = st[ST_MINE];
+            rec.argf = st[ST_ARGF]; rec.argl = st[ST_ARGL]; rec.nmin = st[ST_NMIN];
+            rec.exitE = 0; rec.has_exit = 0;
+            emit_global(a, rec);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// geometry + launch
+// ------------------------------------------------------------------------------------------
+int stream_ring(int nk)
+{
+    int r = 128;
+    while (r < nk + 64) r <<= 1;
+    return r;
+}
+
+bool stream_tables_in_lds(int k, int n_kfv) { return k <= 6 && (size_t)n_kfv * ((size_t)4 << (2 * k)) <= (size_t)64 << 10; }
+
+static size_t stream_wave_bytes(int k, int nk, int n_kfv, int n_sizes)
+{
+    const size_t NB = (size_t)1 << (2 * k);
+    const size_t ring = (size_t)stream_ring(nk);
+    const bool multi = n_kfv > 1;
+    return NB * 2 * (size_t)(multi ? n_sizes : 1) + ring * 2 + (multi ? (size_t)KGMA_MAX_GROUP * ST_WORDS * 4 : 0);
+}
+
+// waves (= streams) per workgroup: as many as the 160 KiB of LDS hold, at most 16
+int stream_waves(int k, int nk, int n_kfv, int n_sizes)
+{
+    const size_t tab = stream_tables_in_lds(k, n_kfv) ? (size_t)n_kfv * ((size_t)4 << (2 * k)) : 0;
+    const size_t budget = ((size_t)160 << 10) - 512;
+    const size_t per = stream_wave_bytes(k, nk, n_kfv, n_sizes);
+    if (tab + per > budget) return 0;
+    size_t w = (budget - tab) / per;
+    return (int)(w > 16 ? 16 : w);
+}
+
+template <int K>
+static hipError_t launch_stream_k(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+{
+    const bool multi = gp.n_kfv > 1;
+    const bool tlds = stream_tables_in_lds(K, gp.n_kfv);
+    const int ring = stream_ring(gp.nk);
+    const int nw = stream_waves(K, gp.nk, gp.n_kfv, gp.n_sizes);
+    if (nw < 1) return hipErrorInvalidValue;
+    const size_t lds = (tlds ? (size_t)gp.n_kfv * ((size_t)4 << (2 * K)) : 0) + (size_t)nw * stream_wave_bytes(K, gp.nk, gp.n_kfv, gp.n_sizes);
+    const unsigned grid = (unsigned)((a.n_tiles + nw - 1) / nw);
+#define KGMA_STREAM_LAUNCH(M, T)                                                                                     \
+    {                                                                                                               \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_kernel<K, M, T>),                  \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+        if (e != hipSuccess) return e;                                                                              \
+        hipLaunchKernelGGL((stream_kernel<K, M, T>), dim3(grid), dim3((unsigned)(64 * nw)), lds, st, a, gp, ring);   \
+    }
+    if (multi) { if (tlds) KGMA_STREAM_LAUNCH(true, true) else KGMA_STREAM_LAUNCH(true, false) }
+    else       { if (tlds) KGMA_STREAM_LAUNCH(false, true) else KGMA_STREAM_LAUNCH(false, false) }
+#undef KGMA_STREAM_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+{
+    switch (gp.k) {
+    case 2: return launch_stream_k<2>(a, gp, st);
+    case 3: return launch_stream_k<3>(a, gp, st);
+    case 4: return launch_stream_k<4>(a, gp, st);
+    case 5: return launch_stream_k<5>(a, gp, st);
+    case 6: return launch_stream_k<6>(a, gp, st);
+    case 7: return launch_stream_k<7>(a, gp, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace kgma
