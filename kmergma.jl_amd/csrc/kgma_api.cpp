@@ -895,9 +895,13 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     // ---- which kernel: the count-table stream kernel for k <= 7 (one wave per stream), the bit-sliced
     //      kernel for longer k-mers (their 4^k counters do not fit a wave's share of the LDS)
     const std::vector<Group> groups = make_groups(ctx, mode);
-    bool use_stream = k <= KGMA_STREAM_MAX_K;
+    // (measured, 400 Mb random sequence: k=6 one KFV 294 vs 172 Gbp/s; below k=5 the 64 transitions of
+    // a step collide too often, and with several KFVs / k=7 the per-wave LDS share leaves too few waves)
+    bool use_stream = k >= 5 && k <= 6;
+    for (const Group &gr : groups) if (gr.kfvs.size() != 1) use_stream = false;
     if (const char *kv = getenv("KGMA_KERNEL")) {      // testing only: run the other kernel where both apply
         if (!strcmp(kv, "bitslice")) use_stream = false;
+        if (!strcmp(kv, "stream")) use_stream = k <= KGMA_STREAM_MAX_K;
     }
     int stream_nw = 16;
     if (use_stream)

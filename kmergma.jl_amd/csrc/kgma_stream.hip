@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kgma_device.h"
 
 namespace kgma {
@@ -89,7 +91,7 @@ __device__ __forceinline__ void emit_global(const ScanArgs &a, const DevRecord &
 // K: k-mer length; MULTI: more than one KFV (state in LDS, loops over KFVs / window sizes);
 // TLDS: the S tables of the launch are staged in LDS (else gathered from global memory / L2).
 template <int K, bool MULTI, bool TLDS>
-__global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp, int ring)
+__global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp)
 {
     constexpr int NB = 1 << (2 * K);
     constexpr uint32_t KM = (1u << K) - 1u;
@@ -101,16 +103,14 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
     const int nwaves = (int)(blockDim.x >> 6);
     const int n_kfv = MULTI ? gp.n_kfv : 1;
     const int n_sizes = MULTI ? gp.n_sizes : 1;
-    const int RM = ring - 1;
 
-    // ---- LDS carve-up: [S tables (TLDS)] then per wave [count table per size | key ring | state]
+    // ---- LDS carve-up: [S tables (TLDS)] then per wave [count table per size | state]
     int32_t *sTab = reinterpret_cast<int32_t *>(smem);
     const size_t tab_words = TLDS ? (size_t)n_kfv * NB : 0;
-    const size_t per_wave_words = (size_t)(NB / 2) * (size_t)n_sizes + (size_t)(ring / 2) + (MULTI ? KGMA_MAX_GROUP * ST_WORDS : 0);
+    const size_t per_wave_words = (size_t)(NB / 2) * (size_t)n_sizes + (MULTI ? KGMA_MAX_GROUP * ST_WORDS : 0);
     uint32_t *wbase = smem + tab_words + (size_t)wave * per_wave_words;
     uint32_t *sCnt = wbase;                                           // [n_sizes][NB/2] dwords = 2 x 16-bit counters
-    uint16_t *sKey = reinterpret_cast<uint16_t *>(wbase + (size_t)(NB / 2) * n_sizes);
-    int32_t *sState = reinterpret_cast<int32_t *>(sKey + ring);
+    int32_t *sState = reinterpret_cast<int32_t *>(wbase + (size_t)(NB / 2) * n_sizes);
 
     if constexpr (TLDS) {
         for (int j = 0; j < n_kfv; j++) {
@@ -133,65 +133,139 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
     const TileDesc td = a.tiles[tile];
     const int n_valid = td.n_valid, first_test = td.first_test;
     const int nk = gp.nk;                                             // largest window of the launch
+    const int nk_min = MULTI ? gp.nk_min : nk;
     const uint2 *g2 = reinterpret_cast<const uint2 *>(a.planes) + td.word_base;
-    const int half = lane >> 5;
-    const uint32_t sh = (uint32_t)(lane & 31);
     const int n_pos = n_valid + nk - 1;                               // k-mer positions this stream needs
     const int n_blocks = (n_pos + 63) >> 6;
-    const uint64_t lt_mask = ((uint64_t)1 << lane) - 1u;
 
-    uint2 wlo = g2[half], whi = g2[half + 1];
-    for (int b = 0; b < n_blocks; b++) {
-        const uint2 clo = wlo, chi = whi;
-        wlo = g2[2 * (b + 1) + half];                                 // next step (the plane array is padded)
-        whi = g2[2 * (b + 1) + half + 1];
-        const int p = (b << 6) + lane;                                // position of the entering k-mer
-        const uint32_t hh = __builtin_amdgcn_alignbit(chi.x, clo.x, sh) & KM;
-        const uint32_t ll = __builtin_amdgcn_alignbit(chi.y, clo.y, sh) & KM;
-        const uint32_t kp = (hh << K) | ll;
-        sKey[p & RM] = (uint16_t)kp;
+    // per-lane constants: entering k-mer at p = 64 b + lane, leaving k-mer of size z at p - nk_z
+    const int e_word = lane >> 5;
+    const uint32_t e_sh = (uint32_t)(lane & 31);
+    int l_word[NZ];
+    uint32_t l_sh[NZ];
+#pragma unroll
+    for (int z = 0; z < NZ; z++) {
+        const int off = lane - ((MULTI && z < n_sizes) ? gp.sizes[z] : nk);
+        l_word[z] = off >> 5;                                         // floor: may be negative
+        l_sh[z] = (uint32_t)(off & 31);
+    }
 
-        // ---- per window size: exact counts of the entering / leaving k-mer in THIS lane's window ----
-        uint32_t ksz[NZ];
-        int32_t cPz[NZ], cSz[NZ];
-        bool actz[NZ];
+    // One step = 64 consecutive entering k-mers = 64 windows per size.  GENERIC steps handle the
+    // warm-up (no leaving k-mer yet, first-window D) and the stream's end (windows past n_valid).
+    // plane words of the NEXT step are loaded one step ahead (global latency hidden behind a step)
+    uint2 pe0, pe1, pl0[NZ], pl1[NZ];
+    auto prefetch = [&](const int b) {
+        pe0 = g2[2 * b + e_word];
+        pe1 = g2[2 * b + e_word + 1];
 #pragma unroll
         for (int z = 0; z < NZ; z++) {
-            ksz[z] = kp; cPz[z] = 0; cSz[z] = 0; actz[z] = false;
             if (z >= n_sizes) continue;
-            const int nkz = MULTI ? gp.sizes[z] : nk;
+            int wi = 2 * b + l_word[z];
+            wi = wi < 0 ? 0 : wi;                                     // warm-up lanes have no leaving k-mer yet
+            pl0[z] = g2[wi];
+            pl1[z] = g2[wi + 1];
+        }
+    };
+    prefetch(0);
+
+    auto step = [&](const int b, auto generic_tag) {
+        constexpr bool GENERIC = decltype(generic_tag)::value;
+        const int p = (b << 6) + lane;                                // position of the entering k-mer
+        const uint2 ce0 = pe0, ce1 = pe1;
+        uint2 cl0[NZ], cl1[NZ];
+#pragma unroll
+        for (int z = 0; z < NZ; z++) { cl0[z] = pl0[z]; cl1[z] = pl1[z]; }
+        prefetch(b + 1);                                              // (the plane array is padded past the last record)
+        uint32_t kp;
+        {
+            const uint32_t hh = __builtin_amdgcn_alignbit(ce1.x, ce0.x, e_sh) & KM;
+            const uint32_t ll = __builtin_amdgcn_alignbit(ce1.y, ce0.y, e_sh) & KM;
+            kp = (hh << K) | ll;
+        }
+        // ---- per window size: issue every LDS operation of the step back to back -------------------
+        uint32_t ksz[NZ], shpz[NZ], shsz[NZ], wcp[NZ], wcs[NZ], wop[NZ], wos[NZ];
+        bool actz[NZ], actEz[NZ];
+#pragma unroll
+        for (int z = 0; z < NZ; z++) {
+            ksz[z] = kp; shpz[z] = shsz[z] = 0; wcp[z] = wcs[z] = wop[z] = wos[z] = 0; actz[z] = actEz[z] = false;
+            if (z >= n_sizes) continue;
             uint32_t *C = sCnt + (size_t)z * (NB / 2);
-            const int s = p - nkz;                                    // window whose last k-mer is p-1; its first leaves
-            const bool haveL = s >= 0;
-            const uint32_t ks = haveL ? (uint32_t)sKey[s & RM] & (uint32_t)(NB - 1) : kp;
-            const bool actE = !haveL || kp != ks;                     // GenomeMiner.jl:66: nothing happens if left == right
-            const bool actL = haveL && kp != ks;
+            bool haveL = true;
+            if constexpr (GENERIC) haveL = p >= ((MULTI) ? gp.sizes[z] : nk);
+            const uint2 w0 = cl0[z], w1 = cl1[z];
+            const uint32_t hh = __builtin_amdgcn_alignbit(w1.x, w0.x, l_sh[z]) & KM;
+            const uint32_t ll = __builtin_amdgcn_alignbit(w1.y, w0.y, l_sh[z]) & KM;
+            uint32_t ks = (hh << K) | ll;
+            if constexpr (GENERIC) ks = haveL ? ks : kp;
+            const bool differ = kp != ks;                             // GenomeMiner.jl:66: nothing happens if left == right
+            const bool actE = differ || !haveL, actL = differ && haveL;
             const uint32_t shp = 16u * (kp & 1u), shs = 16u * (ks & 1u);
-            const uint32_t cp = (C[kp >> 1] >> shp) & 0xFFFFu;        // counts at the start of the step
-            const uint32_t cs = (C[ks >> 1] >> shs) & 0xFFFFu;
-            uint32_t oldp = cp, olds = cs;
-            if (actE) oldp = (atomicAdd(&C[kp >> 1], 1u << shp) >> shp) & 0xFFFFu;
-            if (actL) olds = (atomicSub(&C[ks >> 1], 1u << shs) >> shs) & 0xFFFFu;
-            // a returned value that differs from the value read: another lane's transition touched that k-mer
-            uint64_t pendE = __ballot(oldp != cp), pendL = __ballot(olds != cs);
-            int32_t corrP = 0, corrS = 0;
-            while (pendE | pendL) {
-                uint32_t x0;
-                if (pendE) x0 = (uint32_t)__builtin_amdgcn_readlane((int)kp, __builtin_ctzll(pendE));
-                else x0 = (uint32_t)__builtin_amdgcn_readlane((int)ks, __builtin_ctzll(pendL));
-                const uint64_t ME = __ballot(actE && kp == x0), ML = __ballot(actL && ks == x0);
-                // transitions of lower lanes happen before this lane's window
-                const int32_t corr = __builtin_popcountll(ME & lt_mask) - __builtin_popcountll(ML & lt_mask);
-                corrP = kp == x0 ? corr : corrP;
-                corrS = ks == x0 ? corr : corrS;
-                pendE &= ~ME;
-                pendL &= ~ML;
+            wcp[z] = C[kp >> 1];                                      // counts at the start of the step
+            wcs[z] = C[ks >> 1];
+            // this lane's transition; the old values tell whether another lane touched the k-mer.  Lanes
+            // without a transition (left == right: homopolymer / N runs) issue nothing: 64 lanes adding 0
+            // to one address would serialise in the LDS for nothing.
+            if (actE) wop[z] = atomicAdd(&C[kp >> 1], 1u << shp);
+            if (actL) wos[z] = atomicSub(&C[ks >> 1], 1u << shs);
+            ksz[z] = ks; shpz[z] = shp; shsz[z] = shs; actz[z] = actL; actEz[z] = actE;
+        }
+        int32_t Svj[MULTI ? KGMA_MAX_GROUP : 1], Ssj[MULTI ? KGMA_MAX_GROUP : 1];
+#pragma unroll
+        for (int j = 0; j < (MULTI ? KGMA_MAX_GROUP : 1); j++) {
+            Svj[j] = Ssj[j] = 0;
+            if (j >= n_kfv) continue;
+            int zi = 0;
+            if constexpr (MULTI) {
+#pragma unroll
+                for (int z = 1; z < KGMA_MAX_SIZES; z++) zi = (z < n_sizes && gp.sizes[z] == gp.nk_of[j]) ? z : zi;
             }
-            ksz[z] = ks; cPz[z] = (int32_t)cp + corrP; cSz[z] = (int32_t)cs + corrS; actz[z] = actL;
+            uint32_t ks = ksz[0];
+            if constexpr (MULTI) {
+#pragma unroll
+                for (int z = 1; z < KGMA_MAX_SIZES; z++) ks = zi == z ? ksz[z] : ks;
+            }
+            const int32_t *S = TLDS ? sTab + (size_t)j * NB : a.Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
+            Svj[j] = S[kp];
+            Ssj[j] = S[ks];
+        }
+
+        // ---- exact counts of the entering / leaving k-mer in THIS lane's window ------------------------
+        int32_t cPz[NZ], cSz[NZ];
+#pragma unroll
+        for (int z = 0; z < NZ; z++) {
+            cPz[z] = cSz[z] = 0;
+            if (z >= n_sizes) continue;
+            const uint32_t ks = ksz[z];
+            const uint32_t cp = (wcp[z] >> shpz[z]) & 0xFFFFu, cs = (wcs[z] >> shsz[z]) & 0xFFFFu;
+            const uint32_t oldp = (wop[z] >> shpz[z]) & 0xFFFFu, olds = (wos[z] >> shsz[z]) & 0xFFFFu;
+            // a returned value that differs from the value read: another lane's transition touched that k-mer
+            // (only lanes whose own transition is real take part: the others added 0)
+            uint64_t pendE = __ballot(actEz[z] && oldp != cp), pendL = __ballot(actz[z] && olds != cs);
+            int32_t corrP = 0, corrS = 0;
+            if (pendE | pendL) {
+                const uint64_t AE = __ballot(actEz[z]), AL = __ballot(actz[z]);
+                // (at most 128 distinct k-mers per step; the bound only guards against a runaway wave)
+                for (int it = 0; it < 128 && (pendE | pendL) != 0; it++) {
+                    uint32_t x0;
+                    if (pendE) x0 = (uint32_t)__builtin_amdgcn_readlane((int)kp, __builtin_ctzll(pendE));
+                    else x0 = (uint32_t)__builtin_amdgcn_readlane((int)ks, __builtin_ctzll(pendL));
+                    const uint64_t ME = __ballot(kp == x0) & AE, ML = __ballot(ks == x0) & AL;
+                    // transitions of lower lanes happen before this lane's window
+                    const int32_t ne = (int32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(ME >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ME, 0u));
+                    const int32_t nl = (int32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(ML >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ML, 0u));
+                    corrP = kp == x0 ? ne - nl : corrP;
+                    corrS = ks == x0 ? ne - nl : corrS;
+                    pendE &= ~ME;
+                    pendL &= ~ML;
+                }
+            }
+            cPz[z] = (int32_t)cp + corrP; cSz[z] = (int32_t)cs + corrS;
         }
 
         // ---- per KFV: close the window whose last k-mer is p ------------------------------------
-        for (int j = 0; j < n_kfv; j++) {
+#pragma unroll
+        for (int j = 0; j < (MULTI ? KGMA_MAX_GROUP : 1); j++) {
+            if (j >= n_kfv) continue;
             int32_t *st = MULTI ? sState + j * ST_WORDS : st_local;
             const int nkj = MULTI ? gp.nk_of[j] : nk;
             int zi = 0;
@@ -199,48 +273,45 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
 #pragma unroll
                 for (int z = 1; z < KGMA_MAX_SIZES; z++) zi = (z < n_sizes && gp.sizes[z] == nkj) ? z : zi;
             }
-            uint32_t ks = ksz[0];
             int32_t cP = cPz[0], cS = cSz[0];
             bool act = actz[0];
             if constexpr (MULTI) {
 #pragma unroll
-                for (int z = 1; z < KGMA_MAX_SIZES; z++) {
-                    ks = zi == z ? ksz[z] : ks; cP = zi == z ? cPz[z] : cP; cS = zi == z ? cSz[z] : cS; act = zi == z ? actz[z] : act;
-                }
+                for (int z = 1; z < KGMA_MAX_SIZES; z++) { cP = zi == z ? cPz[z] : cP; cS = zi == z ? cSz[z] : cS; act = zi == z ? actz[z] : act; }
             }
-            const int32_t *S = TLDS ? sTab + (size_t)j * NB : a.Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
             const int32_t Nj = gp.N[j];
             const int64_t twoN = 2 * (int64_t)Nj;
-            const int32_t Sv = S[kp];
-            const int32_t Ss = S[ks];
+            const int32_t Sv = Svj[j], Ss = Ssj[j];
             const int32_t e = act ? Ss - Sv - Nj * (cS - 1 - cP) : 0;  // GenomeMiner.jl:67-68 times 2kN^2 / 2N
 
-            if ((b << 6) < nkj) {                                     // warm-up blocks: first-window D
-                const bool wu = p < nkj;
-                const int64_t ssum = wave_sum_i64(wu ? (int64_t)Sv : 0);
-                const int64_t psum = wave_sum_i64(wu ? (int64_t)cP : 0);
-                int64_t sumS = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_SUMHI]) << 32) | (uint32_t)uni(st[ST_SUMLO])) + ssum;
-                const int32_t pairs = uni(st[ST_PAIRS]) + (int32_t)psum;
-                st[ST_SUMLO] = (int32_t)(uint32_t)sumS;
-                st[ST_SUMHI] = (int32_t)(uint32_t)((uint64_t)sumS >> 32);
-                st[ST_PAIRS] = pairs;
-                if (nkj - 1 < (b << 6) + 64) {                        // last warm-up position is in this block
-                    const int64_t D0 = gp.sumS2[j] - twoN * sumS + (int64_t)Nj * Nj * ((int64_t)nkj + 2 * (int64_t)pairs);
-                    if (lane == 0) a.D0out[(size_t)(gp.kfv_id[j] - 1) * a.n_tiles + tile] = D0;
-                    st[ST_D0LO] = (int32_t)(uint32_t)D0;
-                    st[ST_D0HI] = (int32_t)(uint32_t)((uint64_t)D0 >> 32);
-                    // E_q < TE  <=>  D0 + 2N E_q < T; windows with TE <= E_q < TE + natt are at threshold
-                    const int64_t num = gp.T[j] - D0;
-                    int64_t TE64 = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
-                    const int64_t numh = gp.T_hi[j] - D0;
-                    const int64_t TH64 = numh >= 0 ? numh / twoN : -((-numh + twoN - 1) / twoN);
-                    int64_t na = gp.T_hi[j] >= gp.T[j] ? TH64 - TE64 + 1 : 0;
-                    if (na < 0) na = 0;
-                    if (na > 0x3FFFFFFF) na = 0x3FFFFFFF;
-                    if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; na = 0; }
-                    if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; na = 0; }
-                    st[ST_TE] = (int32_t)TE64;
-                    st[ST_NATT] = (int32_t)na;
+            if constexpr (GENERIC) {
+                if ((b << 6) < nkj) {                                 // warm-up steps: first-window D
+                    const bool wu = p < nkj;
+                    const int64_t ssum = wave_sum_i64(wu ? (int64_t)Sv : 0);
+                    const int64_t psum = wave_sum_i64(wu ? (int64_t)cP : 0);
+                    int64_t sumS = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_SUMHI]) << 32) | (uint32_t)uni(st[ST_SUMLO])) + ssum;
+                    const int32_t pairs = uni(st[ST_PAIRS]) + (int32_t)psum;
+                    st[ST_SUMLO] = (int32_t)(uint32_t)sumS;
+                    st[ST_SUMHI] = (int32_t)(uint32_t)((uint64_t)sumS >> 32);
+                    st[ST_PAIRS] = pairs;
+                    if (nkj - 1 < (b << 6) + 64) {                    // last warm-up position is in this step
+                        const int64_t D0 = gp.sumS2[j] - twoN * sumS + (int64_t)Nj * Nj * ((int64_t)nkj + 2 * (int64_t)pairs);
+                        if (lane == 0) a.D0out[(size_t)(gp.kfv_id[j] - 1) * a.n_tiles + tile] = D0;
+                        st[ST_D0LO] = (int32_t)(uint32_t)D0;
+                        st[ST_D0HI] = (int32_t)(uint32_t)((uint64_t)D0 >> 32);
+                        // E_q < TE  <=>  D0 + 2N E_q < T; windows with TE <= E_q < TE + natt are at threshold
+                        const int64_t num = gp.T[j] - D0;
+                        int64_t TE64 = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
+                        const int64_t numh = gp.T_hi[j] - D0;
+                        const int64_t TH64 = numh >= 0 ? numh / twoN : -((-numh + twoN - 1) / twoN);
+                        int64_t na = gp.T_hi[j] >= gp.T[j] ? TH64 - TE64 + 1 : 0;
+                        if (na < 0) na = 0;
+                        if (na > 0x3FFFFFFF) na = 0x3FFFFFFF;
+                        if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; na = 0; }
+                        if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; na = 0; }
+                        st[ST_TE] = (int32_t)TE64;
+                        st[ST_NATT] = (int32_t)na;
+                    }
                 }
             }
 
@@ -249,7 +320,8 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
             const int32_t TE = uni(st[ST_TE]);
             const int32_t natt = uni(st[ST_NATT]);
             const int q = p - nkj + 1;                                // window start (local) whose last k-mer is p
-            const bool tested = q >= first_test && q < n_valid;
+            bool tested = true;
+            if constexpr (GENERIC) tested = q >= first_test && q < n_valid;
             const bool under = tested && E < TE;
             double *dist = a.dist[j];
             if (dist != nullptr && tested) {
@@ -258,11 +330,11 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
             }
             const bool att = natt != 0 && tested && !under && E - TE < natt;
             const uint64_t U = __ballot(under);
-            const uint64_t A = __ballot(att);
+            const uint64_t A = natt != 0 ? __ballot(att) : 0;
             int in_run = uni(st[ST_INRUN]);
             if ((U | A) == 0 && !in_run) continue;                    // fast path: nothing near the threshold
 
-            // ---- a dip touches this block: walk its runs (wave-uniform) ----------------------------
+            // ---- a dip touches this step: walk its runs (wave-uniform) ----------------------------
             const int kid = gp.kfv_id[j];
             const int q0 = (b << 6) - nkj + 1;                        // window of lane 0
             if (att) {
@@ -315,7 +387,19 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
             st[ST_INRUN] = in_run; st[ST_START] = run_start; st[ST_MINE] = minE; st[ST_ARGF] = argf; st[ST_ARGL] = argl;
             st[ST_NMIN] = nmin;
         }
-    }
+    };
+
+    // warm-up steps (some lane still has p < nk), steady steps (every window exists), end steps
+    int b_warm = (nk + 63) >> 6;
+    if (b_warm > n_blocks) b_warm = n_blocks;
+    int b_tail = n_valid + nk_min - 65;                               // steps b <= b_tail/64 have all windows < n_valid
+    b_tail = b_tail >= 0 ? (b_tail >> 6) + 1 : 0;
+    if (b_tail < b_warm) b_tail = b_warm;
+    if (b_tail > n_blocks) b_tail = n_blocks;
+    int b = 0;
+    for (; b < b_warm; b++) step(b, std::true_type{});
+    for (; b < b_tail; b++) step(b, std::false_type{});
+    for (; b < n_blocks; b++) step(b, std::true_type{});
 
     // ---- runs still open at the end of the stream (the host joins them with the next stream's) ----
     for (int j = 0; j < n_kfv; j++) {
@@ -334,21 +418,13 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
 // ------------------------------------------------------------------------------------------
 // geometry + launch
 // ------------------------------------------------------------------------------------------
-int stream_ring(int nk)
-{
-    int r = 128;
-    while (r < nk + 64) r <<= 1;
-    return r;
-}
-
 bool stream_tables_in_lds(int k, int n_kfv) { return k <= 6 && (size_t)n_kfv * ((size_t)4 << (2 * k)) <= (size_t)64 << 10; }
 
-static size_t stream_wave_bytes(int k, int nk, int n_kfv, int n_sizes)
+static size_t stream_wave_bytes(int k, int n_kfv, int n_sizes)
 {
     const size_t NB = (size_t)1 << (2 * k);
-    const size_t ring = (size_t)stream_ring(nk);
     const bool multi = n_kfv > 1;
-    return NB * 2 * (size_t)(multi ? n_sizes : 1) + ring * 2 + (multi ? (size_t)KGMA_MAX_GROUP * ST_WORDS * 4 : 0);
+    return NB * 2 * (size_t)(multi ? n_sizes : 1) + (multi ? (size_t)KGMA_MAX_GROUP * ST_WORDS * 4 : 0);
 }
 
 // waves (= streams) per workgroup: as many as the 160 KiB of LDS hold, at most 16
@@ -356,7 +432,8 @@ int stream_waves(int k, int nk, int n_kfv, int n_sizes)
 {
     const size_t tab = stream_tables_in_lds(k, n_kfv) ? (size_t)n_kfv * ((size_t)4 << (2 * k)) : 0;
     const size_t budget = ((size_t)160 << 10) - 512;
-    const size_t per = stream_wave_bytes(k, nk, n_kfv, n_sizes);
+    const size_t per = stream_wave_bytes(k, n_kfv, n_sizes);
+    (void)nk;
     if (tab + per > budget) return 0;
     size_t w = (budget - tab) / per;
     return (int)(w > 16 ? 16 : w);
@@ -367,17 +444,16 @@ static hipError_t launch_stream_k(const ScanArgs &a, const GroupParams &gp, hipS
 {
     const bool multi = gp.n_kfv > 1;
     const bool tlds = stream_tables_in_lds(K, gp.n_kfv);
-    const int ring = stream_ring(gp.nk);
     const int nw = stream_waves(K, gp.nk, gp.n_kfv, gp.n_sizes);
     if (nw < 1) return hipErrorInvalidValue;
-    const size_t lds = (tlds ? (size_t)gp.n_kfv * ((size_t)4 << (2 * K)) : 0) + (size_t)nw * stream_wave_bytes(K, gp.nk, gp.n_kfv, gp.n_sizes);
+    const size_t lds = (tlds ? (size_t)gp.n_kfv * ((size_t)4 << (2 * K)) : 0) + (size_t)nw * stream_wave_bytes(K, gp.n_kfv, gp.n_sizes);
     const unsigned grid = (unsigned)((a.n_tiles + nw - 1) / nw);
 #define KGMA_STREAM_LAUNCH(M, T)                                                                                     \
     {                                                                                                               \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_kernel<K, M, T>),                  \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
         if (e != hipSuccess) return e;                                                                              \
-        hipLaunchKernelGGL((stream_kernel<K, M, T>), dim3(grid), dim3((unsigned)(64 * nw)), lds, st, a, gp, ring);   \
+        hipLaunchKernelGGL((stream_kernel<K, M, T>), dim3(grid), dim3((unsigned)(64 * nw)), lds, st, a, gp);   \
     }
     if (multi) { if (tlds) KGMA_STREAM_LAUNCH(true, true) else KGMA_STREAM_LAUNCH(true, false) }
     else       { if (tlds) KGMA_STREAM_LAUNCH(false, true) else KGMA_STREAM_LAUNCH(false, false) }
