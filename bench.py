@@ -140,7 +140,7 @@ def main():
                        "n_hits": len(hits), "n_planted": len(plants), "sharding": "records across GPUs"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "kernel": "scan_kernel<6,2,9>", "kernel_ms": round(avg_scan_ms, 4),
+                         "kernel": ctx.kernel_name(), "kernel_ms": round(avg_scan_ms, 4),
                          "pack_kernel_ms": round(sum(pack_ms) / len(pack_ms), 4),
                          "algorithmic_bytes": ALGO_BYTES_PER_BASE * length,
                          "scan_only_Gbp_s": round(length / avg_scan_ms / 1e6, 2),

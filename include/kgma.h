@@ -232,6 +232,10 @@ int kgma_host_semiglobal_cigar(const uint8_t *a, int64_t m, const uint8_t *b, in
 /* Host stream handle (hipStream_t) the context launches on, for callers that time with hipEvents. */
 void *kgma_stream(kgma_ctx *ctx);
 
+/* Name of the device kernel the last scan launched ("stream_kernel<6>" / "scan_kernel<8>"): the
+ * count-table stream kernel serves k = 5, 6 with one KFV per launch, the bit-sliced kernel the rest. */
+const char *kgma_scan_kernel_name(const kgma_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

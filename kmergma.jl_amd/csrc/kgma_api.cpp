@@ -89,6 +89,7 @@ struct kgma_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evp0 = nullptr, evp1 = nullptr;
     std::string err;
     uint8_t *h_pin = nullptr; size_t h_pin_cap = 0;     // pinned result staging
+    char kernel_name[48] = "";
     uint8_t *d_gath = nullptr, *h_gath = nullptr; size_t gath_cap = 0;   // tie-replay residue gather: [desc | residues]
     uint64_t next_uid = 1;
     // key of the tile table currently on the device
@@ -325,6 +326,8 @@ void kgma_destroy(kgma_ctx *ctx)
 }
 
 void *kgma_stream(kgma_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+const char *kgma_scan_kernel_name(const kgma_ctx *ctx) { return ctx ? ctx->kernel_name : ""; }
 
 int kgma_set_thresholds(kgma_ctx *ctx, const double *thr)
 {
@@ -898,7 +901,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     // (measured, 400 Mb random sequence: k=6 one KFV 294 vs 172 Gbp/s; below k=5 the 64 transitions of
     // a step collide too often, and with several KFVs / k=7 the per-wave LDS share leaves too few waves)
     bool use_stream = k >= 5 && k <= 6;
-    for (const Group &gr : groups) if (gr.kfvs.size() != 1) use_stream = false;
+    for (const Group &gr : groups) if (gr.kfvs.size() != 1) use_stream = false;   // several KFVs: 99 vs 112 Gbp/s (3 KFVs)
     if (const char *kv = getenv("KGMA_KERNEL")) {      // testing only: run the other kernel where both apply
         if (!strcmp(kv, "bitslice")) use_stream = false;
         if (!strcmp(kv, "stream")) use_stream = k <= KGMA_STREAM_MAX_K;
@@ -916,6 +919,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     const int64_t nc = g->n_contigs;
     const bool want_dists = (flags & KGMA_F_RETURN_DISTS) != 0;
     const int geom_version = use_stream ? 2 : 1;
+    snprintf(ctx->kernel_name, sizeof ctx->kernel_name, use_stream ? "stream_kernel<%d>" : "scan_kernel<%d>", k);
 
     ctx->dips.clear();
     ctx->hits.clear();

@@ -88,29 +88,45 @@ __device__ __forceinline__ void emit_global(const ScanArgs &a, const DevRecord &
 
 }  // namespace
 
-// K: k-mer length; MULTI: more than one KFV (state in LDS, loops over KFVs / window sizes);
-// TLDS: the S tables of the launch are staged in LDS (else gathered from global memory / L2).
+// value of x in lane-1 (lane 0 receives `carry_in`): one DPP move
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x, uint32_t carry_in)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry_in, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+
+// K: k-mer length; MULTI: several KFVs per launch (hot per-KFV state in registers, the rest in LDS),
+// possibly with different window sizes; TLDS: the S tables of the launch are staged in LDS (else
+// gathered from global memory / L2).
+//
+// Windows of different sizes are LEFT-aligned like the reference's (one shared left k-mer,
+// OmnGenomeMiner.jl:92): lane p handles, for every size, the transition of the window starting at
+// s = p - n_max.  The count table follows the largest window; for a size with n_z = n_max - d the
+// entering k-mer is the entering k-mer of lane p-d and
+//     c_z[x] = c_max[x] - #{u in 1..d : K_{p-u} == x}                         (x = leaving k-mer)
+//     c_z[r] = c_max at lane p-d [r] - #{u in 1..d : leaving k-mer of lane p-u == r}   (r = entering k-mer)
+// so only the values of the d <= 8 lower lanes are needed (DPP shifts, carried across steps).
 template <int K, bool MULTI, bool TLDS>
 __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp)
 {
     constexpr int NB = 1 << (2 * K);
     constexpr uint32_t KM = (1u << K) - 1u;
     constexpr int NZ = MULTI ? KGMA_MAX_SIZES : 1;
+    constexpr int NG = MULTI ? KGMA_MAX_GROUP : 1;
+    constexpr uint32_t NO_KEY = 0xFFFFFFFFu;                          // "no leaving k-mer": equals no real k-mer
     extern __shared__ uint32_t smem[];
 
     const int lane = threadIdx.x & 63;
     const int wave = uni((int)(threadIdx.x >> 6));
-    const int nwaves = (int)(blockDim.x >> 6);
     const int n_kfv = MULTI ? gp.n_kfv : 1;
     const int n_sizes = MULTI ? gp.n_sizes : 1;
 
-    // ---- LDS carve-up: [S tables (TLDS)] then per wave [count table per size | state]
+    // ---- LDS carve-up: [S tables (TLDS)] then per wave [count table | cold per-KFV state]
     int32_t *sTab = reinterpret_cast<int32_t *>(smem);
     const size_t tab_words = TLDS ? (size_t)n_kfv * NB : 0;
-    const size_t per_wave_words = (size_t)(NB / 2) * (size_t)n_sizes + (MULTI ? KGMA_MAX_GROUP * ST_WORDS : 0);
+    const size_t per_wave_words = (size_t)(NB / 2) + (MULTI ? KGMA_MAX_GROUP * ST_WORDS : 0);
     uint32_t *wbase = smem + tab_words + (size_t)wave * per_wave_words;
-    uint32_t *sCnt = wbase;                                           // [n_sizes][NB/2] dwords = 2 x 16-bit counters
-    int32_t *sState = reinterpret_cast<int32_t *>(wbase + (size_t)(NB / 2) * n_sizes);
+    uint32_t *C = wbase;                                              // NB/2 dwords = 2 x 16-bit counters each
+    int32_t *sState = reinterpret_cast<int32_t *>(wbase + NB / 2);
 
     if constexpr (TLDS) {
         for (int j = 0; j < n_kfv; j++) {
@@ -119,174 +135,229 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
         }
         __syncthreads();
     }
-    const int tile = (int)blockIdx.x * nwaves + wave;
+    // streams are dealt to workgroups round-robin, so that each CU gets an even share of the cheap
+    // stretches of a genome (N runs: no transitions) and of the expensive ones
+    const int tile = wave * (int)gridDim.x + (int)blockIdx.x;
     if (tile >= a.n_tiles) return;                                    // (after the only workgroup barrier)
 
-    for (int i = lane; i < (NB / 2) * n_sizes; i += 64) sCnt[i] = 0;
+    for (int i = lane; i < NB / 2; i += 64) C[i] = 0;
     int32_t st_local[ST_WORDS];
 #pragma unroll
     for (int i = 0; i < ST_WORDS; i++) st_local[i] = 0;
     if constexpr (MULTI) {
         for (int i = lane; i < KGMA_MAX_GROUP * ST_WORDS; i += 64) sState[i] = 0;
     }
+    // hot per-KFV state (wave-uniform, scalar registers): prefix carry and threshold per KFV; one bit per
+    // KFV for "inside a dip", "has a threshold guard band", "distances requested", and its size index
+    int32_t h_carry[NG], h_TE[NG];
+#pragma unroll
+    for (int j = 0; j < NG; j++) { h_carry[j] = 0; h_TE[j] = 0; }
+    uint32_t inrun_mask = 0, att_mask = 0, dist_mask = 0, zi_pack = 0;
+#pragma unroll
+    for (int j = 0; j < NG; j++) {
+        if (j >= n_kfv) continue;
+        if (a.dist[j] != nullptr) dist_mask |= 1u << j;
+        if constexpr (MULTI) {
+            uint32_t zi = 0;
+#pragma unroll
+            for (int z = 1; z < KGMA_MAX_SIZES; z++) zi = (z < n_sizes && gp.sizes[z] == gp.nk_of[j]) ? (uint32_t)z : zi;
+            zi_pack |= zi << (2 * j);
+        }
+    }
 
     const TileDesc td = a.tiles[tile];
     const int n_valid = td.n_valid, first_test = td.first_test;
     const int nk = gp.nk;                                             // largest window of the launch
-    const int nk_min = MULTI ? gp.nk_min : nk;
+    const int DW = MULTI ? nk - gp.nk_min : 0;                        // <= KGMA_MAX_DW
     const uint2 *g2 = reinterpret_cast<const uint2 *>(a.planes) + td.word_base;
     const int n_pos = n_valid + nk - 1;                               // k-mer positions this stream needs
     const int n_blocks = (n_pos + 63) >> 6;
 
-    // per-lane constants: entering k-mer at p = 64 b + lane, leaving k-mer of size z at p - nk_z
+    // per-lane constants: entering k-mer at p = 64 b + lane, leaving k-mer at p - nk
     const int e_word = lane >> 5;
     const uint32_t e_sh = (uint32_t)(lane & 31);
-    int l_word[NZ];
-    uint32_t l_sh[NZ];
-#pragma unroll
-    for (int z = 0; z < NZ; z++) {
-        const int off = lane - ((MULTI && z < n_sizes) ? gp.sizes[z] : nk);
-        l_word[z] = off >> 5;                                         // floor: may be negative
-        l_sh[z] = (uint32_t)(off & 31);
-    }
+    const int l_word = (lane - nk) >> 5;                              // floor: may be negative
+    const uint32_t l_sh = (uint32_t)((lane - nk) & 31);
 
-    // One step = 64 consecutive entering k-mers = 64 windows per size.  GENERIC steps handle the
-    // warm-up (no leaving k-mer yet, first-window D) and the stream's end (windows past n_valid).
     // plane words of the NEXT step are loaded one step ahead (global latency hidden behind a step)
-    uint2 pe0, pe1, pl0[NZ], pl1[NZ];
+    uint2 pe0, pe1, pl0, pl1;
     auto prefetch = [&](const int b) {
         pe0 = g2[2 * b + e_word];
         pe1 = g2[2 * b + e_word + 1];
-#pragma unroll
-        for (int z = 0; z < NZ; z++) {
-            if (z >= n_sizes) continue;
-            int wi = 2 * b + l_word[z];
-            wi = wi < 0 ? 0 : wi;                                     // warm-up lanes have no leaving k-mer yet
-            pl0[z] = g2[wi];
-            pl1[z] = g2[wi + 1];
-        }
+        int wi = 2 * b + l_word;
+        wi = wi < 0 ? 0 : wi;                                         // warm-up lanes have no leaving k-mer yet
+        pl0 = g2[wi];
+        pl1 = g2[wi + 1];
     };
     prefetch(0);
+    // previous step's per-lane values (MULTI: lanes below 0 of a shift come from here)
+    // (kp_prev is also used as a table index: it must always be a real k-mer value)
+    uint32_t kp_prev = 0u, ksc_prev = NO_KEY;
+    int32_t cP_prev = 0;
 
+    // One step = 64 consecutive entering k-mers = 64 windows.  GENERIC steps handle the warm-up (no
+    // leaving k-mer yet, first-window D) and the stream's end (windows past n_valid).
     auto step = [&](const int b, auto generic_tag) {
         constexpr bool GENERIC = decltype(generic_tag)::value;
         const int p = (b << 6) + lane;                                // position of the entering k-mer
-        const uint2 ce0 = pe0, ce1 = pe1;
-        uint2 cl0[NZ], cl1[NZ];
-#pragma unroll
-        for (int z = 0; z < NZ; z++) { cl0[z] = pl0[z]; cl1[z] = pl1[z]; }
+        const uint2 ce0 = pe0, ce1 = pe1, cl0 = pl0, cl1 = pl1;
         prefetch(b + 1);                                              // (the plane array is padded past the last record)
-        uint32_t kp;
+        uint32_t kp, ks;
         {
             const uint32_t hh = __builtin_amdgcn_alignbit(ce1.x, ce0.x, e_sh) & KM;
             const uint32_t ll = __builtin_amdgcn_alignbit(ce1.y, ce0.y, e_sh) & KM;
             kp = (hh << K) | ll;
+            const uint32_t h2 = __builtin_amdgcn_alignbit(cl1.x, cl0.x, l_sh) & KM;
+            const uint32_t l2 = __builtin_amdgcn_alignbit(cl1.y, cl0.y, l_sh) & KM;
+            ks = (h2 << K) | l2;
         }
-        // ---- per window size: issue every LDS operation of the step back to back -------------------
-        uint32_t ksz[NZ], shpz[NZ], shsz[NZ], wcp[NZ], wcs[NZ], wop[NZ], wos[NZ];
-        bool actz[NZ], actEz[NZ];
+        bool haveL = true;
+        if constexpr (GENERIC) { haveL = p >= nk; ks = haveL ? ks : kp; }
+        const bool differ = kp != ks;                                 // GenomeMiner.jl:66: nothing happens if left == right
+        const bool actE = differ || !haveL, actL = differ && haveL;
+
+        // ---- issue every LDS operation of the step back to back --------------------------------------
+        const uint32_t shp = 16u * (kp & 1u), shs = 16u * (ks & 1u);
+        const uint32_t wcp = C[kp >> 1];                              // counts at the start of the step
+        const uint32_t wcs = C[ks >> 1];
+        // this lane's transition; the old values tell whether another lane touched the k-mer.  Lanes
+        // without a transition (left == right: homopolymer / N runs) issue nothing: 64 lanes adding 0
+        // to one address would serialise in the LDS for nothing.
+        uint32_t wop = 0, wos = 0;
+        if (actE) wop = atomicAdd(&C[kp >> 1], 1u << shp);
+        if (actL) wos = atomicSub(&C[ks >> 1], 1u << shs);
+        // ---- MULTI: entering k-mer of every window size (values of the d lower lanes, DPP) ---------
+        uint32_t rz[NZ];                                              // entering k-mer of size z
+        int32_t accS[NZ];                                             // #{u <= d_z : K_{p-u} == leaving k-mer}
+        int dsz[NZ];
 #pragma unroll
-        for (int z = 0; z < NZ; z++) {
-            ksz[z] = kp; shpz[z] = shsz[z] = 0; wcp[z] = wcs[z] = wop[z] = wos[z] = 0; actz[z] = actEz[z] = false;
-            if (z >= n_sizes) continue;
-            uint32_t *C = sCnt + (size_t)z * (NB / 2);
-            bool haveL = true;
-            if constexpr (GENERIC) haveL = p >= ((MULTI) ? gp.sizes[z] : nk);
-            const uint2 w0 = cl0[z], w1 = cl1[z];
-            const uint32_t hh = __builtin_amdgcn_alignbit(w1.x, w0.x, l_sh[z]) & KM;
-            const uint32_t ll = __builtin_amdgcn_alignbit(w1.y, w0.y, l_sh[z]) & KM;
-            uint32_t ks = (hh << K) | ll;
-            if constexpr (GENERIC) ks = haveL ? ks : kp;
-            const bool differ = kp != ks;                             // GenomeMiner.jl:66: nothing happens if left == right
-            const bool actE = differ || !haveL, actL = differ && haveL;
-            const uint32_t shp = 16u * (kp & 1u), shs = 16u * (ks & 1u);
-            wcp[z] = C[kp >> 1];                                      // counts at the start of the step
-            wcs[z] = C[ks >> 1];
-            // this lane's transition; the old values tell whether another lane touched the k-mer.  Lanes
-            // without a transition (left == right: homopolymer / N runs) issue nothing: 64 lanes adding 0
-            // to one address would serialise in the LDS for nothing.
-            if (actE) wop[z] = atomicAdd(&C[kp >> 1], 1u << shp);
-            if (actL) wos[z] = atomicSub(&C[ks >> 1], 1u << shs);
-            ksz[z] = ks; shpz[z] = shp; shsz[z] = shs; actz[z] = actL; actEz[z] = actE;
-        }
-        int32_t Svj[MULTI ? KGMA_MAX_GROUP : 1], Ssj[MULTI ? KGMA_MAX_GROUP : 1];
+        for (int z = 0; z < NZ; z++) { dsz[z] = (MULTI && z < n_sizes) ? nk - gp.sizes[z] : 0; rz[z] = kp; accS[z] = 0; }
+        if constexpr (MULTI) {
+            uint32_t ykp = kp;
+            for (int u = 1; u <= DW; u++) {                           // lane p-u: entering k-mer
+                ykp = wave_shr1(ykp, (uint32_t)__builtin_amdgcn_readlane((int)kp_prev, 64 - u));
 #pragma unroll
-        for (int j = 0; j < (MULTI ? KGMA_MAX_GROUP : 1); j++) {
-            Svj[j] = Ssj[j] = 0;
-            if (j >= n_kfv) continue;
-            int zi = 0;
-            if constexpr (MULTI) {
-#pragma unroll
-                for (int z = 1; z < KGMA_MAX_SIZES; z++) zi = (z < n_sizes && gp.sizes[z] == gp.nk_of[j]) ? z : zi;
+                for (int z = 0; z < NZ; z++) {
+                    if (u <= dsz[z]) accS[z] += ykp == ks ? 1 : 0;
+                    if (u == dsz[z]) rz[z] = ykp;
+                }
             }
-            uint32_t ks = ksz[0];
-            if constexpr (MULTI) {
+        }
+        // S[leaving], S[entering] of every KFV: issued now, consumed after the count corrections
+        int32_t Sl[NG], Sr[NG];
 #pragma unroll
-                for (int z = 1; z < KGMA_MAX_SIZES; z++) ks = zi == z ? ksz[z] : ks;
+        for (int j = 0; j < NG; j++) {
+            Sl[j] = Sr[j] = 0;
+            if (j >= n_kfv) continue;
+            uint32_t r = rz[0];
+            if constexpr (MULTI) {
+                uint32_t zi = (uint32_t)uni((int)((zi_pack >> (2 * j)) & 3u));
+                asm volatile("" : "+s"(zi));                          // keep the selects' conditions out of long-lived SGPRs
+#pragma unroll
+                for (int z = 1; z < KGMA_MAX_SIZES; z++) r = zi == (uint32_t)z ? rz[z] : r;
             }
             const int32_t *S = TLDS ? sTab + (size_t)j * NB : a.Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
-            Svj[j] = S[kp];
-            Ssj[j] = S[ks];
+            Sr[j] = S[r];
+            Sl[j] = S[ks];
         }
 
-        // ---- exact counts of the entering / leaving k-mer in THIS lane's window ------------------------
-        int32_t cPz[NZ], cSz[NZ];
-#pragma unroll
-        for (int z = 0; z < NZ; z++) {
-            cPz[z] = cSz[z] = 0;
-            if (z >= n_sizes) continue;
-            const uint32_t ks = ksz[z];
-            const uint32_t cp = (wcp[z] >> shpz[z]) & 0xFFFFu, cs = (wcs[z] >> shsz[z]) & 0xFFFFu;
-            const uint32_t oldp = (wop[z] >> shpz[z]) & 0xFFFFu, olds = (wos[z] >> shsz[z]) & 0xFFFFu;
+        // ---- exact counts of the entering / leaving k-mer in THIS lane's (largest) window ----------------
+        int32_t cP, cS;
+        {
+            const uint32_t cp = (wcp >> shp) & 0xFFFFu, cs = (wcs >> shs) & 0xFFFFu;
+            const uint32_t oldp = (wop >> shp) & 0xFFFFu, olds = (wos >> shs) & 0xFFFFu;
             // a returned value that differs from the value read: another lane's transition touched that k-mer
-            // (only lanes whose own transition is real take part: the others added 0)
-            uint64_t pendE = __ballot(actEz[z] && oldp != cp), pendL = __ballot(actz[z] && olds != cs);
+            // (only lanes whose own transition is real take part: the others added nothing)
+            uint64_t pendE = __ballot(actE && oldp != cp), pendL = __ballot(actL && olds != cs);
+            // MULTI: a lane without a transition of the largest window (left == right) still feeds its
+            // counts to the smaller windows, and it made no atomic that could notice the other lanes:
+            // its k-mer always goes through the correction loop (one iteration on a homopolymer run)
+            if constexpr (MULTI) pendE |= __ballot(!actE);
             int32_t corrP = 0, corrS = 0;
             if (pendE | pendL) {
-                const uint64_t AE = __ballot(actEz[z]), AL = __ballot(actz[z]);
+                const uint64_t AE = __ballot(actE), AL = __ballot(actL);
                 // (at most 128 distinct k-mers per step; the bound only guards against a runaway wave)
                 for (int it = 0; it < 128 && (pendE | pendL) != 0; it++) {
                     uint32_t x0;
                     if (pendE) x0 = (uint32_t)__builtin_amdgcn_readlane((int)kp, __builtin_ctzll(pendE));
                     else x0 = (uint32_t)__builtin_amdgcn_readlane((int)ks, __builtin_ctzll(pendL));
-                    const uint64_t ME = __ballot(kp == x0) & AE, ML = __ballot(ks == x0) & AL;
+                    const uint64_t eqP = __ballot(kp == x0), eqS = __ballot(ks == x0);
+                    const uint64_t ME = eqP & AE, ML = eqS & AL;
                     // transitions of lower lanes happen before this lane's window
                     const int32_t ne = (int32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(ME >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ME, 0u));
                     const int32_t nl = (int32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(ML >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ML, 0u));
                     corrP = kp == x0 ? ne - nl : corrP;
                     corrS = ks == x0 ? ne - nl : corrS;
-                    pendE &= ~ME;
-                    pendL &= ~ML;
+                    pendE &= ~eqP;
+                    pendL &= ~eqS;
                 }
             }
-            cPz[z] = (int32_t)cp + corrP; cSz[z] = (int32_t)cs + corrS;
+            cP = (int32_t)cp + corrP;
+            cS = (int32_t)cs + corrS;
         }
 
-        // ---- per KFV: close the window whose last k-mer is p ------------------------------------
+        // ---- counts of every window size: dz = c_z[leaving] - 1 - c_z[entering], 0 without a transition ----
+        int32_t dz[NZ];
+        bool az[NZ];                                                  // the transition of size z is real
+        if constexpr (!MULTI) {
+            dz[0] = actL ? cS - 1 - cP : 0; az[0] = actL;
+        } else {
+            const uint32_t ksc = haveL ? ks : NO_KEY;
+            int32_t cR[NZ], accR[NZ];
 #pragma unroll
-        for (int j = 0; j < (MULTI ? KGMA_MAX_GROUP : 1); j++) {
+            for (int z = 0; z < NZ; z++) { cR[z] = cP; accR[z] = 0; }
+            int32_t ycp = cP;
+            uint32_t yks = ksc;
+            for (int u = 1; u <= DW; u++) {                           // lane p-u: its entering count, its leaving k-mer
+                ycp = (int32_t)wave_shr1((uint32_t)ycp, (uint32_t)__builtin_amdgcn_readlane(cP_prev, 64 - u));
+                yks = wave_shr1(yks, (uint32_t)__builtin_amdgcn_readlane((int)ksc_prev, 64 - u));
+#pragma unroll
+                for (int z = 0; z < NZ; z++) {
+                    if (u == dsz[z]) cR[z] = ycp;
+                    if (u <= dsz[z]) accR[z] += yks == rz[z] ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int z = 0; z < NZ; z++) {
+                az[z] = haveL && rz[z] != ks;
+                dz[z] = az[z] ? (cS - accS[z]) - 1 - (cR[z] - accR[z]) : 0;
+            }
+            kp_prev = kp; ksc_prev = ksc; cP_prev = cP;
+        }
+
+        // ---- per KFV: close the window that starts at p - nk + 1 -----------------------------------
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
             if (j >= n_kfv) continue;
             int32_t *st = MULTI ? sState + j * ST_WORDS : st_local;
             const int nkj = MULTI ? gp.nk_of[j] : nk;
-            int zi = 0;
+            int32_t dd = dz[0];
+            bool act = az[0];
             if constexpr (MULTI) {
+                uint32_t zi = (uint32_t)uni((int)((zi_pack >> (2 * j)) & 3u));
+                asm volatile("" : "+s"(zi));
 #pragma unroll
-                for (int z = 1; z < KGMA_MAX_SIZES; z++) zi = (z < n_sizes && gp.sizes[z] == nkj) ? z : zi;
-            }
-            int32_t cP = cPz[0], cS = cSz[0];
-            bool act = actz[0];
-            if constexpr (MULTI) {
+                for (int z = 1; z < KGMA_MAX_SIZES; z++) dd = zi == (uint32_t)z ? dz[z] : dd;
+                if constexpr (GENERIC) {
 #pragma unroll
-                for (int z = 1; z < KGMA_MAX_SIZES; z++) { cP = zi == z ? cPz[z] : cP; cS = zi == z ? cSz[z] : cS; act = zi == z ? actz[z] : act; }
+                    for (int z = 1; z < KGMA_MAX_SIZES; z++) act = zi == (uint32_t)z ? az[z] : act;
+                }
             }
             const int32_t Nj = gp.N[j];
             const int64_t twoN = 2 * (int64_t)Nj;
-            const int32_t Sv = Svj[j], Ss = Ssj[j];
-            const int32_t e = act ? Ss - Sv - Nj * (cS - 1 - cP) : 0;  // GenomeMiner.jl:67-68 times 2kN^2 / 2N
+            // GenomeMiner.jl:67-68 times 2kN^2 / 2N.  Without a transition the two k-mers are equal
+            // (Sl == Sr, dd == 0) except in the warm-up, where there is no leaving k-mer at all.
+            int32_t e = Sl[j] - Sr[j] - Nj * dd;
+            if constexpr (GENERIC) e = act ? e : 0;
 
             if constexpr (GENERIC) {
                 if ((b << 6) < nkj) {                                 // warm-up steps: first-window D
                     const bool wu = p < nkj;
+                    int32_t Sv = Sr[j];                               // S[kp]
+                    if constexpr (MULTI) {
+                        const int32_t *S = TLDS ? sTab + (size_t)j * NB : a.Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
+                        Sv = S[kp];
+                    }
                     const int64_t ssum = wave_sum_i64(wu ? (int64_t)Sv : 0);
                     const int64_t psum = wave_sum_i64(wu ? (int64_t)cP : 0);
                     int64_t sumS = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_SUMHI]) << 32) | (uint32_t)uni(st[ST_SUMLO])) + ssum;
@@ -309,34 +380,39 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
                         if (na > 0x3FFFFFFF) na = 0x3FFFFFFF;
                         if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; na = 0; }
                         if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; na = 0; }
-                        st[ST_TE] = (int32_t)TE64;
+                        h_TE[j] = uni((int32_t)TE64);
                         st[ST_NATT] = (int32_t)na;
+                        if (uni((int32_t)na) != 0) att_mask |= 1u << j;
                     }
                 }
             }
 
-            const int32_t E = wave_incl_scan(e) + uni(st[ST_CARRY]);
-            st[ST_CARRY] = __builtin_amdgcn_readlane(E, 63);
-            const int32_t TE = uni(st[ST_TE]);
-            const int32_t natt = uni(st[ST_NATT]);
-            const int q = p - nkj + 1;                                // window start (local) whose last k-mer is p
+            const int32_t E = wave_incl_scan(e) + h_carry[j];
+            h_carry[j] = __builtin_amdgcn_readlane(E, 63);
+            const int32_t TE = h_TE[j];
+            const int q = p - nk + 1;                                 // window start (local) this transition leads to
             bool tested = true;
             if constexpr (GENERIC) tested = q >= first_test && q < n_valid;
             const bool under = tested && E < TE;
-            double *dist = a.dist[j];
-            if (dist != nullptr && tested) {
-                const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
-                dist[td.dist_base + q] = (double)(D0 + twoN * (int64_t)E) / gp.inv_scale[j];
+            if ((dist_mask >> j) & 1u) {
+                if (tested) {
+                    const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
+                    a.dist[j][td.dist_base + q] = (double)(D0 + twoN * (int64_t)E) / gp.inv_scale[j];
+                }
             }
-            const bool att = natt != 0 && tested && !under && E - TE < natt;
+            bool att = false;
+            uint64_t A = 0;
+            if ((att_mask >> j) & 1u) {                                // (only KFVs whose threshold sits on the distance lattice)
+                att = tested && !under && E - TE < uni(st[ST_NATT]);
+                A = __ballot(att);
+            }
             const uint64_t U = __ballot(under);
-            const uint64_t A = natt != 0 ? __ballot(att) : 0;
-            int in_run = uni(st[ST_INRUN]);
+            int in_run = (int)((inrun_mask >> j) & 1u);
             if ((U | A) == 0 && !in_run) continue;                    // fast path: nothing near the threshold
 
             // ---- a dip touches this step: walk its runs (wave-uniform) ----------------------------
             const int kid = gp.kfv_id[j];
-            const int q0 = (b << 6) - nkj + 1;                        // window of lane 0
+            const int q0 = (b << 6) - nk + 1;                         // window of lane 0
             if (att) {
                 DevRecord rec;
                 rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8);
@@ -384,15 +460,15 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
                     in_run = 1; run_start = q0 + cursor; nmin = 0; minE = 0; argf = argl = run_start;
                 }
             }
-            st[ST_INRUN] = in_run; st[ST_START] = run_start; st[ST_MINE] = minE; st[ST_ARGF] = argf; st[ST_ARGL] = argl;
-            st[ST_NMIN] = nmin;
+            inrun_mask = (inrun_mask & ~(1u << j)) | ((uint32_t)in_run << j);
+            st[ST_START] = run_start; st[ST_MINE] = minE; st[ST_ARGF] = argf; st[ST_ARGL] = argl; st[ST_NMIN] = nmin;
         }
     };
 
     // warm-up steps (some lane still has p < nk), steady steps (every window exists), end steps
     int b_warm = (nk + 63) >> 6;
     if (b_warm > n_blocks) b_warm = n_blocks;
-    int b_tail = n_valid + nk_min - 65;                               // steps b <= b_tail/64 have all windows < n_valid
+    int b_tail = n_valid + nk - 65;                                   // steps b <= b_tail/64 have all windows < n_valid
     b_tail = b_tail >= 0 ? (b_tail >> 6) + 1 : 0;
     if (b_tail < b_warm) b_tail = b_warm;
     if (b_tail > n_blocks) b_tail = n_blocks;
@@ -402,9 +478,11 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
     for (; b < n_blocks; b++) step(b, std::true_type{});
 
     // ---- runs still open at the end of the stream (the host joins them with the next stream's) ----
-    for (int j = 0; j < n_kfv; j++) {
+#pragma unroll
+    for (int j = 0; j < NG; j++) {
+        if (j >= n_kfv) continue;
         int32_t *st = MULTI ? sState + j * ST_WORDS : st_local;
-        if (uni(st[ST_INRUN]) && lane == 0) {
+        if (((inrun_mask >> j) & 1u) && lane == 0) {
             DevRecord rec;
             rec.tile = tile; rec.kind_kfv = REC_RUN | (gp.kfv_id[j] << 8);
             rec.start = st[ST_START]; rec.end = n_valid - 1; rec.minE = st[ST_MINE];
@@ -418,24 +496,29 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
 // ------------------------------------------------------------------------------------------
 // geometry + launch
 // ------------------------------------------------------------------------------------------
-bool stream_tables_in_lds(int k, int n_kfv) { return k <= 6 && (size_t)n_kfv * ((size_t)4 << (2 * k)) <= (size_t)64 << 10; }
-
-static size_t stream_wave_bytes(int k, int n_kfv, int n_sizes)
+static size_t stream_wave_bytes(int k, int n_kfv)
 {
     const size_t NB = (size_t)1 << (2 * k);
-    const bool multi = n_kfv > 1;
-    return NB * 2 * (size_t)(multi ? n_sizes : 1) + (multi ? (size_t)KGMA_MAX_GROUP * ST_WORDS * 4 : 0);
+    return NB * 2 + (n_kfv > 1 ? (size_t)KGMA_MAX_GROUP * ST_WORDS * 4 : 0);
+}
+
+// S tables go to LDS when at least 8 waves (streams) still fit beside them
+bool stream_tables_in_lds(int k, int n_kfv)
+{
+    const size_t tab = (size_t)n_kfv * ((size_t)4 << (2 * k));
+    const size_t budget = ((size_t)160 << 10) - 512;
+    return tab < budget && (budget - tab) / stream_wave_bytes(k, n_kfv) >= 8;
 }
 
 // waves (= streams) per workgroup: as many as the 160 KiB of LDS hold, at most 16
 int stream_waves(int k, int nk, int n_kfv, int n_sizes)
 {
+    (void)nk; (void)n_sizes;
     const size_t tab = stream_tables_in_lds(k, n_kfv) ? (size_t)n_kfv * ((size_t)4 << (2 * k)) : 0;
     const size_t budget = ((size_t)160 << 10) - 512;
-    const size_t per = stream_wave_bytes(k, n_kfv, n_sizes);
-    (void)nk;
+    const size_t per = stream_wave_bytes(k, n_kfv);
     if (tab + per > budget) return 0;
-    size_t w = (budget - tab) / per;
+    const size_t w = (budget - tab) / per;
     return (int)(w > 16 ? 16 : w);
 }
 
@@ -446,7 +529,7 @@ static hipError_t launch_stream_k(const ScanArgs &a, const GroupParams &gp, hipS
     const bool tlds = stream_tables_in_lds(K, gp.n_kfv);
     const int nw = stream_waves(K, gp.nk, gp.n_kfv, gp.n_sizes);
     if (nw < 1) return hipErrorInvalidValue;
-    const size_t lds = (tlds ? (size_t)gp.n_kfv * ((size_t)4 << (2 * K)) : 0) + (size_t)nw * stream_wave_bytes(K, gp.n_kfv, gp.n_sizes);
+    const size_t lds = (tlds ? (size_t)gp.n_kfv * ((size_t)4 << (2 * K)) : 0) + (size_t)nw * stream_wave_bytes(K, gp.n_kfv);
     const unsigned grid = (unsigned)((a.n_tiles + nw - 1) / nw);
 #define KGMA_STREAM_LAUNCH(M, T)                                                                                     \
     {                                                                                                               \

@@ -28,7 +28,7 @@ EXPORTS = [
     "kgma_genome_fetch", "kgma_genome_num_contigs", "kgma_genome_contig_len", "kgma_genome_total_bases",
     "kgma_genome_free", "kgma_genome_repack", "kgma_genome_poke", "kgma_scan", "kgma_scan_device", "kgma_get_hits",
     "kgma_get_dips", "kgma_get_first_window", "kgma_get_dists", "kgma_get_stats", "kgma_stream",
-    "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_header",
+    "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_header", "kgma_scan_kernel_name",
 ]
 
 
@@ -122,6 +122,8 @@ def load():
     L.kgma_host_semiglobal_cigar.argtypes = [C.c_char_p, i64, C.c_char_p, i64, i32, i32, C.c_char_p, i64, P(i64)]
     L.kgma_stream.argtypes = [vp]
     L.kgma_stream.restype = vp
+    L.kgma_scan_kernel_name.argtypes = [vp]
+    L.kgma_scan_kernel_name.restype = C.c_char_p
     _lib = L
     return L
 
@@ -324,3 +326,8 @@ class Context:
     @property
     def stream(self) -> int:
         return int(load().kgma_stream(self._h) or 0)
+
+    def kernel_name(self) -> str:
+        """Device kernel launched by the last scan."""
+        return (load().kgma_scan_kernel_name(self._h) or b"").decode()
+
