@@ -45,6 +45,24 @@ def cpu_baseline(ctx_genome_fetch, refs, length, thr, max_bases=50_818_468, reps
     return n / best / 1e6, n, nh
 
 
+def pmc_traffic(kernel_name, length):
+    """HBM bytes per launch of the scan kernel from the committed rocprofv3 PMC summary of THIS command
+    (FETCH_SIZE x 1 KiB x 2, the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE x 1 KiB); PMC
+    passes cannot run inside the timed process, so the number is only reported when the summary was
+    taken on the same kernel and workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01c_scan_pmc_summary.json")
+    try:
+        with open(path) as f:
+            prof = json.load(f)
+        same = kernel_name.split("<")[0] in prof.get("kernel", "") and str(length) in prof.get("workload", "")
+        if not same:
+            return None, None
+        d = prof["derived"]
+        return round(d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]), "profiles/r01c_scan_pmc_summary.json"
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +146,7 @@ def main():
         value = total_bases * args.steps / elapsed / 1e6
         avg_scan_ms = sum(scan_ms) / len(scan_ms)          # hipEvents on the library's stream
         achieved = ALGO_BYTES_PER_BASE * length / (avg_scan_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(ctx.kernel_name(), length)
         out = {
             "metric": "Mbp scanned/sec (whole node) at k=6, 1 ref cluster", "value": round(value, 1),
             "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -139,13 +158,15 @@ def main():
                        "k": 6, "windowsize": int(refs["ws"]), "n_ref_clusters": 1, "bases_per_gpu": length,
                        "n_hits": len(hits), "n_planted": len(plants), "sharding": "records across GPUs"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": ctx.kernel_name(), "kernel_ms": round(avg_scan_ms, 4),
                          "pack_kernel_ms": round(sum(pack_ms) / len(pack_ms), 4),
                          "algorithmic_bytes": ALGO_BYTES_PER_BASE * length,
                          "scan_only_Gbp_s": round(length / avg_scan_ms / 1e6, 2),
-                         "valu_note": "the binding resource is VALU issue, not HBM: DESIGN.md section 4 "
-                                      "(profiles/ hold the SQ_INSTS_VALU / cycle counts)"},
+                         "valu_note": "the path moves 0.25 B per base: the binding resources are VALU issue and LDS "
+                                      "latency, not HBM (DESIGN.md section 4; profiles/ hold the SQ_INSTS_VALU, "
+                                      "SQ_INSTS_LDS and cycle counts)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             v, n, nh = cpu_baseline(genome.fetch, refs, length, thr)

@@ -969,6 +969,15 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             P = (total_nwin + slots * rounds - 1) / (slots * rounds);
             P = ((P + 63) / 64) * 64;
             P = std::min<int64_t>(std::max<int64_t>(P, KGMA_STREAM_MIN_WINDOWS), KGMA_STREAM_MAX_WINDOWS);
+            // every record ends with a shorter stream: lengthen the streams until they fit the wave slots
+            // again (one stream too many would cost a whole extra round on one CU)
+            auto count_streams = [&](int64_t len) {
+                int64_t n = 0;
+                for (int64_t c = 0; c < nc; c++) n += (ctx->contig_nwin[(size_t)c] + len - 1) / len;
+                return n;
+            };
+            for (int it = 0; it < 64 && P < KGMA_STREAM_MAX_WINDOWS && count_streams(P) > slots * rounds; it++)
+                P = std::min<int64_t>(((P + P / 128 + 63) / 64) * 64, KGMA_STREAM_MAX_WINDOWS);
         } else {
             P = (int64_t)scan_tile_stride_words((int)(maxws - k + 1)) * 32;
         }
