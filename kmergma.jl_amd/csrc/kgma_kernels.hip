@@ -4,9 +4,13 @@
 // (src/GenomeMiner.jl:32-107 ac_gma_testing!, src/OmnGenomeMiner.jl:55-160 Omn_KmerGMA!) and the
 // base encoding they use (src/Consts.jl:22-28 NUCLEOTIDE_BITS, src/Kmers.jl:33-44 kmer_count!).
 //
-// Algorithm (DESIGN.md has the derivation).  The reference keeps a 4^k count table per window
-// and rolls the distance one base at a time; that is a serial chain per stream and the table
-// (8 KiB at k=6) caps a CU at ~20 streams.  Here the same integer quantity
+// This file: ASCII -> bit-plane packing, FASTA ingest, the synthetic-genome generator and the
+// BIT-SLICED scan kernel, used for k >= 7, k <= 4 and launches with several KFVs (the count-table
+// stream kernel for k = 5, 6 lives in kgma_stream.hip; DESIGN.md section 2 has both derivations).
+//
+// The reference keeps a 4^k count table per window and rolls the distance one base at a time.  For
+// long k-mers that table (32 KiB at k=7, 128 KiB at k=8) does not fit a wave's share of the LDS, so
+// here the same integer quantity
 //     D_s = sum_x (S[x] - N c_s[x])^2            (d_s = D_s / (2 k N^2), S = N * refVec)
 // is obtained without any count table.  With n = W-k+1 k-mers per window and K_p the k-mer at p:
 //     D_{s+1} - D_s = 2N [ (S[K_s] - S[K_{s+n}]) - N (fwd_s - back_{s+n}) ]
@@ -20,7 +24,7 @@
 // counters.  Everything is exact integer arithmetic, independent of how the genome is tiled.
 //
 // No MFMA (there is no contraction), no count table, no atomics on the hot path; LDS holds the
-// tile's bit-planes and the (plane-index-permuted) S tables.
+// tile's bit-planes.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -429,3 +429,56 @@ def test_synthetic_generator_matches_host_model(ctx):
                 out.append(b"ACGT"[(z >> (2 * i)) & 3])
         assert g.fetch(c, 1, L) == bytes(out[:L])
     g.free()
+
+
+@pytest.fixture
+def force_kernel(monkeypatch):
+    """KGMA_KERNEL is read at every scan: run the kernel that is NOT the default for the case."""
+    def _force(name):
+        monkeypatch.setenv("KGMA_KERNEL", name)
+    return _force
+
+
+def test_both_kernels_single(ctx, alp_ref, genes, force_kernel):
+    """k=6, one KFV: default is the count-table stream kernel; the bit-sliced kernel must agree."""
+    rng = np.random.default_rng(31)
+    contigs, _ = make_genome(rng, [120000, 289, 5000, 70001], genes, n_plants_per_mb=150)
+    a = bytearray(contigs[0])
+    a[2000:9000] = b"N" * 7000
+    a[20000:20700] = b"ACGT" * 175
+    contigs[0] = bytes(a)
+    _assert_single_parity(ctx, contigs, alp_ref, 30.0)
+    assert ctx.kernel_name().startswith("stream_kernel")
+    force_kernel("bitslice")
+    _assert_single_parity(ctx, contigs, alp_ref, 30.0)
+    assert ctx.kernel_name().startswith("scan_kernel")
+
+
+@pytest.mark.parametrize("k", [5, 6, 7])
+def test_stream_kernel_cluster_mode(ctx, data_dir, genes, k, force_kernel):
+    """Several KFVs / window sizes in the stream kernel (one count table, lane-shifted corrections)."""
+    from kmergma_amd import workloads
+    force_kernel("stream")
+    c = workloads.fixture_clusters(data_dir, k)
+    ws, m = c["ws"], len(c["ws"])
+    rng = np.random.default_rng(40 + k)
+    maxws = max(ws)
+    contigs, _ = make_genome(rng, [maxws + k - 2, maxws + k, 150000, 40000, 7], genes, n_plants_per_mb=150)
+    a = bytearray(contigs[2])
+    a[1000:4000] = b"T" * 3000
+    a[9000:9900] = b"AG" * 450
+    contigs[2] = bytes(a)
+    thr = [37, 33, 38, 34, 28][:m]
+    ctx.set_refs(k, c["KFVs"], ws, thr, c["N"])
+    gen = ctx.genome_from_host(contigs)
+    ctx.scan(gen, _lib.MODE_OMN, 100, 77, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
+    assert ctx.kernel_name().startswith("stream_kernel")
+    hits = ctx.hits()
+    dists = [ctx.dists(j + 1) for j in range(m)]
+    gen.free()
+    T = [orc.int_threshold(t, k, n) for t, n in zip(thr, c["N"])]
+    ohi, oD = orc.omn_scan_int(contigs, c["S"], c["N"], k, ws, T, 100, 77, return_D=True)
+    assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi]
+    assert [h["D"] for h in hits] == [h["D"] for h in ohi]
+    for j in range(m):
+        assert np.array_equal(dists[j], oD[j] / (2.0 * k * c["N"][j] ** 2))
