@@ -33,6 +33,9 @@ hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t s
 int stream_waves(int k, int nk, int n_kfv, int n_sizes);
 hipError_t launch_fasta_count(const uint8_t *raw, int64_t n, uint32_t *counts, hipStream_t st);
 hipError_t launch_gather_ranges(const uint8_t *src, const int64_t *desc, int n, uint8_t *dst, hipStream_t st);
+hipError_t launch_tie_gather(DevRecord *recs, const unsigned int *rec_count, unsigned int rec_cap, const TileDesc *tiles,
+                             const ContigDesc *cd, const uint8_t *ascii, const int64_t *Wtab, uint8_t *aux,
+                             unsigned int *aux_used, unsigned int aux_cap, hipStream_t st);
 hipError_t launch_fasta_scatter(const uint8_t *raw, int64_t n, const int64_t *block_base, const int64_t *rec_start,
                                 const ContigDesc *cd, int n_rec, uint8_t *ascii, hipStream_t st);
 int scan_tile_stride_words(int nk);
@@ -99,6 +102,7 @@ struct kgma_ctx {
     std::vector<KfvInfo> kfv;
     int32_t *d_Stab = nullptr;        // m x 4^k, device index order (first base least significant)
     int32_t *d_StabC = nullptr;       // the same tables in the stream kernel's index order ((hi bits << k) | lo bits)
+    int64_t *d_Wtab = nullptr;        // window size per KFV (tie_gather_kernel)
     // scan scratch
     TileDesc *d_tiles = nullptr; int64_t tiles_cap = 0;
     // one device block: [counters 16 B: rec_count u32 @0, n_att u64 @8][D0: res_d0_slots int64][records]
@@ -116,6 +120,9 @@ struct kgma_ctx {
     std::vector<int64_t> D0;                 // [m][n_tiles] (slot = kfv index)
     std::vector<kgma_dip> dips;
     std::vector<int64_t> dip_argl;           // last window attaining the minimum (parallel to dips)
+    std::vector<int64_t> dip_aux;            // byte offset of the dip's tied-stretch residues in the aux copy, or -1
+    const uint8_t *aux_host = nullptr;       // aux region of the last scan (pinned staging)
+    unsigned int aux_used = 0;
     std::vector<kgma_hit> hits;
     std::vector<int64_t> contig_len;
     int64_t n_dists_per_kfv = 0;
@@ -183,6 +190,16 @@ uint32_t stream_index_of(uint32_t v, int k)
         L |= (code & 1u) << j;
     }
     return (H << k) | L;
+}
+
+// The scan is latency-critical (a chr22-size step is ~0.3 ms): poll the stream instead of sleeping in
+// hipStreamSynchronize (interrupt wake-up costs 10-20 us per synchronisation).
+hipError_t sync_spin(hipStream_t st)
+{
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+    }
 }
 
 // Integer thresholds of one KFV.  thr * 2kN^2 is formed exactly (thr is a dyadic rational); windows
@@ -312,6 +329,7 @@ void kgma_destroy(kgma_ctx *ctx)
     for (double *p : ctx->d_dist) if (p) (void)hipFree(p);
     if (ctx->d_Stab) (void)hipFree(ctx->d_Stab);
     if (ctx->d_StabC) (void)hipFree(ctx->d_StabC);
+    if (ctx->d_Wtab) (void)hipFree(ctx->d_Wtab);
     if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
     if (ctx->d_res) (void)hipFree(ctx->d_res);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -412,6 +430,13 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
                 tab[(size_t)j * (size_t)NB + stream_index_of((uint32_t)v, k)] = (int32_t)kv[(size_t)j].S[(size_t)v];
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_StabC), tab.size() * sizeof(int32_t)));
         HIP_TRY(ctx, hipMemcpy(ctx->d_StabC, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    {
+        std::vector<int64_t> wt((size_t)m);
+        for (int j = 0; j < m; j++) wt[(size_t)j] = kv[(size_t)j].W;
+        if (ctx->d_Wtab) { (void)hipFree(ctx->d_Wtab); ctx->d_Wtab = nullptr; }
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_Wtab), wt.size() * sizeof(int64_t)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_Wtab, wt.data(), wt.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     }
     ctx->k = k;
     ctx->m = m;
@@ -782,6 +807,7 @@ struct Frag {             // one device record in global coordinates
     int64_t argf, argl;
     int64_t nmin;
     bool has_exit;
+    int64_t aux;          // byte offset of the residues under [argf, argl + W) in the aux region, or -1
 };
 
 int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
@@ -803,7 +829,8 @@ int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
         f.minD = D0 + twoN * (int64_t)r.minE;
         f.exitD = D0 + twoN * (int64_t)r.exitE;
         f.argf = td.win0 + r.argf; f.argl = td.win0 + r.argl;
-        f.nmin = r.nmin; f.has_exit = r.has_exit != 0;
+        f.nmin = r.nmin; f.has_exit = (r.has_exit & 1) != 0;
+        f.aux = (r.has_exit >> 1) > 0 ? (int64_t)((r.has_exit >> 1) - 1) * 16 : -1;
         fr.push_back(f);
     }
     std::sort(fr.begin(), fr.end(), [](const Frag &a, const Frag &b) {
@@ -814,6 +841,7 @@ int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
     });
     ctx->dips.clear();
     ctx->dip_argl.clear();
+    ctx->dip_aux.clear();
     int64_t n_tie = 0;
     size_t i = 0;
     const size_t n = fr.size();
@@ -840,8 +868,8 @@ int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
             if (!cur.has_exit && nx < n && fr[nx].kind == REC_RUN && fr[nx].contig == cur.contig && fr[nx].kfv == cur.kfv &&
                 fr[nx].start == cur.end + 1) {
                 const Frag &b = fr[nx];
-                if (b.minD < cur.minD) { cur.minD = b.minD; cur.argf = b.argf; cur.argl = b.argl; cur.nmin = b.nmin; }
-                else if (b.minD == cur.minD) { cur.argl = b.argl; cur.nmin += b.nmin; }
+                if (b.minD < cur.minD) { cur.minD = b.minD; cur.argf = b.argf; cur.argl = b.argl; cur.nmin = b.nmin; cur.aux = b.aux; }
+                else if (b.minD == cur.minD) { cur.argl = b.argl; cur.nmin += b.nmin; cur.aux = -1; }   // tied stretch spans fragments
                 cur.end = b.end; cur.has_exit = b.has_exit; cur.exitD = b.exitD;
                 jx = nx + 1;
             } else break;
@@ -874,6 +902,7 @@ int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
             d.flags |= KGMA_HIT_AT_THRESHOLD;
         ctx->dips.push_back(d);
         ctx->dip_argl.push_back(cur.argl);
+        ctx->dip_aux.push_back(cur.aux);
         i = jx > i ? jx : i + 1;
     }
     ctx->stats.n_dips = (int64_t)ctx->dips.size();
@@ -1054,7 +1083,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         recs = std::max<int64_t>(recs, ctx->rec_cap);
         int64_t cap = 0;
         uint8_t *fresh = nullptr;
-        const int64_t bytes = 16 + d0_slots * 8 + recs * (int64_t)sizeof(DevRecord);
+        const int64_t bytes = 16 + d0_slots * 8 + KGMA_AUX_BYTES + recs * (int64_t)sizeof(DevRecord);
         int r2 = dev_reserve(ctx, fresh, cap, bytes);
         if (r2) return r2;
         if (ctx->d_res) { (void)hipFree(ctx->d_res); ctx->device_bytes -= ctx->res_bytes; }
@@ -1071,7 +1100,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     // pinned staging: [meta 16 B][D0 n_tiles*m*8][first INLINE_RECS records]
     constexpr size_t INLINE_RECS = 4096;
     const size_t d0_bytes = (size_t)ctx->res_d0_slots * sizeof(int64_t);
-    const size_t pin_need = 16 + d0_bytes + INLINE_RECS * sizeof(DevRecord);
+    const size_t pin_need = 16 + d0_bytes + KGMA_AUX_BYTES + INLINE_RECS * sizeof(DevRecord);
     if (pin_need > ctx->h_pin_cap) {
         if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
         ctx->h_pin = nullptr; ctx->h_pin_cap = 0;
@@ -1081,7 +1110,8 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     unsigned int *h_nrecs = reinterpret_cast<unsigned int *>(ctx->h_pin);
     unsigned long long *h_natt = reinterpret_cast<unsigned long long *>(ctx->h_pin + 8);
     int64_t *h_D0 = reinterpret_cast<int64_t *>(ctx->h_pin + 16);
-    DevRecord *h_recs = reinterpret_cast<DevRecord *>(ctx->h_pin + 16 + d0_bytes);
+    const uint8_t *h_aux = ctx->h_pin + 16 + d0_bytes;
+    DevRecord *h_recs = reinterpret_cast<DevRecord *>(ctx->h_pin + 16 + d0_bytes + KGMA_AUX_BYTES);
 
     if (!tiles_cached) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tiles, ctx->tiles.data(), (size_t)n_tiles * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
@@ -1093,7 +1123,8 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     for (int attempt = 0;; attempt++) {
         uint8_t *d_cnt = ctx->d_res;
         int64_t *d_D0 = reinterpret_cast<int64_t *>(ctx->d_res + 16);
-        DevRecord *d_recs = reinterpret_cast<DevRecord *>(ctx->d_res + 16 + ctx->res_d0_slots * 8);
+        uint8_t *d_aux = ctx->d_res + 16 + ctx->res_d0_slots * 8;
+        DevRecord *d_recs = reinterpret_cast<DevRecord *>(d_aux + KGMA_AUX_BYTES);
         HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 16, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         ctx->stats.n_launches = 0;
@@ -1135,13 +1166,19 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             ctx->stats.n_launches++;
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        // residues under tied minima, gathered on the device behind the scan (spares the host a second
+        // round trip for the Float64 tie replay); skipped when the caller wants pure exact arithmetic
+        if (!(flags & KGMA_F_NO_TIE_RESOLVE))
+            HIP_TRY(ctx, launch_tie_gather(d_recs, reinterpret_cast<unsigned int *>(d_cnt), ctx->rec_cap, ctx->d_tiles, g->d_cd,
+                                           g->d_ascii, ctx->d_Wtab, d_aux, reinterpret_cast<unsigned int *>(d_cnt + 4),
+                                           (unsigned int)KGMA_AUX_BYTES, ctx->stream));
         // everything the host needs comes back behind ONE synchronisation (records beyond the
         // inline block need a second copy; that only happens for dip-dense inputs)
         // (the host mirror has the same layout: counters | D0 slots | records)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_res,
-                                    16 + (size_t)ctx->res_d0_slots * 8 + std::min<size_t>(INLINE_RECS, ctx->rec_cap) * sizeof(DevRecord),
+                                    16 + (size_t)ctx->res_d0_slots * 8 + KGMA_AUX_BYTES + std::min<size_t>(INLINE_RECS, ctx->rec_cap) * sizeof(DevRecord),
                                     hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, sync_spin(ctx->stream));
         if (g->pack_pending) {
             float pms = 0;
             (void)hipEventElapsedTime(&pms, ctx->evp0, ctx->evp1);
@@ -1165,10 +1202,12 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     if (n_inline) memcpy(recs.data(), h_recs, n_inline * sizeof(DevRecord));
     if (n_recs > n_inline)
         HIP_TRY(ctx, hipMemcpy(recs.data() + n_inline,
-                               reinterpret_cast<DevRecord *>(ctx->d_res + 16 + ctx->res_d0_slots * 8) + n_inline,
+                               reinterpret_cast<DevRecord *>(ctx->d_res + 16 + ctx->res_d0_slots * 8 + KGMA_AUX_BYTES) + n_inline,
                                ((size_t)n_recs - n_inline) * sizeof(DevRecord), hipMemcpyDeviceToHost));
     ctx->D0.assign(h_D0, h_D0 + (size_t)n_tiles * (size_t)ctx->m);
     ctx->stats.n_at_threshold = (int64_t)*h_natt;
+    ctx->aux_host = h_aux;
+    ctx->aux_used = *reinterpret_cast<const unsigned int *>(ctx->h_pin + 4);
     ctx->have_dists = want_dists;
     rc = stitch_dips(ctx, recs);
     if (rc) return rc;
@@ -1214,6 +1253,7 @@ struct TieResolver {
     std::vector<uint8_t> seqbuf;
     const uint8_t *pre = nullptr;        // residues under the tied stretch of every TIE-flagged dip (one gather)
     std::vector<int64_t> pre_off;        // per dip: offset into `pre`, or -1
+    std::vector<const uint8_t *> pre_ptr; // per dip: residues gathered on the device behind the scan, or nullptr
     static constexpr int64_t MAX_SPAN = 1 << 22;
     static constexpr int64_t MAX_PREFETCH = (int64_t)256 << 20;
 
@@ -1224,6 +1264,7 @@ struct TieResolver {
         pre_off.assign(nd, -1);
         std::vector<int64_t> desc;
         int64_t total = 0;
+        pre_ptr.assign(nd, nullptr);
         for (size_t i = 0; i < nd; i++) {
             const kgma_dip &d = ctx->dips[i];
             if (!(d.flags & KGMA_HIT_TIE)) continue;
@@ -1231,7 +1272,14 @@ struct TieResolver {
             const int64_t span = ctx->dip_argl[i] - d.argmin;
             if (d.argmin < 1 || span < 0 || span > MAX_SPAN) continue;
             const int64_t nb = span + W;
-            if (d.argmin - 1 + nb > g->cd[(size_t)d.contig].len || total + nb > MAX_PREFETCH) continue;
+            if (d.argmin - 1 + nb > g->cd[(size_t)d.contig].len) continue;
+            // already gathered on the device behind the scan kernel?
+            const int64_t ax = i < ctx->dip_aux.size() ? ctx->dip_aux[i] : -1;
+            if (ax >= 0 && ctx->aux_host && ax + nb <= (int64_t)KGMA_AUX_BYTES && ax + nb <= (int64_t)((ctx->aux_used + 15u) & ~15u)) {
+                pre_ptr[i] = ctx->aux_host + ax;
+                continue;
+            }
+            if (total + nb > MAX_PREFETCH) continue;
             desc.push_back(g->cd[(size_t)d.contig].ascii_off + (d.argmin - 1));
             desc.push_back(total);
             desc.push_back(nb);
@@ -1258,13 +1306,14 @@ struct TieResolver {
                  launch_gather_ranges(g->d_ascii, reinterpret_cast<const int64_t *>(ctx->d_gath), (int)(desc.size() / 3),
                                       ctx->d_gath + desc_bytes, ctx->stream) == hipSuccess &&
                  hipMemcpyAsync(ctx->h_gath + desc_bytes, ctx->d_gath + desc_bytes, (size_t)total, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-                 hipStreamSynchronize(ctx->stream) == hipSuccess;
+                 sync_spin(ctx->stream) == hipSuccess;
         }
         pre = ok ? ctx->h_gath + desc_bytes : nullptr;
         if (!ok) pre_off.assign(nd, -1);       // replay() falls back to its own copies
     }
     const uint8_t *prefetched(size_t dip_index) const
     {
+        if (dip_index < pre_ptr.size() && pre_ptr[dip_index]) return pre_ptr[dip_index];
         return dip_index < pre_off.size() && pre_off[dip_index] >= 0 && pre ? pre + pre_off[dip_index] : nullptr;
     }
 
@@ -1365,7 +1414,7 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
     if (rc) return rc;
     if (buff < 0) return fail(ctx, KGMA_E_ARG, "buff < 0");
     const bool resolve = !(flags & KGMA_F_NO_TIE_RESOLVE);
-    TieResolver tr{ctx, g, {}, {}, {}, nullptr, {}};
+    TieResolver tr{ctx, g, {}, {}, {}, nullptr, {}, {}};
     if (resolve) tr.prefetch();
     int64_t n_resolved = 0, n_ambiguous = 0;
     const double t0 = now_ms();

@@ -67,7 +67,8 @@ struct DevRecord {
     int32_t argf, argl;   // RUN: first / last local position attaining minE
     int32_t nmin;         // RUN: number of positions attaining minE
     int32_t exitE;        // RUN: E at end+1 when has_exit
-    int32_t has_exit;     // RUN: 1 if end+1 lies inside the same lane span and was evaluated
+    int32_t has_exit;     // RUN: bit 0 = end+1 was evaluated by the same lane/wave (exitE valid);
+                          // bits 1.. = 1 + 16-byte slot of the residues under the tied minimum in the aux region (0: none)
 };
 
 // Arguments of one scan launch (either kernel).
@@ -88,6 +89,10 @@ struct ScanArgs {
 constexpr int KGMA_STREAM_MIN_WINDOWS = 2048;                  // shorter streams waste their warm-up (n k-mers)
 constexpr int KGMA_STREAM_MAX_WINDOWS = 1 << 20;
 constexpr int KGMA_STREAM_MAX_K = 7;                           // 4^k 16-bit counters per wave must fit the LDS
+
+// Aux region of the result block: residues under tied minima, gathered on the device (tie_gather_kernel)
+constexpr int KGMA_AUX_BYTES = 64 << 10;
+constexpr int KGMA_AUX_MAX_RANGE = 4096;                       // longest residue range gathered speculatively
 
 // Per-record info for the pack kernel.
 struct ContigDesc {

@@ -987,6 +987,52 @@ hipError_t launch_gather_ranges(const uint8_t *src, const int64_t *desc, int n, 
     return hipGetLastError();
 }
 
+// Speculative tie gather.  A dip whose minimum is attained by several windows is decided in the
+// reference by Float64 rounding; the host replays that over the residues under the tied stretch
+// (kgma_api.cpp, TieResolver).  To spare the host a second round trip, this kernel runs right behind
+// the scan kernel, looks at the records it produced and copies the residues of every RUN record with
+// nmin > 1 into the aux region of the result block (one wave per record; 16-byte slots).  The slot
+// index + 1 is stored in the record's has_exit word above bit 0.
+__global__ __launch_bounds__(256) void tie_gather_kernel(DevRecord *__restrict__ recs, const unsigned int *__restrict__ rec_count,
+                                                         unsigned int rec_cap, const TileDesc *__restrict__ tiles,
+                                                         const ContigDesc *__restrict__ cd, const uint8_t *__restrict__ ascii,
+                                                         const int64_t *__restrict__ Wtab, uint8_t *__restrict__ aux,
+                                                         unsigned int *__restrict__ aux_used, unsigned int aux_cap)
+{
+    unsigned int n = *rec_count;
+    if (n > rec_cap) n = rec_cap;
+    const int lane = threadIdx.x & 63;
+    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned int i = wave; i < n; i += n_waves) {
+        const DevRecord r = recs[i];
+        if ((r.kind_kfv & 0xFF) != REC_RUN || r.nmin <= 1) continue;
+        const TileDesc td = tiles[r.tile];
+        const ContigDesc c = cd[td.contig];
+        const int64_t W = Wtab[(r.kind_kfv >> 8) - 1];
+        const int64_t a0 = td.win0 + r.argf;                 // 1-based window start = 1-based first residue
+        const int64_t nbytes = (int64_t)(r.argl - r.argf) + W;
+        if (nbytes <= 0 || nbytes > KGMA_AUX_MAX_RANGE || a0 < 1 || a0 - 1 + nbytes > c.len) continue;
+        const unsigned int need = (unsigned int)((nbytes + 15) & ~(int64_t)15);
+        unsigned int slot = 0;
+        if (lane == 0) slot = atomicAdd(aux_used, need);
+        slot = (unsigned int)__builtin_amdgcn_readfirstlane((int)slot);
+        if (slot + need > aux_cap) continue;                 // the host falls back to its own gather
+        const uint8_t *src = ascii + c.ascii_off + (a0 - 1);
+        for (int64_t b = lane; b < nbytes; b += 64) aux[slot + b] = src[b];
+        if (lane == 0) recs[i].has_exit = (r.has_exit & 1) | (int32_t)(((slot >> 4) + 1u) << 1);
+    }
+}
+
+hipError_t launch_tie_gather(DevRecord *recs, const unsigned int *rec_count, unsigned int rec_cap, const TileDesc *tiles,
+                             const ContigDesc *cd, const uint8_t *ascii, const int64_t *Wtab, uint8_t *aux,
+                             unsigned int *aux_used, unsigned int aux_cap, hipStream_t st)
+{
+    hipLaunchKernelGGL(tie_gather_kernel, dim3(64), dim3(256), 0, st, recs, rec_count, rec_cap, tiles, cd, ascii, Wtab, aux,
+                       aux_used, aux_cap);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc *cd, int n_contigs,
                        int64_t total_words, unsigned long long *first_bad, hipStream_t st)
 {
