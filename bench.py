@@ -106,15 +106,17 @@ def main():
     genome, plants = workloads.make_chr22_like(ctx, refs["genes"], seed=22 + rank, length=length)
     scale = 2.0 * 6 * refs["N"] ** 2
 
+    gatherer = None
+    if world > 1:
+        gatherer = parallel.HitGatherer(device=dev if backend == "nccl" else None, capacity=256)
+        gp_advance = parallel.genome_pos_advance([length], True, refs["ws"])
+
     def step():
         genome.repack()                                   # ASCII -> bit-planes (Kmers.jl encoding)
         ctx.scan(genome, _lib.MODE_SINGLE, 50, 0, 0, None)   # scan kernel + dips + hit state machine
         hits = ctx.hits_array()                           # kgma_hit records (numpy view, no per-hit objects)
-        if world > 1:
-            hl = [dict(contig=int(h["contig"]), kfv=int(h["kfv"]), cmi=int(h["cmi"]), lo=int(h["lo"]), hi=int(h["hi"]),
-                       genome_pos=int(h["genome_pos"]), D=int(h["D"]), flags=int(h["flags"])) for h in hits]
-            hits = parallel.gather_hits(hl, rank, parallel.genome_pos_advance([length], True, refs["ws"]),
-                                        lambda kfv: scale, device=dev if backend == "nccl" else None)
+        if world > 1:                                     # one RCCL all_gather of the 64-byte hit records
+            hits = gatherer.gather(hits, rank, gp_advance)
         return hits
 
     def barrier():

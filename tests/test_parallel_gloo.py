@@ -72,3 +72,59 @@ def test_gather_hits_world2_gloo():
     assert [h["cmi"] for h in out] == [10, 77, 5]
     assert abs(out[2]["dist"] - 3000 / 84672.0) < 1e-15
     assert out[1]["flags"] == 1
+
+
+def _worker_fast(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "kmergma.jl_amd"))
+    import torch.distributed as dist
+    from kmergma_amd import parallel as par
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = par.HitGatherer(device=None, capacity=4)
+    outs = []
+    for step in range(3):                       # buffers are reused across steps
+        n = [2, 1][rank] if step != 1 else [0, 3][rank]
+        hits = np.zeros(n, dtype=par.HIT_RECORD_DTYPE)
+        hits["contig"] = np.arange(n)
+        hits["cmi"] = 100 * rank + 10 * step + np.arange(n)
+        hits["genome_pos"] = 7
+        hits["dist"] = 1.5 + rank
+        hits["D"] = 1000 + rank
+        hits["flags"] = rank
+        out = g.gather(hits, [0, 3][rank], [4000, 5100][rank])
+        if rank == 0:
+            outs.append(out.copy())
+        else:
+            assert out is None
+    try:
+        g.gather(np.zeros(5, dtype=par.HIT_RECORD_DTYPE), 0, 0)
+        overflow = False
+    except RuntimeError:
+        overflow = True
+    if rank == 0:
+        q.put((outs, overflow))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hit_gatherer_world2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_fast, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs, overflow = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert overflow
+    a = outs[0]
+    assert list(a["contig"]) == [0, 1, 3] and list(a["cmi"]) == [0, 1, 100]
+    assert list(a["genome_pos"]) == [7, 7, 4007]          # rank 1's records continue after rank 0's 4000 bases
+    assert list(a["dist"]) == [1.5, 1.5, 2.5] and list(a["flags"]) == [0, 0, 1]
+    b = outs[1]                                            # step with 0 hits on rank 0 and 3 on rank 1
+    assert list(b["contig"]) == [3, 4, 5] and list(b["cmi"]) == [110, 111, 112]
+    assert list(outs[2]["cmi"]) == [20, 21, 120]
