@@ -45,22 +45,27 @@ def cpu_baseline(ctx_genome_fetch, refs, length, thr, max_bases=50_818_468, reps
     return n / best / 1e6, n, nh
 
 
-def pmc_traffic(kernel_name, length):
-    """HBM bytes per launch of the scan kernel from the committed rocprofv3 PMC summary of THIS command
-    (FETCH_SIZE x 1 KiB x 2, the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE x 1 KiB); PMC
-    passes cannot run inside the timed process, so the number is only reported when the summary was
-    taken on the same kernel and workload."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01c_scan_pmc_summary.json")
+def pmc_profile(kernel_name, length):
+    """Figures of the committed rocprofv3 PMC summary of THIS command (PMC passes cannot run inside the
+    timed process): HBM bytes per launch of the scan kernel (FETCH_SIZE x 1 KiB x 2, the gfx950 correction
+    of MI355X_MICROARCH.md, + WRITE_SIZE x 1 KiB) and the VALU / LDS occupancy that actually bind the
+    kernel.  Only reported when the summary was taken on the same kernel and workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01d_scan_pmc_summary.json")
     try:
         with open(path) as f:
             prof = json.load(f)
         same = kernel_name.split("<")[0] in prof.get("kernel", "") and str(length) in prof.get("workload", "")
         if not same:
-            return None, None
+            return None, None, None
         d = prof["derived"]
-        return round(d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]), "profiles/r01c_scan_pmc_summary.json"
-    except (OSError, KeyError, ValueError):
-        return None, None
+        extra = {"valu_inst_per_cycle_per_simd": round(d["valu_instructions_per_cycle_per_simd"], 4),
+                 "valu_inst_per_64_windows": round(d["valu_wave_instructions_per_64_windows"], 1),
+                 "lds_inst_per_64_windows": round(d["lds_instructions_per_64_windows"], 2),
+                 "lds_active_frac": round(d["lds_active_fraction_of_kernel"], 4),
+                 "lds_bank_conflict_frac_of_lds_cycles": round(d["lds_bank_conflict_cycles"] / d["lds_active_cycles"], 4)}
+        return round(d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]), "profiles/r01d_scan_pmc_summary.json", extra
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None, None, None
 
 
 def main():
@@ -148,7 +153,7 @@ def main():
         value = total_bases * args.steps / elapsed / 1e6
         avg_scan_ms = sum(scan_ms) / len(scan_ms)          # hipEvents on the library's stream
         achieved = ALGO_BYTES_PER_BASE * length / (avg_scan_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(ctx.kernel_name(), length)
+        traffic, traffic_src, pmc_extra = pmc_profile(ctx.kernel_name(), length)
         out = {
             "metric": "Mbp scanned/sec (whole node) at k=6, 1 ref cluster", "value": round(value, 1),
             "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -161,7 +166,7 @@ def main():
                        "n_hits": len(hits), "n_planted": len(plants), "sharding": "records across GPUs"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "pmc": pmc_extra,
                          "kernel": ctx.kernel_name(), "kernel_ms": round(avg_scan_ms, 4),
                          "pack_kernel_ms": round(sum(pack_ms) / len(pack_ms), 4),
                          "algorithmic_bytes": ALGO_BYTES_PER_BASE * length,
