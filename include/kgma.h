@@ -229,6 +229,20 @@ int kgma_host_semiglobal_cigar(const uint8_t *a, int64_t m, const uint8_t *b, in
                                int32_t gap_open_score, int32_t gap_extend_score, char *cigar,
                                int64_t cigar_cap, int64_t *score_out);
 
+/* ---- scans sharded INSIDE a record (one process per GPU; kmergma_amd.parallel.scan_sharded) ----------
+ * A rank scans its slice of the records with kgma_scan_device, decides the ties that need its residues
+ * (kgma_resolve_ties_local), and ships kgma_get_dips + kgma_get_dip_last_min (+ kgma_get_first_window for
+ * the records whose first window it owns) to rank 0, which translates the dips to whole-record window
+ * coordinates, joins the dips that straddle a slice boundary and runs the reference's hit state machine
+ * (GenomeMiner.jl:82-104 / OmnGenomeMiner.jl:113-156) over them with kgma_replay_dips.  first_D is
+ * [m][n_records] (D of each record's first window, -1 for skipped records); dips must be sorted by
+ * (record, KFV, start).  Hits then come from kgma_get_hits as usual. */
+int kgma_resolve_ties_local(kgma_ctx *ctx, const kgma_genome *genome);
+int kgma_get_dip_last_min(kgma_ctx *ctx, int64_t *out, int64_t cap, int64_t *n);   /* last window attaining each dip's minimum */
+int kgma_replay_dips(kgma_ctx *ctx, int32_t mode, int64_t buff, int64_t genome_pos0, uint32_t flags, int64_t n_records,
+                     const int64_t *record_len, const int64_t *first_D, const kgma_dip *dips, const int64_t *dip_last_min,
+                     int64_t n_dips, kgma_align_fn align, void *align_user);
+
 /* Host stream handle (hipStream_t) the context launches on, for callers that time with hipEvents. */
 void *kgma_stream(kgma_ctx *ctx);
 

@@ -118,6 +118,7 @@ struct kgma_ctx {
     std::vector<int64_t> contig_looked;      // last residue the reference looks up (-1: BoundsError)
     int64_t tk_bases = 0, tk_windows = 0;
     std::vector<int64_t> D0;                 // [m][n_tiles] (slot = kfv index)
+    std::vector<int64_t> firstD;             // [m][records]: D of every record's first window (-1: record skipped)
     std::vector<kgma_dip> dips;
     std::vector<int64_t> dip_argl;           // last window attaining the minimum (parallel to dips)
     std::vector<int64_t> dip_aux;            // byte offset of the dip's tied-stretch residues in the aux copy, or -1
@@ -1069,6 +1070,8 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         rc0 = check_records();
         if (rc0) return rc0;
         ctx->D0.assign((size_t)ctx->m, -1);
+        ctx->firstD.assign((size_t)ctx->m * (size_t)nc, -1);
+        ctx->dips.clear(); ctx->dip_argl.clear(); ctx->dip_aux.clear();
         ctx->last_mode = mode;
         ctx->have_dists = want_dists;
         return KGMA_OK;
@@ -1205,6 +1208,12 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
                                reinterpret_cast<DevRecord *>(ctx->d_res + 16 + ctx->res_d0_slots * 8 + KGMA_AUX_BYTES) + n_inline,
                                ((size_t)n_recs - n_inline) * sizeof(DevRecord), hipMemcpyDeviceToHost));
     ctx->D0.assign(h_D0, h_D0 + (size_t)n_tiles * (size_t)ctx->m);
+    ctx->firstD.assign((size_t)ctx->m * (size_t)nc, -1);
+    for (int j = 0; j < ctx->m; j++)
+        for (int64_t c = 0; c < nc; c++) {
+            const int64_t tb = ctx->contig_tile_base[(size_t)c];
+            if (tb >= 0) ctx->firstD[(size_t)j * (size_t)nc + (size_t)c] = ctx->D0[(size_t)j * (size_t)n_tiles + (size_t)tb];
+        }
     ctx->stats.n_at_threshold = (int64_t)*h_natt;
     ctx->aux_host = h_aux;
     ctx->aux_used = *reinterpret_cast<const unsigned int *>(ctx->h_pin + 4);
@@ -1327,6 +1336,7 @@ struct TieResolver {
                   int64_t Dmin, bool include_start, const uint8_t *residues = nullptr)
     {
         Result r{false, true, false, cand_lo};
+        if (!g) return r;                                   // no residues at hand (dips came from another GPU)
         const KfvInfo &f = ctx->kfv[(size_t)kfv];
         const int k = ctx->k;
         const int64_t NB = (int64_t)1 << (2 * k);
@@ -1407,19 +1417,19 @@ extern "C" {
 // ------------------------------------------------------------------------------------------
 // scan: host replay of the hit state machine over the dips
 // ------------------------------------------------------------------------------------------
-int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, int64_t genome_pos0,
-              uint32_t flags, kgma_align_fn align, void *align_user)
+// The reference's hit state machines (GenomeMiner.jl:82-104, OmnGenomeMiner.jl:113-156) over
+// ctx->dips (sorted by record, KFV, start), ctx->firstD, ctx->contig_len / contig_nwin.  `g` may be
+// NULL (dips gathered from other GPUs: kgma_replay_dips): ties that would need residues then stay flagged.
+static int replay_hits(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, int64_t genome_pos0,
+                       uint32_t flags, kgma_align_fn align, void *align_user)
 {
-    int rc = kgma_scan_device(ctx, g, mode, flags);
-    if (rc) return rc;
     if (buff < 0) return fail(ctx, KGMA_E_ARG, "buff < 0");
     const bool resolve = !(flags & KGMA_F_NO_TIE_RESOLVE);
     TieResolver tr{ctx, g, {}, {}, {}, nullptr, {}, {}};
-    if (resolve) tr.prefetch();
+    if (resolve && g) tr.prefetch();
     int64_t n_resolved = 0, n_ambiguous = 0;
     const double t0 = now_ms();
     const int k = ctx->k;
-    const int64_t n_tiles = (int64_t)ctx->tiles.size();
     ctx->hits.clear();
     const int64_t nc = (int64_t)ctx->contig_len.size();
     size_t di = 0;   // dips are sorted by (contig, kfv, start)
@@ -1431,7 +1441,7 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
         for (int64_t c = 0; c < nc; c++) {
             const int64_t L = ctx->contig_len[(size_t)c];
             if (ctx->contig_nwin[(size_t)c] == 0) continue;            // L < W: :37-39
-            const int64_t D1 = ctx->D0[(size_t)ctx->contig_tile_base[(size_t)c]];
+            const int64_t D1 = ctx->firstD[(size_t)c];
             int64_t CMI = 2, goal_ind = 0, currmin = D1;               // :57
             int64_t currmin_pos = 1;                                   // window whose value currminim holds
             bool stop = true;
@@ -1505,9 +1515,8 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
             while (di < ctx->dips.size() && ctx->dips[di].contig < c) di++;
             if (ctx->contig_nwin[(size_t)c] > 0) {
                 int64_t prev_lo = 0, prev_hi = 0;                      // prev_hit_range = 0:0, :59
-                const int64_t tb = ctx->contig_tile_base[(size_t)c];
                 for (int j = 0; j < m; j++) {                          // :61-82
-                    curr_mins[(size_t)j] = ctx->D0[(size_t)j * (size_t)n_tiles + (size_t)tb];
+                    curr_mins[(size_t)j] = ctx->firstD[(size_t)j * (size_t)nc + (size_t)c];
                     CMIs[(size_t)j] = 1; stops[(size_t)j] = 1; cflags[(size_t)j] = 0; min_pos[(size_t)j] = 1;
                 }
                 evs.clear();
@@ -1587,6 +1596,92 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
     return KGMA_OK;
 }
 
+int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, int64_t genome_pos0,
+              uint32_t flags, kgma_align_fn align, void *align_user)
+{
+    const int rc = kgma_scan_device(ctx, g, mode, flags);
+    if (rc) return rc;
+    return replay_hits(ctx, g, mode, buff, genome_pos0, flags, align, align_user);
+}
+
+// windows a record of L residues contributes (GenomeMiner.jl:37-39,60 / OmnGenomeMiner.jl:89)
+static int64_t record_windows(const kgma_ctx *ctx, int32_t mode, int64_t L)
+{
+    if (mode == KGMA_MODE_SINGLE) {
+        const int64_t W = ctx->kfv[0].W;
+        return L >= W ? L - W + 1 : 0;
+    }
+    int64_t maxws = 0;
+    for (int j = 0; j < ctx->m; j++) maxws = std::max(maxws, ctx->kfv[(size_t)j].W);
+    const int64_t n_iter = L - maxws - ctx->k + 2;
+    return n_iter >= 1 ? n_iter + 1 : 0;
+}
+
+// Ties inside a dip (several windows attain its minimum) do not depend on the hit state machine: they
+// can be decided where the residues are.  Called by a rank before it ships its dips (kgma_replay_dips).
+int kgma_resolve_ties_local(kgma_ctx *ctx, const kgma_genome *g)
+{
+    if (!ctx || !g) return KGMA_E_ARG;
+    if (ctx->last_mode < 0) return fail(ctx, KGMA_E_STATE, "no scan has been run");
+    TieResolver tr{ctx, g, {}, {}, {}, nullptr, {}, {}};
+    tr.prefetch();
+    for (size_t i = 0; i < ctx->dips.size(); i++) {
+        kgma_dip &d = ctx->dips[i];
+        if (!(d.flags & KGMA_HIT_TIE)) continue;
+        const TieResolver::Result r = tr.replay(d.kfv - 1, d.contig, d.argmin, d.D_min, d.argmin, ctx->dip_argl[i], d.D_min, false,
+                                                tr.prefetched(i));
+        if (r.ok && !r.sensitive) {
+            d.argmin = r.pos;
+            d.flags = (d.flags & ~(uint32_t)KGMA_HIT_TIE) | KGMA_HIT_TIE_RESOLVED;
+        }
+    }
+    return KGMA_OK;
+}
+
+int kgma_get_dip_last_min(kgma_ctx *ctx, int64_t *out, int64_t cap, int64_t *n)
+{
+    if (!ctx || !n) return KGMA_E_ARG;
+    *n = (int64_t)ctx->dip_argl.size();
+    if (!out) return KGMA_OK;
+    if (cap < *n) return fail(ctx, KGMA_E_ARG, "kgma_get_dip_last_min: capacity too small");
+    if (*n) memcpy(out, ctx->dip_argl.data(), (size_t)*n * sizeof(int64_t));
+    return KGMA_OK;
+}
+
+// Hit state machine over dips that were found elsewhere (other GPUs of a sharded scan): record lengths,
+// the D of every record's first window per KFV ([m][n_records], -1 for skipped records), and the dips
+// in whole-record coordinates, sorted by (record, KFV, start).  Needs kgma_set_refs only.
+int kgma_replay_dips(kgma_ctx *ctx, int32_t mode, int64_t buff, int64_t genome_pos0, uint32_t flags, int64_t n_records,
+                     const int64_t *record_len, const int64_t *first_D, const kgma_dip *dips, const int64_t *dip_last_min,
+                     int64_t n_dips, kgma_align_fn align, void *align_user)
+{
+    if (!ctx || n_records < 0 || n_dips < 0 || (n_records && (!record_len || !first_D)) || (n_dips && (!dips || !dip_last_min)))
+        return KGMA_E_ARG;
+    if (ctx->m == 0) return fail(ctx, KGMA_E_STATE, "kgma_set_refs has not been called");
+    if (mode != KGMA_MODE_SINGLE && mode != KGMA_MODE_OMN) return fail(ctx, KGMA_E_ARG, "unknown mode %d", mode);
+    ctx->contig_len.assign(record_len, record_len + n_records);
+    ctx->contig_nwin.assign((size_t)n_records, 0);
+    for (int64_t c = 0; c < n_records; c++) ctx->contig_nwin[(size_t)c] = record_windows(ctx, mode, record_len[c]);
+    ctx->firstD.assign(first_D, first_D + (size_t)ctx->m * (size_t)n_records);
+    ctx->dips.assign(dips, dips + n_dips);
+    ctx->dip_argl.assign(dip_last_min, dip_last_min + n_dips);
+    ctx->dip_aux.assign((size_t)n_dips, -1);
+    for (int64_t i = 1; i < n_dips; i++) {
+        const kgma_dip &a = dips[i - 1], &b = dips[i];
+        const bool ordered = a.contig < b.contig || (a.contig == b.contig && (a.kfv < b.kfv || (a.kfv == b.kfv && a.start < b.start)));
+        if (!ordered) return fail(ctx, KGMA_E_ARG, "kgma_replay_dips: dips are not sorted by (record, KFV, start) at %lld", (long long)i);
+    }
+    for (int64_t i = 0; i < n_dips; i++)
+        if (dips[i].contig < 0 || dips[i].contig >= n_records || dips[i].kfv < 1 || dips[i].kfv > ctx->m)
+            return fail(ctx, KGMA_E_ARG, "kgma_replay_dips: dip %lld refers to record %d / KFV %d", (long long)i, dips[i].contig, dips[i].kfv);
+    ctx->tiles.clear();
+    ctx->contig_tile_base.assign((size_t)n_records, -1);
+    ctx->have_dists = false;
+    ctx->last_mode = mode;
+    ctx->stats.n_dips = n_dips;
+    return replay_hits(ctx, nullptr, mode, buff, genome_pos0, flags, align, align_user);
+}
+
 // ------------------------------------------------------------------------------------------
 // results
 // ------------------------------------------------------------------------------------------
@@ -1619,11 +1714,7 @@ int kgma_get_first_window(kgma_ctx *ctx, int32_t kfv, int64_t *out, int64_t cap,
     *n = nc;
     if (!out) return KGMA_OK;
     if (cap < nc) return fail(ctx, KGMA_E_ARG, "kgma_get_first_window: capacity too small");
-    const int64_t n_tiles = (int64_t)ctx->tiles.size();
-    for (int64_t c = 0; c < nc; c++) {
-        const int64_t tb = ctx->contig_tile_base[(size_t)c];
-        out[c] = tb < 0 ? -1 : ctx->D0[(size_t)(kfv - 1) * (size_t)std::max<int64_t>(1, n_tiles) + (size_t)tb];
-    }
+    for (int64_t c = 0; c < nc; c++) out[c] = ctx->firstD[(size_t)(kfv - 1) * (size_t)nc + (size_t)c];
     return KGMA_OK;
 }
 

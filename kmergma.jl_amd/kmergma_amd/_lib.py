@@ -29,6 +29,7 @@ EXPORTS = [
     "kgma_genome_free", "kgma_genome_repack", "kgma_genome_poke", "kgma_scan", "kgma_scan_device", "kgma_get_hits",
     "kgma_get_dips", "kgma_get_first_window", "kgma_get_dists", "kgma_get_stats", "kgma_stream",
     "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_header", "kgma_scan_kernel_name",
+    "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips",
 ]
 
 
@@ -53,6 +54,9 @@ class KgmaStats(C.Structure):
 
 HIT_DTYPE = np.dtype([("contig", "<i4"), ("kfv", "<i4"), ("cmi", "<i8"), ("lo", "<i8"), ("hi", "<i8"),
                       ("genome_pos", "<i8"), ("dist", "<f8"), ("D", "<i8"), ("flags", "<u4"), ("reserved", "<u4")])
+
+DIP_DTYPE = np.dtype([("contig", "<i4"), ("kfv", "<i4"), ("start", "<i8"), ("end", "<i8"), ("argmin", "<i8"),
+                      ("D_min", "<i8"), ("exit_pos", "<i8"), ("D_exit", "<i8"), ("flags", "<u4"), ("reserved", "<u4")])
 
 ALIGN_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                        C.POINTER(C.c_int64), C.POINTER(C.c_int64))
@@ -119,6 +123,9 @@ def load():
     L.kgma_get_first_window.argtypes = [vp, i32, P(i64), i64, P(i64)]
     L.kgma_get_dists.argtypes = [vp, i32, P(dbl), i64, P(i64)]
     L.kgma_get_stats.argtypes = [vp, P(KgmaStats)]
+    L.kgma_resolve_ties_local.argtypes = [vp, vp]
+    L.kgma_get_dip_last_min.argtypes = [vp, P(i64), i64, P(i64)]
+    L.kgma_replay_dips.argtypes = [vp, i32, i64, i64, C.c_uint32, i64, P(i64), P(i64), P(KgmaDip), P(i64), i64, ALIGN_FN, vp]
     L.kgma_host_semiglobal_cigar.argtypes = [C.c_char_p, i64, C.c_char_p, i64, i32, i32, C.c_char_p, i64, P(i64)]
     L.kgma_stream.argtypes = [vp]
     L.kgma_stream.restype = vp
@@ -230,6 +237,7 @@ class Context:
         self._check(load().kgma_set_refs(self._h, k, m, _np_ptr(R, C.c_double), _np_ptr(ws, C.c_int64),
                                          _np_ptr(th, C.c_double), None if nr is None else _np_ptr(nr, C.c_int64)))
         self.k, self.m = k, m
+        self.ws = [int(w) for w in ws]
 
     def set_thresholds(self, thr: Sequence[float]) -> None:
         th = np.asarray(list(thr)[:self.m], dtype=np.float64)
@@ -317,6 +325,43 @@ class Context:
         out = np.zeros(max(n.value, 1), dtype=np.float64)
         self._check(load().kgma_get_dists(self._h, kfv, _np_ptr(out, C.c_double), out.size, C.byref(n)))
         return out[:n.value]
+
+    def dips_array(self) -> np.ndarray:
+        """Dips of the last scan as a numpy structured array (DIP_DTYPE)."""
+        n = C.c_int64(0)
+        self._check(load().kgma_get_dips(self._h, None, 0, C.byref(n)))
+        arr = np.zeros(max(n.value, 1), dtype=DIP_DTYPE)
+        self._check(load().kgma_get_dips(self._h, arr.ctypes.data_as(C.POINTER(KgmaDip)), n.value, C.byref(n)))
+        return arr[:n.value]
+
+    def dip_last_min(self) -> np.ndarray:
+        """Last window attaining the minimum of every dip (parallel to dips_array())."""
+        n = C.c_int64(0)
+        self._check(load().kgma_get_dip_last_min(self._h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.int64)
+        self._check(load().kgma_get_dip_last_min(self._h, _np_ptr(out, C.c_int64), out.size, C.byref(n)))
+        return out[:n.value]
+
+    def resolve_ties_local(self, genome: "Genome") -> None:
+        self._check(load().kgma_resolve_ties_local(self._h, genome._h))
+
+    def replay_dips(self, mode: int, buff: int, genome_pos: int, flags: int, record_len, first_D, dips: np.ndarray,
+                    last_min: np.ndarray, align: Optional[Callable] = None) -> None:
+        """Hit state machine over dips gathered from a sharded scan (kgma_replay_dips); hits() afterwards."""
+        rl = np.ascontiguousarray(record_len, dtype=np.int64)
+        fd = np.ascontiguousarray(first_D, dtype=np.int64).reshape(-1)
+        dd = np.ascontiguousarray(dips, dtype=DIP_DTYPE)
+        lm = np.ascontiguousarray(last_min, dtype=np.int64)
+        if align is None:
+            cb = C.cast(None, ALIGN_FN)
+        else:
+            def tramp(_u, contig, kfv, lo, hi, L, plo, phi):
+                nlo, nhi = align(int(contig), int(kfv), int(lo), int(hi), int(L))
+                plo[0], phi[0] = int(nlo), int(nhi)
+            cb = ALIGN_FN(tramp)
+        self._check(load().kgma_replay_dips(self._h, mode, buff, genome_pos, flags, rl.size, _np_ptr(rl, C.c_int64),
+                                            _np_ptr(fd, C.c_int64), dd.ctypes.data_as(C.POINTER(KgmaDip)),
+                                            _np_ptr(lm, C.c_int64), dd.size, cb, None))
 
     def stats(self) -> dict:
         s = KgmaStats()

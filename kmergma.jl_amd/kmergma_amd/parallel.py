@@ -177,3 +177,167 @@ class HitGatherer:
             parts.append(rec)
             gp_off += adv
         return np.concatenate(parts) if parts else np.zeros(0, dtype=HIT_RECORD_DTYPE)
+
+
+# ------------------------------------------------------------------------------------------------
+# Sharding INSIDE records (balance by bases, not by record).  Windows are
+# independent in exact arithmetic, so a record's windows are cut into slices; consecutive slices share
+# ONE tested window, so every dip that leaves a slice has its exit value, and a dip that reaches the
+# end of a slice continues in the dip that starts the next one.  Ranks ship dips (not hits); rank 0
+# joins them and runs the reference's hit state machine once over whole records (kgma_replay_dips).
+# ------------------------------------------------------------------------------------------------
+def record_windows(L: int, mode_single: bool, windowsizes: Sequence[int], k: int) -> int:
+    """Windows a record contributes (GenomeMiner.jl:37-39,60; OmnGenomeMiner.jl:89)."""
+    if mode_single:
+        W = int(windowsizes[0])
+        return L - W + 1 if L >= W else 0
+    n_iter = L - max(int(w) for w in windowsizes) - k + 2
+    return n_iter + 1 if n_iter >= 1 else 0
+
+
+def plan_slices(lengths: Sequence[int], world: int, mode_single: bool, windowsizes: Sequence[int], k: int,
+                min_windows: int = 4096) -> List[List[Tuple[int, int, int]]]:
+    """Per rank: slices (record, u, v) = windows u..v (1-based window starts) of that record.  A slice's
+    first window is never tested: it is the record's first window (u = 1) or the previous slice's last
+    but one (u = v_prev - 1, so window v_prev is tested by both slices).  Cuts fall every total/world
+    windows; a slice takes at least `min_windows` new windows (>= 2)."""
+    min_windows = max(int(min_windows), 2)
+    nwin = [record_windows(int(L), mode_single, windowsizes, k) for L in lengths]
+    total = sum(nwin)
+    per = max((total + world - 1) // max(world, 1), 1)
+    out: List[List[Tuple[int, int, int]]] = [[] for _ in range(world)]
+    done = 0                                   # windows handed out so far, over all records
+    for c, n in enumerate(nwin):
+        if n == 0:
+            continue                           # skipped record: nobody scans it, the replay still counts its length
+        u, covered = 1, 0
+        while True:
+            rank = min(done // per, world - 1)
+            room = (rank + 1) * per - done
+            remaining = n - covered
+            take = remaining if (rank == world - 1 or remaining <= room + min_windows) else max(room, min_windows)
+            take = min(take, remaining)
+            v = covered + take
+            out[rank].append((c, u, v))
+            done += take
+            covered += take
+            if covered >= n:
+                break
+            u = v - 1
+    return out
+
+
+def slice_bases(u: int, v: int, L: int, mode_single: bool, windowsizes: Sequence[int], k: int) -> Tuple[int, int]:
+    """0-based [begin, end) residues a slice needs so that its local scan evaluates exactly windows u..v."""
+    if mode_single:
+        n = (v - u) + int(windowsizes[0])
+    else:
+        n = (v - u + 1) + max(int(w) for w in windowsizes) + k - 3
+    return u - 1, min(u - 1 + n, L)
+
+
+def local_scan(ctx, records: Sequence[bytes], my_slices: Sequence[Tuple[int, int, int]], mode: int, flags: int = 0) -> dict:
+    """One rank's part: scan the slices, decide local ties, return dips in whole-record coordinates."""
+    from . import _lib
+    mode_single = mode == _lib.MODE_SINGLE
+    ws = [ctx.ws[0]] if mode_single else list(ctx.ws)
+    m = 1 if mode_single else len(ctx.ws)
+    pieces = []
+    for (c, u, v) in my_slices:
+        b, e = slice_bases(u, v, len(records[c]), mode_single, ws, ctx.k)
+        pieces.append(records[c][b:e])
+    payload = dict(slices=list(my_slices), dips=np.zeros(0, dtype=_lib.DIP_DTYPE), last_min=np.zeros(0, dtype=np.int64), first_D={})
+    if not pieces:
+        return payload
+    g = ctx.genome_from_host(pieces)
+    try:
+        ctx.scan_device(g, mode, flags)
+        if not (flags & _lib.F_NO_TIE_RESOLVE):
+            ctx.resolve_ties_local(g)
+        dips = ctx.dips_array().copy()
+        last_min = ctx.dip_last_min().copy()
+        fw = [ctx.first_window(j + 1) for j in range(m)]
+    finally:
+        g.free()
+    off = np.array([u - 1 for (_, u, _) in my_slices], dtype=np.int64)
+    rec = np.array([c for (c, _, _) in my_slices], dtype=np.int32)
+    if dips.size:
+        loc = dips["contig"].astype(np.int64)
+        o = off[loc]
+        for f in ("start", "end", "argmin"):
+            dips[f] += o
+        dips["exit_pos"] = np.where(dips["exit_pos"] != 0, dips["exit_pos"] + o, 0)
+        last_min = last_min + o
+        dips["reserved"] = loc.astype(np.uint32)                     # slice order inside the rank (ties in sorting)
+        dips["contig"] = rec[loc]
+    payload["dips"], payload["last_min"] = dips, last_min
+    for i, (c, u, _) in enumerate(my_slices):
+        if u == 1:
+            payload["first_D"][int(c)] = [int(fw[j][i]) for j in range(m)]
+    return payload
+
+
+def merge_payloads(payloads: Sequence[dict], n_records: int, m: int):
+    """Join the ranks' dips: sort by (record, KFV, start), merge a dip that reaches the end of its slice
+    with the dip that starts the next slice at the shared window.  Returns (dips, last_min, first_D)."""
+    from . import _lib
+    TIE, RESOLVED = _lib.HIT_TIE, _lib.HIT_TIE_RESOLVED
+    dips = np.concatenate([p["dips"] for p in payloads]) if payloads else np.zeros(0, dtype=_lib.DIP_DTYPE)
+    last_min = np.concatenate([p["last_min"] for p in payloads]) if payloads else np.zeros(0, dtype=np.int64)
+    first_D = np.full((m, n_records), -1, dtype=np.int64)
+    for p in payloads:
+        for c, vals in p["first_D"].items():
+            first_D[:, c] = vals
+    if dips.size == 0:
+        return dips, last_min, first_D
+    order = np.lexsort((dips["end"], dips["start"], dips["kfv"], dips["contig"]))
+    dips, last_min = dips[order], last_min[order]
+    out, out_last = [], []
+    cur, cur_last = None, 0
+    for d, lm in zip(dips, last_min):
+        d = d.copy()
+        if (cur is not None and cur["contig"] == d["contig"] and cur["kfv"] == d["kfv"] and cur["exit_pos"] == 0
+                and cur["end"] == d["start"]):
+            # the shared window is under the threshold in both slices: one dip
+            if d["D_min"] < cur["D_min"]:
+                cur["D_min"], cur["argmin"], cur_last = d["D_min"], d["argmin"], lm
+                cur["flags"] = (cur["flags"] & ~np.uint32(TIE | RESOLVED)) | (d["flags"] & np.uint32(TIE | RESOLVED))
+            elif d["D_min"] == cur["D_min"]:
+                single = cur["argmin"] == cur_last == d["argmin"] == lm           # the minimum IS the shared window
+                cur_last = lm
+                if not single:
+                    cur["flags"] = (cur["flags"] & ~np.uint32(RESOLVED)) | np.uint32(TIE)   # tie across a slice boundary
+            cur["flags"] |= d["flags"] & np.uint32(_lib.HIT_AT_THRESHOLD)
+            cur["end"], cur["exit_pos"], cur["D_exit"] = d["end"], d["exit_pos"], d["D_exit"]
+            continue
+        if cur is not None:
+            out.append(cur); out_last.append(cur_last)
+        cur, cur_last = d, lm
+    if cur is not None:
+        out.append(cur); out_last.append(cur_last)
+    merged = np.array(out, dtype=_lib.DIP_DTYPE)
+    merged["reserved"] = 0
+    return merged, np.array(out_last, dtype=np.int64), first_D
+
+
+def scan_sharded(ctx, records: Sequence[bytes], mode: int, buff: int = 50, genome_pos: int = 0, flags: int = 0,
+                 align=None, group=None, min_windows: int = 4096):
+    """findGenes-style scan of `records` sharded over all ranks INSIDE records.  Every rank passes the
+    same records (or at least the residues of its slices); rank 0 returns the hits (list of dicts in
+    the reference's order), the others []."""
+    import torch.distributed as dist
+    from . import _lib
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mode_single = mode == _lib.MODE_SINGLE
+    ws = [ctx.ws[0]] if mode_single else list(ctx.ws)
+    lengths = [len(r) for r in records]
+    plan = plan_slices(lengths, world, mode_single, ws, ctx.k, min_windows)
+    payload = local_scan(ctx, records, plan[rank], mode, flags)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, payload, group=group)
+    if rank != 0:
+        return []
+    m = 1 if mode_single else len(ctx.ws)
+    dips, last_min, first_D = merge_payloads(gathered, len(records), m)
+    ctx.replay_dips(mode, buff, genome_pos, flags, lengths, first_D, dips, last_min, align)
+    return ctx.hits()

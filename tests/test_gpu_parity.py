@@ -482,3 +482,48 @@ def test_stream_kernel_cluster_mode(ctx, data_dir, genes, k, force_kernel):
     assert [h["D"] for h in hits] == [h["D"] for h in ohi]
     for j in range(m):
         assert np.array_equal(dists[j], oD[j] / (2.0 * k * c["N"][j] ** 2))
+
+
+@pytest.mark.parametrize("mode_single", [True, False])
+def test_sharding_inside_records(ctx, alp_ref, alp_clusters, genes, mode_single):
+    """Intra-record sharding (parallel.plan_slices / local_scan / merge_payloads / kgma_replay_dips): the
+    ranks' parts are run one after the other in this process; the joined result must be the unsharded scan."""
+    from kmergma_amd import parallel
+    rng = np.random.default_rng(77)
+    contigs, _ = make_genome(rng, [150000, 300, 52000, 9000], genes, n_plants_per_mb=250)
+    if mode_single:
+        mode, k, ws, thr, N, S, KF = _lib.MODE_SINGLE, alp_ref["k"], [alp_ref["ws"]], [30.0], [alp_ref["N"]], [alp_ref["S"]], [alp_ref["RV"]]
+    else:
+        c = alp_clusters
+        mode, k, ws, thr, N, S, KF = _lib.MODE_OMN, c["k"], c["ws"], [37, 33, 38, 34, 28], c["N"], c["S"], c["KFVs"]
+    ctx.set_refs(k, KF, ws, thr, N)
+    # a gene planted across every cut of the (2, 3, 5)-rank plans: its dip leaves one slice and ends in the next
+    a = bytearray(contigs[0])
+    for world, minw in ((2, 4096), (3, 64), (5, 1000)):
+        for sl in parallel.plan_slices([len(x) for x in contigs], world, mode_single, ws, k, minw):
+            for (c, u, v) in sl:
+                if c == 0 and u > 1:
+                    g0 = genes[(u * 7) % len(genes)]
+                    a[u - 140:u - 140 + len(g0)] = g0
+    contigs[0] = bytes(a)
+    for flags in (_lib.F_NO_TIE_RESOLVE, 0):
+        gen = ctx.genome_from_host(contigs)
+        ctx.scan(gen, mode, 50, 123, flags, None)
+        ref_hits = ctx.hits()
+        gen.free()
+        assert len(ref_hits) > 3
+        for world, minw in ((2, 4096), (3, 64), (5, 1000)):
+            plan = parallel.plan_slices([len(x) for x in contigs], world, mode_single, ws, k, minw)
+            assert sum(len(p) for p in plan) >= 3
+            payloads = [parallel.local_scan(ctx, contigs, plan[r], mode, flags) for r in range(world)]
+            dips, last_min, first_D = parallel.merge_payloads(payloads, len(contigs), len(ws))
+            ctx.replay_dips(mode, 50, 123, flags, [len(x) for x in contigs], first_D, dips, last_min, None)
+            hits = ctx.hits()
+            assert any(d["exit_pos"] == 0 and d["end"] == v for p, sl in zip(payloads, plan) for (c, u, v) in sl
+                       for d in p["dips"] if d["contig"] == c and v < parallel.record_windows(len(contigs[c]), mode_single, ws, k)), \
+                "no dip straddles a slice boundary: the test lost its point"
+            if flags & _lib.F_NO_TIE_RESOLVE:
+                assert [hit_key(h) for h in hits] == [hit_key(h) for h in ref_hits]
+                assert [h["D"] for h in hits] == [h["D"] for h in ref_hits]
+            elif [hit_key(h) for h in hits] != [hit_key(h) for h in ref_hits]:
+                assert any(d["flags"] & _lib.HIT_TIE for d in ctx.dips())      # only a tie across a slice boundary may differ

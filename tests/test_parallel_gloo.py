@@ -128,3 +128,34 @@ def test_hit_gatherer_world2_gloo():
     b = outs[1]                                            # step with 0 hits on rank 0 and 3 on rank 1
     assert list(b["contig"]) == [3, 4, 5] and list(b["cmi"]) == [110, 111, 112]
     assert list(outs[2]["cmi"]) == [20, 21, 120]
+
+
+def test_plan_slices_covers_every_window_once_plus_shared():
+    """Intra-record sharding plan: every tested window belongs to a slice, consecutive slices of a record
+    share exactly one tested window, and the slices' residue ranges stay inside the record."""
+    rng = np.random.default_rng(3)
+    for mode_single, ws in ((True, [289]), (False, [288, 288, 290])):
+        for world in (1, 2, 3, 8):
+            lens = [int(x) for x in rng.integers(50, 400000, size=9)] + [289, 288, 5]
+            plan = parallel.plan_slices(lens, world, mode_single, ws, 6, min_windows=512)
+            assert len(plan) == world
+            per_rec = {}
+            for r, sl in enumerate(plan):
+                for (c, u, v) in sl:
+                    per_rec.setdefault(c, []).append((u, v, r))
+            for c, L in enumerate(lens):
+                n = parallel.record_windows(L, mode_single, ws, 6)
+                if n == 0:
+                    assert c not in per_rec
+                    continue
+                sl = sorted(per_rec[c])
+                assert sl[0][0] == 1 and sl[-1][1] == n
+                for (u0, v0, r0), (u1, v1, r1) in zip(sl, sl[1:]):
+                    assert u1 == v0 - 1 and v1 > v0 and r1 >= r0      # window v0 tested by both, ranks in order
+                for (u, v, _) in sl:
+                    b, e = parallel.slice_bases(u, v, L, mode_single, ws, 6)
+                    assert 0 <= b < e <= L
+                    assert parallel.record_windows(e - b, mode_single, ws, 6) == v - u + 1
+            loads = [sum(v - u for (_, u, v) in sl) for sl in plan]
+            total = sum(parallel.record_windows(L, mode_single, ws, 6) for L in lens)
+            assert max(loads) <= total / world + 2 * 512 + max(1, total // world // 50) + 4096
