@@ -453,6 +453,51 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
 // ------------------------------------------------------------------------------------------
 // genomes
 // ------------------------------------------------------------------------------------------
+// Two pinned staging buffers used alternately: the CPU fills one while the DMA engine drains the other
+// (host bytes -> device at the pace of the slower of memcpy and PCIe instead of their sum).
+struct StagePipe {
+    uint8_t *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int cur = 0;
+    size_t cap = 0;
+    hipStream_t st = nullptr;
+    bool init(size_t cap_, hipStream_t st_)
+    {
+        cap = cap_; st = st_;
+        for (int i = 0; i < 2; i++)
+            if (hipHostMalloc(reinterpret_cast<void **>(&buf[i]), cap, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+        return true;
+    }
+    uint8_t *acquire()                        // buffer to fill next (waits for its previous copy)
+    {
+        if (busy[cur]) { (void)hipEventSynchronize(ev[cur]); busy[cur] = false; }
+        return buf[cur];
+    }
+    hipError_t submit(uint8_t *dst, size_t n) // copy the buffer just filled to the device, switch buffers
+    {
+        hipError_t e = hipMemcpyAsync(dst, buf[cur], n, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(ev[cur], st);
+        busy[cur] = true;
+        cur ^= 1;
+        return e;
+    }
+    void drain()
+    {
+        for (int i = 0; i < 2; i++)
+            if (busy[i]) { (void)hipEventSynchronize(ev[i]); busy[i] = false; }
+    }
+    ~StagePipe()
+    {
+        drain();
+        for (int i = 0; i < 2; i++) {
+            if (buf[i]) (void)hipHostFree(buf[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+        }
+    }
+};
+
 static int genome_layout(kgma_ctx *ctx, kgma_genome *g, const int64_t *contig_len, int64_t n_contigs)
 {
     g->n_contigs = n_contigs;
@@ -522,20 +567,22 @@ int kgma_genome_from_host(kgma_ctx *ctx, const uint8_t *const *contig_ascii, con
     if (!g) return fail(ctx, KGMA_E_NOMEM, "out of host memory");
     int rc = genome_layout(ctx, g, contig_len, n_contigs);
     if (rc != KGMA_OK) { kgma_genome_free(ctx, g); return rc; }
-    // stream the records through a pinned staging buffer
-    const size_t stage_cap = (size_t)64 << 20;
-    uint8_t *stage = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void **>(&stage), stage_cap, hipHostMallocDefault) != hipSuccess) {
+    // stream the records through two pinned staging buffers (fill one while the other is copied)
+    const size_t stage_cap = (size_t)32 << 20;
+    StagePipe pipe;
+    if (!pipe.init(stage_cap, ctx->stream)) {
         kgma_genome_free(ctx, g);
-        return fail(ctx, KGMA_E_NOMEM, "cannot allocate the pinned staging buffer");
+        return fail(ctx, KGMA_E_NOMEM, "cannot allocate the pinned staging buffers");
     }
+    uint8_t *stage = pipe.acquire();
     int64_t win_base = 0;   // device offset of stage[0]
     size_t fill = 0;        // bytes of the window in use
     auto flush = [&]() -> hipError_t {
         if (fill == 0) return hipSuccess;
-        hipError_t e = hipMemcpy(g->d_ascii + win_base, stage, fill, hipMemcpyHostToDevice);
+        hipError_t e = pipe.submit(g->d_ascii + win_base, fill);
         win_base += (int64_t)fill;
         fill = 0;
+        stage = pipe.acquire();
         return e;
     };
     hipError_t he = hipSuccess;
@@ -557,7 +604,7 @@ int kgma_genome_from_host(kgma_ctx *ctx, const uint8_t *const *contig_ascii, con
         }
     }
     if (he == hipSuccess) he = flush();
-    (void)hipHostFree(stage);
+    pipe.drain();
     if (he != hipSuccess) {
         kgma_genome_free(ctx, g);
         return fail(ctx, KGMA_E_HIP, "host-to-device copy failed: %s", hipGetErrorString(he));
@@ -644,15 +691,15 @@ int kgma_genome_from_fasta(kgma_ctx *ctx, const uint8_t *text, int64_t n, kgma_g
     uint8_t *d_raw = nullptr;
     uint32_t *d_counts = nullptr;
     int64_t *d_base = nullptr, *d_rs = nullptr;
-    uint8_t *stage = nullptr;
+    StagePipe pipe;
     kgma_genome *g = nullptr;
     int rc = KGMA_OK;
     auto cleanup = [&]() {
+        pipe.drain();
         if (d_raw) (void)hipFree(d_raw);
         if (d_counts) (void)hipFree(d_counts);
         if (d_base) (void)hipFree(d_base);
         if (d_rs) (void)hipFree(d_rs);
-        if (stage) (void)hipHostFree(stage);
     };
 #define FA_TRY(expr)                                                                              \
     do {                                                                                          \
@@ -666,11 +713,15 @@ int kgma_genome_from_fasta(kgma_ctx *ctx, const uint8_t *text, int64_t n, kgma_g
     } while (0)
     FA_TRY(hipMalloc(reinterpret_cast<void **>(&d_raw), (size_t)n_pad));
     FA_TRY(hipMalloc(reinterpret_cast<void **>(&d_counts), (size_t)std::max<int64_t>(nb, 1) * sizeof(uint32_t)));
-    const size_t stage_cap = (size_t)64 << 20;
-    FA_TRY(hipHostMalloc(reinterpret_cast<void **>(&stage), stage_cap, hipHostMallocDefault));
+    const size_t stage_cap = (size_t)32 << 20;
+    if (!pipe.init(stage_cap, ctx->stream)) {
+        cleanup();
+        return fail(ctx, KGMA_E_NOMEM, "cannot allocate the pinned staging buffers");
+    }
     {
         size_t hi = 0;   // first header that may intersect the current chunk
         for (int64_t off = 0; off < n_pad; off += (int64_t)stage_cap) {
+            uint8_t *stage = pipe.acquire();               // (the other buffer may still be on its way to the device)
             const int64_t len = std::min<int64_t>((int64_t)stage_cap, n_pad - off);
             const int64_t data = std::max<int64_t>(0, std::min<int64_t>(len, n - off));
             if (data) memcpy(stage, text + off, (size_t)data);
@@ -680,7 +731,7 @@ int kgma_genome_from_fasta(kgma_ctx *ctx, const uint8_t *text, int64_t n, kgma_g
                 const int64_t b = std::max<int64_t>(hdrs[h].begin, off), e = std::min<int64_t>(hdrs[h].end, off + len);
                 if (e > b) memset(stage + (b - off), '\n', (size_t)(e - b));
             }
-            FA_TRY(hipMemcpy(d_raw + off, stage, (size_t)len, hipMemcpyHostToDevice));
+            FA_TRY(pipe.submit(d_raw + off, (size_t)len));
         }
     }
     // ---- kernel 1: residues per block; host prefix sum -> block bases --------------------------
