@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-from kmergma_amd import _lib, refprep  # noqa: E402
+from kmergma_amd import _lib, parallel, refprep  # noqa: E402
 from kmergma_amd.fasta import Record  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
@@ -111,6 +111,18 @@ def one_case(ctx, rng, case):
                 assert np.array_equal(dl[j], oD[j] / (2.0 * k * Ns[j] ** 2)), f"dists kfv {j}"
         assert [key(h) for h in hits] == [key(h) for h in ohi], "hits vs integer oracle"
         assert [h["D"] for h in hits] == [h["D"] for h in ohi], "D vs integer oracle"
+        # the same scan sharded INSIDE records (the ranks' parts run one after the other): identical hits
+        if not (mode_single is False and any(len(c) < k - 1 for c in contigs)):
+            world = int(rng.integers(2, 5))
+            minw = int(rng.choice([2, 7, 64, 1000]))
+            mode = _lib.MODE_SINGLE if mode_single else _lib.MODE_OMN
+            plan = parallel.plan_slices([len(c) for c in contigs], world, mode_single, ws if not mode_single else ws[:1], k, minw)
+            payloads = [parallel.local_scan(ctx, contigs, plan[r], mode, _lib.F_NO_TIE_RESOLVE) for r in range(world)]
+            sd, slm, sfd = parallel.merge_payloads(payloads, len(contigs), 1 if mode_single else m)
+            ctx.replay_dips(mode, buff, 0 if mode_single else gp0, _lib.F_NO_TIE_RESOLVE, [len(c) for c in contigs], sfd, sd, slm, None)
+            sh = ctx.hits()
+            assert [key(h) for h in sh] == [key(h) for h in ohi], "sharded hits vs integer oracle"
+            assert [h["D"] for h in sh] == [h["D"] for h in ohi], "sharded D vs integer oracle"
         nflag = 0
         if [key(h) for h in hits_f] != [key(h) for h in ohf]:
             # Float64 rounding decided something exact arithmetic cannot: legitimate only downstream
