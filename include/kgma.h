@@ -243,6 +243,16 @@ int kgma_replay_dips(kgma_ctx *ctx, int32_t mode, int64_t buff, int64_t genome_p
                      const int64_t *record_len, const int64_t *first_D, const kgma_dip *dips, const int64_t *dip_last_min,
                      int64_t n_dips, kgma_align_fn align, void *align_user);
 
+/* Batched re-alignment of hits ON THE DEVICE (single engine; replaces the per-hit
+ * pairalign(SemiGlobalAlignment(), consensus, view(seq, lo:hi), AffineGapScoreModel(EDNAFULL, ...)) +
+ * cigar_to_UnitRange of src/Alignment.jl:13-30,41-46 for hosts without BioAlignments): same algorithm and
+ * tie-breaking as kgma_host_semiglobal_cigar, one wave per hit, segments read from the resident genome.
+ * first_out/last_out receive cigar_to_UnitRange's (first, last); the caller maps them to the record as the
+ * reference does: max(lo + first - 1, 1) : min(lo + last - 1, L).  Segments up to 8191 residues. */
+int kgma_align_hits_device(kgma_ctx *ctx, const kgma_genome *genome, const uint8_t *consensus, int64_t m,
+                           int32_t gap_open_score, int32_t gap_extend_score, int64_t n_hits, const int32_t *contig,
+                           const int64_t *lo, const int64_t *hi, int64_t *first_out, int64_t *last_out, int64_t *score_out);
+
 /* Host stream handle (hipStream_t) the context launches on, for callers that time with hipEvents. */
 void *kgma_stream(kgma_ctx *ctx);
 

@@ -31,6 +31,9 @@ hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int
 hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 int stream_waves(int k, int nk, int n_kfv, int n_sizes);
+int64_t align_trace_bytes(int m, int n);
+hipError_t launch_align(const uint8_t *ascii, const AlignJob *jobs, int n_jobs, const uint8_t *cons, int m, int go, int ge,
+                        uint8_t *trace, int64_t trace_stride, int max_n, int64_t *out, hipStream_t st);
 hipError_t launch_fasta_count(const uint8_t *raw, int64_t n, uint32_t *counts, hipStream_t st);
 hipError_t launch_gather_ranges(const uint8_t *src, const int64_t *desc, int n, uint8_t *dst, hipStream_t st);
 hipError_t launch_tie_gather(DevRecord *recs, const unsigned int *rec_count, unsigned int rec_cap, const TileDesc *tiles,
@@ -342,6 +345,62 @@ void kgma_destroy(kgma_ctx *ctx)
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+// Batched device re-alignment of hits (single engine): see kgma_align.hip
+int kgma_align_hits_device(kgma_ctx *ctx, const kgma_genome *g, const uint8_t *consensus, int64_t m, int32_t gap_open_score,
+                           int32_t gap_extend_score, int64_t n_hits, const int32_t *contig, const int64_t *lo, const int64_t *hi,
+                           int64_t *first_out, int64_t *last_out, int64_t *score_out)
+{
+    if (!ctx || !g) return KGMA_E_ARG;
+    if (n_hits < 0 || !consensus || (n_hits > 0 && (!contig || !lo || !hi || !first_out || !last_out)))
+        return fail(ctx, KGMA_E_ARG, "null argument");
+    if (m < 1 || m > KGMA_ALIGN_MAX_CONSENSUS) return fail(ctx, KGMA_E_UNSUPPORTED, "consensus of %lld residues", (long long)m);
+    if (n_hits == 0) return KGMA_OK;
+    (void)hipSetDevice(ctx->device);
+    std::vector<AlignJob> jobs((size_t)n_hits);
+    int max_n = 1;
+    for (int64_t i = 0; i < n_hits; i++) {
+        if (contig[i] < 0 || contig[i] >= g->n_contigs) return fail(ctx, KGMA_E_ARG, "hit %lld: record %d out of range", (long long)i, contig[i]);
+        const ContigDesc &d = g->cd[(size_t)contig[i]];
+        const int64_t n = hi[i] - lo[i] + 1;
+        if (lo[i] < 1 || hi[i] > d.len || n < 1) return fail(ctx, KGMA_E_ARG, "hit %lld: range %lld:%lld outside the record", (long long)i, (long long)lo[i], (long long)hi[i]);
+        if (n > KGMA_ALIGN_MAX_SEGMENT) return fail(ctx, KGMA_E_UNSUPPORTED, "hit %lld: segment of %lld residues (max %d)", (long long)i, (long long)n, KGMA_ALIGN_MAX_SEGMENT);
+        jobs[(size_t)i].ascii_off = d.ascii_off + (lo[i] - 1);
+        jobs[(size_t)i].n = (int32_t)n;
+        jobs[(size_t)i].pad = 0;
+        max_n = std::max(max_n, (int)n);
+    }
+    const int64_t stride = (align_trace_bytes((int)m, max_n) + 255) & ~(int64_t)255;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n_hits, ((int64_t)1 << 30) / stride));
+    AlignJob *d_jobs = nullptr;
+    uint8_t *d_cons = nullptr, *d_trace = nullptr;
+    int64_t *d_out = nullptr;
+    std::vector<int64_t> out((size_t)n_hits * 4);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_jobs), (size_t)n_hits * sizeof(AlignJob));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_cons), (size_t)m);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_out), (size_t)n_hits * 4 * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_trace), (size_t)(chunk * stride));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_jobs, jobs.data(), (size_t)n_hits * sizeof(AlignJob), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cons, consensus, (size_t)m, hipMemcpyHostToDevice, ctx->stream);
+    for (int64_t b = 0; b < n_hits && e == hipSuccess; b += chunk) {
+        const int nb = (int)std::min<int64_t>(chunk, n_hits - b);
+        e = launch_align(g->d_ascii, d_jobs + b, nb, d_cons, (int)m, -gap_open_score, -gap_extend_score, d_trace, stride, max_n,
+                         d_out + 4 * b, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, (size_t)n_hits * 4 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (d_jobs) (void)hipFree(d_jobs);
+    if (d_cons) (void)hipFree(d_cons);
+    if (d_out) (void)hipFree(d_out);
+    if (d_trace) (void)hipFree(d_trace);
+    if (e != hipSuccess) return fail(ctx, KGMA_E_HIP, "device alignment failed: %s", hipGetErrorString(e));
+    for (int64_t i = 0; i < n_hits; i++) {
+        first_out[i] = out[(size_t)i * 4];
+        last_out[i] = out[(size_t)i * 4 + 1];
+        if (score_out) score_out[i] = out[(size_t)i * 4 + 2];
+    }
+    return KGMA_OK;
 }
 
 void *kgma_stream(kgma_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }

@@ -94,6 +94,15 @@ constexpr int KGMA_STREAM_MAX_K = 7;                           // 4^k 16-bit cou
 constexpr int KGMA_AUX_BYTES = 64 << 10;
 constexpr int KGMA_AUX_MAX_RANGE = 4096;                       // longest residue range gathered speculatively
 
+// One hit to re-align on the device (kgma_align.hip): its segment of the resident residue text.
+struct AlignJob {
+    int64_t ascii_off;    // byte offset of the segment's first residue
+    int32_t n;            // residues
+    int32_t pad;
+};
+constexpr int KGMA_ALIGN_MAX_SEGMENT = 8191;                   // longest segment (LDS rows of the wavefront)
+constexpr int KGMA_ALIGN_MAX_CONSENSUS = 65535;
+
 // Per-record info for the pack kernel.
 struct ContigDesc {
     int64_t ascii_off;    // byte offset of the record's first residue in the ASCII buffer (32-aligned)

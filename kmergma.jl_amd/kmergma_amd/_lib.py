@@ -29,7 +29,7 @@ EXPORTS = [
     "kgma_genome_free", "kgma_genome_repack", "kgma_genome_poke", "kgma_scan", "kgma_scan_device", "kgma_get_hits",
     "kgma_get_dips", "kgma_get_first_window", "kgma_get_dists", "kgma_get_stats", "kgma_stream",
     "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_header", "kgma_scan_kernel_name",
-    "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips",
+    "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips", "kgma_align_hits_device",
 ]
 
 
@@ -124,6 +124,7 @@ def load():
     L.kgma_get_dists.argtypes = [vp, i32, P(dbl), i64, P(i64)]
     L.kgma_get_stats.argtypes = [vp, P(KgmaStats)]
     L.kgma_resolve_ties_local.argtypes = [vp, vp]
+    L.kgma_align_hits_device.argtypes = [vp, vp, C.c_char_p, i64, i32, i32, i64, P(i32), P(i64), P(i64), P(i64), P(i64), P(i64)]
     L.kgma_get_dip_last_min.argtypes = [vp, P(i64), i64, P(i64)]
     L.kgma_replay_dips.argtypes = [vp, i32, i64, i64, C.c_uint32, i64, P(i64), P(i64), P(KgmaDip), P(i64), i64, ALIGN_FN, vp]
     L.kgma_host_semiglobal_cigar.argtypes = [C.c_char_p, i64, C.c_char_p, i64, i32, i32, C.c_char_p, i64, P(i64)]
@@ -362,6 +363,22 @@ class Context:
         self._check(load().kgma_replay_dips(self._h, mode, buff, genome_pos, flags, rl.size, _np_ptr(rl, C.c_int64),
                                             _np_ptr(fd, C.c_int64), dd.ctypes.data_as(C.POINTER(KgmaDip)),
                                             _np_ptr(lm, C.c_int64), dd.size, cb, None))
+
+    def align_hits_device(self, genome: "Genome", consensus: bytes, gap_open: int, gap_extend: int, contig, lo, hi):
+        """Batched semi-global affine re-alignment of hit ranges on the device (kgma_align_hits_device).
+        Returns (first, last, score) arrays: cigar_to_UnitRange's range of every alignment."""
+        c = np.ascontiguousarray(contig, dtype=np.int32)
+        a = np.ascontiguousarray(lo, dtype=np.int64)
+        b = np.ascontiguousarray(hi, dtype=np.int64)
+        n = c.size
+        first = np.zeros(max(n, 1), dtype=np.int64)
+        last = np.zeros(max(n, 1), dtype=np.int64)
+        score = np.zeros(max(n, 1), dtype=np.int64)
+        self._check(load().kgma_align_hits_device(self._h, genome._h, bytes(consensus), len(consensus), int(gap_open), int(gap_extend),
+                                                  n, _np_ptr(c, C.c_int32) if n else None, _np_ptr(a, C.c_int64) if n else None,
+                                                  _np_ptr(b, C.c_int64) if n else None, _np_ptr(first, C.c_int64),
+                                                  _np_ptr(last, C.c_int64), _np_ptr(score, C.c_int64)))
+        return first[:n], last[:n], score[:n]
 
     def stats(self) -> dict:
         s = KgmaStats()

@@ -116,13 +116,25 @@ def ac_gma_testing(*, genome_path, refVec, consensus_refseq: bytes = b"", k: int
     genome = view.genome
     try:
         cb = None
-        if do_align:
+        device_align = do_align and aligner is None and int(windowsize) + 2 * int(buff) <= 8191
+        if do_align and not device_align:
             if aligner is None:
                 from .align import align_range as aligner  # noqa: N813
             cb = _make_align_cb(aligner, view, lambda kfv: consensus_refseq, lambda kfv: int(windowsize),
                                 gap_open_score, gap_extend_score, result_align_vec if do_return_align else None)
         ctx.scan(genome, _lib.MODE_SINGLE, int(buff), 0, _lib.F_RETURN_DISTS if do_return_dists else 0, cb)
-        for h in ctx.hits():
+        hits = ctx.hits()
+        if device_align and hits:
+            # the single engine's alignment does not feed back into the hit state machine
+            # (GenomeMiner.jl:96-99): all hits of the scan are re-aligned in one device batch
+            first, last, _ = ctx.align_hits_device(genome, consensus_refseq[:int(windowsize)], gap_open_score, gap_extend_score,
+                                                   [h["contig"] for h in hits], [h["lo"] for h in hits], [h["hi"] for h in hits])
+            for h, a_first, a_last in zip(hits, first, last):
+                lo, hi, L = h["lo"], h["hi"], genome.contig_len(h["contig"])
+                if do_return_align and result_align_vec is not None:
+                    result_align_vec.append((h["contig"], 0, lo, hi, int(a_first), int(a_last)))
+                h["lo"], h["hi"] = max(1, lo + int(a_first) - 1), min(lo + int(a_last) - 1, L)
+        for h in hits:
             c = h["contig"]
             hdr = headers.single_header(view.identifier(c), h["dist"], h["lo"], h["hi"], h["genome_pos"], with_genome_pos)
             resultVec.append(Record(hdr, view.subseq(c, h["lo"], h["hi"])))

@@ -527,3 +527,47 @@ def test_sharding_inside_records(ctx, alp_ref, alp_clusters, genes, mode_single)
                 assert [h["D"] for h in hits] == [h["D"] for h in ref_hits]
             elif [hit_key(h) for h in hits] != [hit_key(h) for h in ref_hits]:
                 assert any(d["flags"] & _lib.HIT_TIE for d in ctx.dips())      # only a tie across a slice boundary may differ
+
+
+def test_device_alignment_matches_host_aligner(ctx, alp_ref, genes, data_dir):
+    """kgma_align_hits_device (one wave per hit) against kgma_host_semiglobal_cigar + cigar_to_UnitRange:
+    same score, same range, on planted genes with substitutions / insertions / deletions / N, on random
+    segments, on short and long segments, for both gap models the API uses."""
+    from kmergma_amd import align, refprep
+    rng = np.random.default_rng(91)
+    cons = refprep.gen_ref_ws_cons(os.path.join(data_dir, "Alp_V_ref.fasta"), 6)[2][:alp_ref["ws"]]
+    segs = []
+    for t in range(60):
+        g = bytearray(genes[int(rng.integers(0, len(genes)))])
+        for _ in range(int(rng.integers(0, 12))):                       # substitutions, N
+            p = int(rng.integers(0, len(g))); g[p] = b"ACGTN"[int(rng.integers(0, 5))]
+        for _ in range(int(rng.integers(0, 4))):                        # indels
+            p = int(rng.integers(1, len(g) - 1))
+            if rng.random() < 0.5:
+                del g[p:p + int(rng.integers(1, 9))]
+            else:
+                g[p:p] = random_dna(rng, int(rng.integers(1, 9)))
+        left, right = int(rng.integers(0, 120)), int(rng.integers(0, 120))
+        segs.append(random_dna(rng, left) + bytes(g) + random_dna(rng, right))
+    segs += [random_dna(rng, n) for n in (1, 2, 17, 64, 65, 289, 500, 1200)]
+    segs += [bytes(cons), bytes(cons)[10:-10], b"N" * 300, bytes(cons).lower()]
+    contig = b"".join(segs)
+    bounds = np.cumsum([0] + [len(s_) for s_ in segs])
+    g = ctx.genome_from_host([contig, random_dna(rng, 50)])
+    try:
+        for (go, ge) in ((-69, -1), (-200, -1), (-5, -3)):
+            lo = bounds[:-1] + 1
+            hi = bounds[1:]
+            first, last, score = ctx.align_hits_device(g, cons, go, ge, np.zeros(len(segs), dtype=np.int32), lo, hi)
+            for i, sg in enumerate(segs):
+                cig, sc = align.semiglobal_cigar(cons, sg, go, ge)
+                assert int(score[i]) == sc, (i, go, ge)
+                assert (int(first[i]), int(last[i])) == align.cigar_to_UnitRange(cig), (i, go, ge, cig)
+        # consensus longer than one 64-row strip boundary cases and a tiny consensus
+        for cons2 in (cons[:64], cons[:65], cons[:1], cons[:128], cons + cons[:100]):
+            first, last, score = ctx.align_hits_device(g, cons2, -69, -1, [0, 0], [bounds[3] + 1, bounds[10] + 1], [bounds[4], bounds[11]])
+            for i, sg in enumerate((segs[3], segs[10])):
+                cig, sc = align.semiglobal_cigar(cons2, sg, -69, -1)
+                assert int(score[i]) == sc and (int(first[i]), int(last[i])) == align.cigar_to_UnitRange(cig)
+    finally:
+        g.free()
