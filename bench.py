@@ -117,9 +117,9 @@ def main():
         gp_advance = parallel.genome_pos_advance([length], True, refs["ws"])
 
     def step():
-        genome.repack()                                   # ASCII -> bit-planes (Kmers.jl encoding)
-        ctx.scan(genome, _lib.MODE_SINGLE, 50, 0, 0, None)   # scan kernel + dips + hit state machine
-        hits = ctx.hits_array()                           # kgma_hit records (numpy view, no per-hit objects)
+        # one library call: ASCII -> bit-planes (Kmers.jl encoding), scan kernel, dips, hit state machine,
+        # kgma_hit records into a numpy buffer (no per-hit objects)
+        hits = ctx.step_hits(genome, _lib.MODE_SINGLE, 50, 0, 0)
         if world > 1:                                     # one RCCL all_gather of the 64-byte hit records
             hits = gatherer.gather(hits, rank, gp_advance)
         return hits

@@ -253,6 +253,12 @@ int kgma_align_hits_device(kgma_ctx *ctx, const kgma_genome *genome, const uint8
                            int32_t gap_open_score, int32_t gap_extend_score, int64_t n_hits, const int32_t *contig,
                            const int64_t *lo, const int64_t *hi, int64_t *first_out, int64_t *last_out, int64_t *score_out);
 
+/* kgma_genome_repack + kgma_scan (no align callback) + kgma_get_hits in one call, for callers that run the
+ * whole step in a loop (bench.py): out must hold `cap` hits; if more were found KGMA_E_ARG is returned and
+ * *n holds the number needed (the scan results stay valid: call kgma_get_hits with a larger buffer). */
+int kgma_repack_scan_hits(kgma_ctx *ctx, kgma_genome *genome, int32_t mode, int64_t buff, int64_t genome_pos0,
+                          uint32_t flags, kgma_hit *out, int64_t cap, int64_t *n);
+
 /* Host stream handle (hipStream_t) the context launches on, for callers that time with hipEvents. */
 void *kgma_stream(kgma_ctx *ctx);
 

@@ -403,6 +403,19 @@ int kgma_align_hits_device(kgma_ctx *ctx, const kgma_genome *g, const uint8_t *c
     return KGMA_OK;
 }
 
+// One findGenes step in one call: re-encode the resident residues (Consts.jl:22-28), scan, replay, and
+// copy the hits out (two-call pattern collapsed: `cap` hits fit or KGMA_E_ARG with *n = needed).
+int kgma_repack_scan_hits(kgma_ctx *ctx, kgma_genome *g, int32_t mode, int64_t buff, int64_t genome_pos0, uint32_t flags,
+                          kgma_hit *out, int64_t cap, int64_t *n)
+{
+    if (!ctx || !g || !n) return KGMA_E_ARG;
+    int rc = kgma_genome_repack(ctx, g);
+    if (rc) return rc;
+    rc = kgma_scan(ctx, g, mode, buff, genome_pos0, flags, nullptr, nullptr);
+    if (rc) return rc;
+    return kgma_get_hits(ctx, out, cap, n);
+}
+
 void *kgma_stream(kgma_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 const char *kgma_scan_kernel_name(const kgma_ctx *ctx) { return ctx ? ctx->kernel_name : ""; }

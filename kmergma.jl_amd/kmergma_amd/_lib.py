@@ -29,7 +29,7 @@ EXPORTS = [
     "kgma_genome_free", "kgma_genome_repack", "kgma_genome_poke", "kgma_scan", "kgma_scan_device", "kgma_get_hits",
     "kgma_get_dips", "kgma_get_first_window", "kgma_get_dists", "kgma_get_stats", "kgma_stream",
     "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_header", "kgma_scan_kernel_name",
-    "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips", "kgma_align_hits_device",
+    "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips", "kgma_align_hits_device", "kgma_repack_scan_hits",
 ]
 
 
@@ -124,6 +124,7 @@ def load():
     L.kgma_get_dists.argtypes = [vp, i32, P(dbl), i64, P(i64)]
     L.kgma_get_stats.argtypes = [vp, P(KgmaStats)]
     L.kgma_resolve_ties_local.argtypes = [vp, vp]
+    L.kgma_repack_scan_hits.argtypes = [vp, vp, i32, i64, i64, C.c_uint32, P(KgmaHit), i64, P(i64)]
     L.kgma_align_hits_device.argtypes = [vp, vp, C.c_char_p, i64, i32, i32, i64, P(i32), P(i64), P(i64), P(i64), P(i64), P(i64)]
     L.kgma_get_dip_last_min.argtypes = [vp, P(i64), i64, P(i64)]
     L.kgma_replay_dips.argtypes = [vp, i32, i64, i64, C.c_uint32, i64, P(i64), P(i64), P(KgmaDip), P(i64), i64, ALIGN_FN, vp]
@@ -379,6 +380,23 @@ class Context:
                                                   _np_ptr(b, C.c_int64) if n else None, _np_ptr(first, C.c_int64),
                                                   _np_ptr(last, C.c_int64), _np_ptr(score, C.c_int64)))
         return first[:n], last[:n], score[:n]
+
+    def step_hits(self, genome: "Genome", mode: int, buff: int = 50, genome_pos: int = 0, flags: int = 0) -> np.ndarray:
+        """repack + scan + hits in ONE library call (kgma_repack_scan_hits); returns the hits as a structured
+        array (a view of a buffer owned by this context and reused by the next call)."""
+        buf = getattr(self, "_step_buf", None)
+        if buf is None:
+            buf = self._step_buf = np.zeros(4096, dtype=HIT_DTYPE)
+            self._step_ptr = buf.ctypes.data_as(C.POINTER(KgmaHit))
+            self._step_n = C.c_int64(0)
+        st = load().kgma_repack_scan_hits(self._h, genome._h, mode, buff, genome_pos, flags, self._step_ptr, buf.size,
+                                          C.byref(self._step_n))
+        if st != 0 and self._step_n.value > buf.size:          # more hits than the buffer holds: grow and fetch
+            buf = self._step_buf = np.zeros(int(self._step_n.value) * 2, dtype=HIT_DTYPE)
+            self._step_ptr = buf.ctypes.data_as(C.POINTER(KgmaHit))
+            st = load().kgma_get_hits(self._h, self._step_ptr, buf.size, C.byref(self._step_n))
+        self._check(st)
+        return buf[:self._step_n.value]
 
     def stats(self) -> dict:
         s = KgmaStats()
