@@ -81,6 +81,7 @@ struct kgma_genome {
     std::vector<std::string> headers;          // FASTA header lines (without '>'), only for genomes built from FASTA text
     unsigned long long *first_bad = nullptr;   // pinned host copy, valid once pack_pending is cleared
     bool pack_pending = false;
+    bool text_dirty = true;      // residue text changed since first_bad was last computed (new genome, poke)
     uint64_t uid = 0;
     uint8_t *d_ascii = nullptr;
     uint32_t *d_planes = nullptr;
@@ -615,14 +616,19 @@ int kgma_genome_repack(kgma_ctx *ctx, kgma_genome *g)
 {
     if (!ctx || !g) return KGMA_E_ARG;
     (void)hipSetDevice(ctx->device);
-    HIP_TRY(ctx, hipMemsetAsync(g->d_first_bad, 0xFF, std::max<size_t>(1, (size_t)g->n_contigs) * 8, ctx->stream));
+    // first_bad (smallest position of a residue outside A/C/G/T/N per record) is a function of the residue
+    // text: re-encoding unchanged text finds the same minima, so the reset and the download of the table
+    // are only queued when the text changed (new genome, kgma_genome_poke)
+    const bool dirty = g->text_dirty;
+    if (dirty) HIP_TRY(ctx, hipMemsetAsync(g->d_first_bad, 0xFF, std::max<size_t>(1, (size_t)g->n_contigs) * 8, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->evp0, ctx->stream));
     if (g->n_contigs > 0)
         HIP_TRY(ctx, launch_pack(g->d_ascii, g->d_planes, g->d_cd, (int)g->n_contigs, g->total_words, g->d_first_bad, ctx->stream));
     else
         HIP_TRY(ctx, hipMemsetAsync(g->d_planes, 0, (size_t)g->total_words * 8, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->evp1, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(g->first_bad, g->d_first_bad, std::max<size_t>(1, (size_t)g->n_contigs) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (dirty) HIP_TRY(ctx, hipMemcpyAsync(g->first_bad, g->d_first_bad, std::max<size_t>(1, (size_t)g->n_contigs) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    g->text_dirty = false;
     g->pack_pending = true;     // completed by the next scan's single synchronisation (or genome_sync)
     return KGMA_OK;
 }
@@ -893,6 +899,7 @@ int kgma_genome_poke(kgma_ctx *ctx, kgma_genome *g, int64_t contig, int64_t pos,
     if (len == 0) return KGMA_OK;
     (void)hipSetDevice(ctx->device);
     HIP_TRY(ctx, hipMemcpy(g->d_ascii + g->cd[(size_t)contig].ascii_off + (pos - 1), bytes, (size_t)len, hipMemcpyHostToDevice));
+    g->text_dirty = true;
     return KGMA_OK;
 }
 
