@@ -111,6 +111,17 @@ def one_case(ctx, rng, case):
                 assert np.array_equal(dl[j], oD[j] / (2.0 * k * Ns[j] ** 2)), f"dists kfv {j}"
         assert [key(h) for h in hits] == [key(h) for h in ohi], "hits vs integer oracle"
         assert [h["D"] for h in hits] == [h["D"] for h in ohi], "D vs integer oracle"
+        nflag = 0
+        if [key(h) for h in hits_f] != [key(h) for h in ohf]:
+            # Float64 rounding decided something exact arithmetic cannot: legitimate only downstream
+            # (same record) of a dip the library flagged as ambiguous (unresolved tie / at threshold).
+            first = next((i for i, (a, b) in enumerate(zip(hits_f, ohf)) if key(a) != key(b)),
+                         min(len(hits_f), len(ohf)))
+            cands = [h for h in (hits_f[first:first + 1] + ohf[first:first + 1])]
+            c0, p0 = min((h["contig"], h["cmi"]) for h in cands)
+            flagged = [d for d in ctx.dips() if d["contig"] == c0 and (d["flags"] & 3) and d["start"] <= p0 + max(ws)]
+            assert flagged or ctx.stats()["n_at_threshold"] > 0, "float oracle: difference with no flagged dip upstream"
+            nflag = 1
         # the same scan sharded INSIDE records (the ranks' parts run one after the other): identical hits
         if not (mode_single is False and any(len(c) < k - 1 for c in contigs)):
             world = int(rng.integers(2, 5))
@@ -123,17 +134,6 @@ def one_case(ctx, rng, case):
             sh = ctx.hits()
             assert [key(h) for h in sh] == [key(h) for h in ohi], "sharded hits vs integer oracle"
             assert [h["D"] for h in sh] == [h["D"] for h in ohi], "sharded D vs integer oracle"
-        nflag = 0
-        if [key(h) for h in hits_f] != [key(h) for h in ohf]:
-            # Float64 rounding decided something exact arithmetic cannot: legitimate only downstream
-            # (same record) of a dip the library flagged as ambiguous (unresolved tie / at threshold).
-            first = next((i for i, (a, b) in enumerate(zip(hits_f, ohf)) if key(a) != key(b)),
-                         min(len(hits_f), len(ohf)))
-            cands = [h for h in (hits_f[first:first + 1] + ohf[first:first + 1])]
-            c0, p0 = min((h["contig"], h["cmi"]) for h in cands)
-            flagged = [d for d in ctx.dips() if d["contig"] == c0 and (d["flags"] & 3) and d["start"] <= p0 + max(ws)]
-            assert flagged or ctx.stats()["n_at_threshold"] > 0, "float oracle: difference with no flagged dip upstream"
-            nflag = 1
         return dict(k=k, m=m, ws=ws, single=mode_single, hits=len(hits), amb=nflag)
     finally:
         gen.free()
