@@ -31,6 +31,8 @@ hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int
 hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 int stream_waves(int k, int nk, int n_kfv, int n_sizes);
+hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
+int pos_tables_per_pass(int k);
 int64_t align_trace_bytes(int m, int n);
 hipError_t launch_align(const uint8_t *ascii, const AlignJob *jobs, int n_jobs, const uint8_t *cons, int m, int go, int ge,
                         uint8_t *trace, int64_t trace_stride, int max_n, int64_t *out, hipStream_t st);
@@ -107,6 +109,7 @@ struct kgma_ctx {
     int32_t *d_Stab = nullptr;        // m x 4^k, device index order (first base least significant)
     int32_t *d_StabC = nullptr;       // the same tables in the stream kernel's index order ((hi bits << k) | lo bits)
     int64_t *d_Wtab = nullptr;        // window size per KFV (tie_gather_kernel)
+    int16_t *d_diff = nullptr; int64_t diff_cap = 0;   // two-kernel cluster path: per-window self-match differences of a tile chunk
     // scan scratch
     TileDesc *d_tiles = nullptr; int64_t tiles_cap = 0;
     // one device block: [counters 16 B: rec_count u32 @0, n_att u64 @8][D0: res_d0_slots int64][records]
@@ -335,6 +338,7 @@ void kgma_destroy(kgma_ctx *ctx)
     if (ctx->d_Stab) (void)hipFree(ctx->d_Stab);
     if (ctx->d_StabC) (void)hipFree(ctx->d_StabC);
     if (ctx->d_Wtab) (void)hipFree(ctx->d_Wtab);
+    if (ctx->d_diff) (void)hipFree(ctx->d_diff);
     if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
     if (ctx->d_res) (void)hipFree(ctx->d_res);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -1079,7 +1083,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     const int64_t nc = g->n_contigs;
     const bool want_dists = (flags & KGMA_F_RETURN_DISTS) != 0;
     const int geom_version = use_stream ? 2 : 1;
-    snprintf(ctx->kernel_name, sizeof ctx->kernel_name, use_stream ? "stream_kernel<%d>" : "scan_kernel<%d>", k);
+    snprintf(ctx->kernel_name, sizeof ctx->kernel_name, use_stream ? "stream_kernel<%d>" : "scan_kernel<%d>", k);   // (+ pos_kernel for multi-KFV groups)
 
     ctx->dips.clear();
     ctx->hits.clear();
@@ -1295,6 +1299,36 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             a.rec_cap = ctx->rec_cap;
             a.n_tiles = (int32_t)n_tiles;
             a.n_att = reinterpret_cast<unsigned long long *>(d_cnt + 8);
+            a.tile0 = 0;
+            a.n_chunk_tiles = (int32_t)n_tiles;
+            a.tile_windows = ctx->tile_windows;
+            // several KFVs, k <= 7: two kernels (match loop -> per-window differences; window pass with the S
+            // tables in LDS), in chunks of tiles so that the difference buffer stays bounded (kgma_pos.hip)
+            // (measured, 400 Mb: k=7 with 8 KFVs 10.5 vs 16.3 ms; at k <= 6 the bit-sliced kernel's own position
+            // phase, with one table at a time in LDS, is faster: 4.8 vs 7.5 ms at 5 KFVs.  KGMA_TWOKERNEL=1/0 forces)
+            bool two_kernels = !use_stream && gr.kfvs.size() >= 2 && k == KGMA_STREAM_MAX_K;
+            if (const char *tk = getenv("KGMA_TWOKERNEL")) two_kernels = !use_stream && gr.kfvs.size() >= 2 && k <= KGMA_STREAM_MAX_K && atoi(tk) != 0;
+            if (two_kernels) {
+                const int64_t P = ctx->tile_windows;
+                const int64_t per_tile = (int64_t)gp.n_sizes * P;                 // int16 elements
+                const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n_tiles, (((int64_t)2 << 30) / 2) / per_tile));
+                rc = dev_reserve(ctx, ctx->d_diff, ctx->diff_cap, chunk * per_tile);
+                if (rc) return rc;
+                const int per_pass = std::max(1, pos_tables_per_pass(k));
+                for (int64_t t0 = 0; t0 < n_tiles; t0 += chunk) {
+                    a.tile0 = (int32_t)t0;
+                    a.n_chunk_tiles = (int32_t)std::min<int64_t>(chunk, n_tiles - t0);
+                    for (int z = 0; z < gp.n_sizes; z++) a.diff[z] = ctx->d_diff + (int64_t)z * chunk * P;
+                    a.Stab = ctx->d_Stab;
+                    HIP_TRY(ctx, launch_scan(a, gp, ctx->stream));
+                    ScanArgs b = a;
+                    b.Stab = ctx->d_StabC;
+                    for (int j0 = 0; j0 < gp.n_kfv; j0 += per_pass)
+                        HIP_TRY(ctx, launch_pos(b, gp, j0, std::min(per_pass, gp.n_kfv - j0), ctx->stream));
+                    ctx->stats.n_launches++;
+                }
+                continue;
+            }
             HIP_TRY(ctx, use_stream ? launch_stream(a, gp, ctx->stream) : launch_scan(a, gp, ctx->stream));
             ctx->stats.n_launches++;
         }

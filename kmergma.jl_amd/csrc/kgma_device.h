@@ -83,6 +83,11 @@ struct ScanArgs {
     int32_t n_tiles;
     double *dist[KGMA_MAX_GROUP];   // per-KFV distance arrays or nullptr
     unsigned long long *n_att;      // stats: tested windows inside the threshold guard band
+    // two-kernel cluster path (kgma_pos.hip): this launch covers tiles [tile0, tile0 + n_chunk_tiles);
+    // diff[z] holds, per window size z of the launch, tile_windows int16 per tile of the chunk
+    int32_t tile0, n_chunk_tiles;
+    int64_t tile_windows;
+    int16_t *diff[KGMA_MAX_SIZES];
 };
 
 // Count-table stream kernel (kgma_stream.hip): one wave per stream of consecutive window starts.

@@ -425,7 +425,9 @@ __device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t *sRed, int t
 // The S tables stay in global memory: the two gathers per window of the position phase are served
 // by L1/L2 (16 KiB per KFV at k=6) as fast as from LDS, without a per-tile copy or LDS footprint.
 // MULTI: the launch holds more than one window size (correction masks, per-size counts).
-template <int K, int R, int NP, bool MULTI>
+// DIFFOUT: kernel A of the two-kernel cluster path (kgma_pos.hip): match loop and first-window D only; the
+// banded self-match difference fwd_q - back_{q+n} of every window is written out as int16 per window size.
+template <int K, int R, int NP, bool MULTI, bool DIFFOUT>
 __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupParams gp)
 {
     constexpr bool HIST = K <= 6;                // first-window D from an LDS histogram (else by pair counting)
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
     const int lane = tid & 63, wave = tid >> 6;
     const int slot = 63 * wave + lane;
     const bool dup = lane == 63 && wave < 3;     // duplicates the next wave's lane 0
-    const int tile = blockIdx.x;
+    const int tile = a.tile0 + (int)blockIdx.x;
     const TileDesc td = a.tiles[tile];
     const int nk = gp.nk;
     const int nblocks = gp.nblocks;
@@ -762,6 +764,48 @@ __global__ __launch_bounds__(KGMA_THREADS) void scan_kernel(ScanArgs a, GroupPar
         interior_w = __ballot(!inside) == 0ull;
     }
 
+    if constexpr (DIFFOUT) {
+        // kernel A of the two-kernel path: the per-window differences of this size go to global memory
+        // (each lane owns 32*R consecutive windows = 64*R contiguous bytes); no position phase here
+        int16_t *dout = a.diff[zi] + (int64_t)(tile - a.tile0) * a.tile_windows;
+        if (!dup) {
+#pragma unroll
+            for (int w = 0; w < R; w++) {
+                const int qw = qa + 32 * w;
+                uint32_t packed[16];
+#pragma unroll
+                for (int b = 0; b < 32; b++) {
+                    int32_t diff;
+                    if (small_w) {                          // wave-uniform: every |difference| < 8
+                        uint32_t v = (dpl[w][0] >> b) & 1u;
+                        v |= ((dpl[w][1] >> b) & 1u) << 1;
+                        v |= ((dpl[w][2] >> b) & 1u) << 2;
+                        const int32_t sg = ((int32_t)(dpl[w][NP] << (31u - b))) >> 31;   // 0 or -1
+                        diff = (int32_t)((uint32_t)(sg << 3) | v);
+                    } else {
+                        uint32_t v = (dpl[w][0] >> b) & 1u;
+#pragma unroll
+                        for (int p = 1; p <= NP; p++) v |= ((dpl[w][p] >> b) & 1u) << p;
+                        diff = ((int32_t)(v << (31 - NP))) >> (31 - NP);
+                    }
+                    if (b & 1) packed[b >> 1] |= (uint32_t)(diff & 0xFFFF) << 16; else packed[b >> 1] = (uint32_t)(diff & 0xFFFF);
+                }
+                if (qw >= 0 && qw + 32 <= n_valid) {
+                    uint4 *o = reinterpret_cast<uint4 *>(dout + qw);
+#pragma unroll
+                    for (int x = 0; x < 4; x++) o[x] = make_uint4(packed[4 * x], packed[4 * x + 1], packed[4 * x + 2], packed[4 * x + 3]);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 32; b++) {
+                        const int q = qw + b;
+                        if (q >= 0 && q < n_valid) dout[q] = (int16_t)((packed[b >> 1] >> (16 * (b & 1))) & 0xFFFFu);
+                    }
+                }
+            }
+        }
+        continue;
+    }
+
     // walks the lane's 32*R positions in order, calling body(q, e_q) with e_q the integer roll
     // delta (D_{q+1}-D_q)/(2N) of KFV slot j
     auto walk = [&](int j, auto small_tag, auto interior_tag, auto &&body) {
@@ -1078,17 +1122,25 @@ static hipError_t launch_scan_kn(const ScanArgs &a, const GroupParams &gp, hipSt
 {
     constexpr int R = KGMA_R;
     const size_t lds = scan_lds_bytes(K, gp.nk, gp.n_kfv, R, NP, gp.nk - gp.nk_min);
-    if (gp.n_sizes > 1) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K, R, NP, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((scan_kernel<K, R, NP, true>), dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
-    } else {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K, R, NP, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((scan_kernel<K, R, NP, false>), dim3((unsigned)a.n_tiles), dim3(KGMA_THREADS), lds, st, a, gp);
+    const bool diffout = a.diff[0] != nullptr;
+    const unsigned grid = (unsigned)(a.n_chunk_tiles > 0 ? a.n_chunk_tiles : a.n_tiles);
+#define KGMA_SCAN_LAUNCH(M, DO)                                                                                    \
+    {                                                                                                              \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<K, R, NP, M, DO>),          \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL((scan_kernel<K, R, NP, M, DO>), dim3(grid), dim3(KGMA_THREADS), lds, st, a, gp);        \
     }
+    if constexpr (K <= 7) {
+        if (diffout) {
+            if (gp.n_sizes > 1) KGMA_SCAN_LAUNCH(true, true) else KGMA_SCAN_LAUNCH(false, true)
+            return hipGetLastError();
+        }
+    } else if (diffout) {
+        return hipErrorInvalidValue;
+    }
+    if (gp.n_sizes > 1) KGMA_SCAN_LAUNCH(true, false) else KGMA_SCAN_LAUNCH(false, false)
+#undef KGMA_SCAN_LAUNCH
     return hipGetLastError();
 }
 

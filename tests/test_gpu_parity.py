@@ -571,3 +571,34 @@ def test_device_alignment_matches_host_aligner(ctx, alp_ref, genes, data_dir):
                 assert int(score[i]) == sc and (int(first[i]), int(last[i])) == align.cigar_to_UnitRange(cig)
     finally:
         g.free()
+
+
+@pytest.mark.parametrize("k,two", [(7, "1"), (6, "1"), (5, "1"), (7, "0")])
+def test_two_kernel_cluster_path(ctx, data_dir, genes, k, two, monkeypatch):
+    """Several KFVs through kernel A (match loop -> per-window differences) + kernel B (window pass with
+    the S tables in LDS), forced on and off, against the integer oracle (hits, D, every distance)."""
+    from kmergma_amd import workloads
+    monkeypatch.setenv("KGMA_KERNEL", "bitslice")
+    monkeypatch.setenv("KGMA_TWOKERNEL", two)
+    c = workloads.fixture_clusters(data_dir, k)
+    ws, m = c["ws"], len(c["ws"])
+    rng = np.random.default_rng(60 + k)
+    maxws = max(ws)
+    contigs, _ = make_genome(rng, [maxws + k - 2, maxws + k, 180000, 33000, 5], genes, n_plants_per_mb=150)
+    a = bytearray(contigs[2])
+    a[1000:4000] = b"G" * 3000
+    a[9000:9900] = b"AT" * 450
+    contigs[2] = bytes(a)
+    thr = [37, 33, 38, 34, 28][:m]
+    ctx.set_refs(k, c["KFVs"], ws, thr, c["N"])
+    gen = ctx.genome_from_host(contigs)
+    ctx.scan(gen, _lib.MODE_OMN, 100, 5, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
+    hits = ctx.hits()
+    dists = [ctx.dists(j + 1) for j in range(m)]
+    gen.free()
+    T = [orc.int_threshold(t, k, n) for t, n in zip(thr, c["N"])]
+    ohi, oD = orc.omn_scan_int(contigs, c["S"], c["N"], k, ws, T, 100, 5, return_D=True)
+    assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi]
+    assert [h["D"] for h in hits] == [h["D"] for h in ohi]
+    for j in range(m):
+        assert np.array_equal(dists[j], oD[j] / (2.0 * k * c["N"][j] ** 2))
