@@ -71,8 +71,8 @@ def main():
         "bases": int(bases), "n_tiles": int(st["n_tiles"]), "n_launches": int(st["n_launches"]),
         "scan_kernels_s": round(kernel_s, 4), "scan_wall_s": round(min(times), 4),
         "Gbp_per_s_kernels": round(bases / kernel_s / 1e9, 2), "Gbp_per_s_wall": round(bases / min(times) / 1e9, 2),
-        "hbm_algorithmic_GBps": round(0.25 * bases * st["n_launches"] / kernel_s / 1e9, 2),
-        "hbm_fraction_of_8TBps": round(0.25 * bases * st["n_launches"] / kernel_s / 8e12, 5),
+        "hbm_algorithmic_GBps": round(0.25 * bases / kernel_s / 1e9, 2),
+        "hbm_fraction_of_8TBps": round(0.25 * bases / kernel_s / 8e12, 5),
         "pack_ms": round(st["pack_ms"], 2), "generate_and_pack_s": round(t_gen, 2),
         "n_hits": int(len(hits)), "n_dips": int(st["n_dips"]), "planted": len(plants), "planted_found": found,
         "device_GB": round(st["device_bytes"] / 1e9, 1),
