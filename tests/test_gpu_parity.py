@@ -584,7 +584,7 @@ def test_two_kernel_cluster_path(ctx, data_dir, genes, k, two, monkeypatch):
     ws, m = c["ws"], len(c["ws"])
     rng = np.random.default_rng(60 + k)
     maxws = max(ws)
-    contigs, _ = make_genome(rng, [maxws + k - 2, maxws + k, 180000, 33000, 5], genes, n_plants_per_mb=150)
+    contigs, _ = make_genome(rng, [maxws + k - 2, maxws + k, 180000, 33000, 8], genes, n_plants_per_mb=150)
     a = bytearray(contigs[2])
     a[1000:4000] = b"G" * 3000
     a[9000:9900] = b"AT" * 450
