@@ -53,9 +53,73 @@ __device__ __forceinline__ void emit_global(const ScanArgs &a, const DevRecord &
 
 }  // namespace
 
+// Dip state of one (tile, KFV): wave-uniform.
+struct RunState { int in_run, run_start, minE, argf, argl, nmin; };
+
+// Everything that happens only when a step touches a dip (or a window inside the threshold guard band).
+// Deliberately NOT inlined: it contains global stores and atomics; kept out of the step loop, the loop
+// has only loads in flight, which complete in order, so the compiler can wait for "all but the N newest"
+// loads (the four-steps-ahead prefetch) instead of draining the memory pipeline every step.
+__device__ __noinline__ RunState dip_step(RunState st, int32_t E, uint64_t U, bool att, int q, int q0, int tile, int kid, int n_valid,
+                                          DevRecord *recs, unsigned int *rec_count, unsigned int rec_cap, unsigned long long *n_att)
+{
+    const int lane = threadIdx.x & 63;
+    auto emit = [&](const DevRecord &r) {
+        const unsigned int idx = atomicAdd(rec_count, 1u);
+        if (idx < rec_cap) recs[idx] = r;
+    };
+    if (att) {
+        DevRecord rec;
+        rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8);
+        rec.start = q; rec.end = q; rec.minE = E;
+        rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
+        emit(rec);
+        atomicAdd(n_att, 1ull);
+    }
+    int cursor = 0;
+    while (cursor < 64) {
+        const uint64_t rem = ~(uint64_t)0 << cursor;
+        if (st.in_run) {
+            const uint64_t nz = ~U & rem;
+            const int end_lane = nz ? __builtin_ctzll(nz) : 64;
+            if (end_lane > cursor) {
+                const bool inseg = lane >= cursor && lane < end_lane;
+                const int32_t segmin = wave_min_i32(inseg ? E : 0x7FFFFFFF);
+                const uint64_t eq = __ballot(inseg && E == segmin);
+                const int fl = __builtin_ctzll(eq), ll2 = 63 - __builtin_clzll(eq), pc = __builtin_popcountll(eq);
+                if (st.nmin == 0 || segmin < st.minE) { st.minE = segmin; st.argf = q0 + fl; st.argl = q0 + ll2; st.nmin = pc; }
+                else if (segmin == st.minE) { st.argl = q0 + ll2; st.nmin += pc; }
+            }
+            if (end_lane < 64) {
+                const int qe = q0 + end_lane;
+                const int32_t exitE = __builtin_amdgcn_readlane(E, end_lane);
+                if (lane == 0) {
+                    DevRecord rec;
+                    rec.tile = tile; rec.kind_kfv = REC_RUN | (kid << 8);
+                    rec.start = st.run_start; rec.end = qe - 1; rec.minE = st.minE;
+                    rec.argf = st.argf; rec.argl = st.argl; rec.nmin = st.nmin;
+                    rec.exitE = exitE; rec.has_exit = qe < n_valid ? 1 : 0;
+                    emit(rec);
+                }
+                st.in_run = 0;
+                cursor = end_lane;
+            } else {
+                cursor = 64;
+            }
+        } else {
+            const uint64_t nu = U & rem;
+            if (!nu) break;
+            cursor = __builtin_ctzll(nu);
+            st.in_run = 1; st.run_start = q0 + cursor; st.nmin = 0; st.minE = 0; st.argf = st.argl = st.run_start;
+        }
+    }
+    return st;
+}
+
 // One workgroup = NW waves sharing the S tables of KFV slots [j0, j0 + nj) of the launch group; wave w of
 // workgroup b walks tiles b*NW + w, + gridDim*NW, ...
-template <int K>
+// DIST: the per-window distances are written too (KGMA_F_RETURN_DISTS): stores in the loop, no deep prefetch
+template <int K, bool DIST>
 __global__ __launch_bounds__(1024) void pos_kernel(ScanArgs a, GroupParams gp, int j0, int nj)
 {
     constexpr int NB = 1 << (2 * K);
@@ -113,9 +177,14 @@ __global__ __launch_bounds__(1024) void pos_kernel(ScanArgs a, GroupParams gp, i
             const int r_word = (lane + nkj) >> 5;
             const uint32_t r_sh = (uint32_t)((lane + nkj) & 31);
             int32_t carry = 0;
-            int in_run = 0, run_start = 0, minE = 0, argf = 0, argl = 0, nmin = 0;
-            // the inputs of a step (plane words, difference) are loaded FOUR steps ahead: a step is ~50
-            // instructions, far shorter than a trip to HBM, and a wave has nothing else to overlap it with
+            RunState st{0, 0, 0, 0, 0, 0};
+            // The inputs of a step (plane words, difference) are loaded FOUR steps ahead: a step is ~50
+            // instructions, far shorter than a trip to HBM, and a wave has nothing else to overlap it with.
+            // That only works while nothing but loads is in flight (loads complete in order, so the compiler
+            // can wait for "all but the N newest"); stores / atomics complete out of order with them and force
+            // a full drain.  Hence two loops: a QUIET loop without any store, left as soon as a step touches a
+            // dip, and a plain loop (no prefetch) that handles the steps around dips and hands back once the
+            // windows are quiet again.
             struct Inputs { uint2 l0, l1, r0, r1; int32_t dq; };
             auto load_inputs = [&](Inputs &I, const int b) {
                 I.l0 = g2[2 * b + e_word]; I.l1 = g2[2 * b + e_word + 1];      // (reads past the tile stay inside the padded arrays)
@@ -123,86 +192,73 @@ __global__ __launch_bounds__(1024) void pos_kernel(ScanArgs a, GroupParams gp, i
                 const int q = (b << 6) + lane;
                 I.dq = q < lim ? (int32_t)diff[q] : 0;
             };
-            Inputs P0, P1, P2, P3;
-            load_inputs(P0, 0); load_inputs(P1, 1); load_inputs(P2, 2); load_inputs(P3, 3);
-            auto step = [&](Inputs &P, const int b) {
+            // prefix sums and threshold masks of step b from its inputs; returns whether the step is quiet
+            auto evaluate = [&](const Inputs &C, const int b, int32_t &E, int32_t &total, uint64_t &U, bool &att) -> bool {
                 const int q = (b << 6) + lane;             // window (local), lane = window
-                const uint2 l0 = P.l0, l1 = P.l1, r0 = P.r0, r1 = P.r1;
-                const int32_t dq = P.dq;
-                load_inputs(P, b + 4);
-                const uint32_t kl = ((__builtin_amdgcn_alignbit(l1.x, l0.x, e_sh) & KM) << K) | (__builtin_amdgcn_alignbit(l1.y, l0.y, e_sh) & KM);
-                const uint32_t kr = ((__builtin_amdgcn_alignbit(r1.x, r0.x, r_sh) & KM) << K) | (__builtin_amdgcn_alignbit(r1.y, r0.y, r_sh) & KM);
-                int32_t e = S[kl] - S[kr] - Nj * dq;
+                const uint32_t kl = ((__builtin_amdgcn_alignbit(C.l1.x, C.l0.x, e_sh) & KM) << K) | (__builtin_amdgcn_alignbit(C.l1.y, C.l0.y, e_sh) & KM);
+                const uint32_t kr = ((__builtin_amdgcn_alignbit(C.r1.x, C.r0.x, r_sh) & KM) << K) | (__builtin_amdgcn_alignbit(C.r1.y, C.r0.y, r_sh) & KM);
+                int32_t e = S[kl] - S[kr] - Nj * C.dq;
                 e = q < lim ? e : 0;
                 const int32_t incl = wave_incl_scan(e);
-                const int32_t E = carry + incl - e;        // prefix BEFORE the window's own transition
-                carry += __builtin_amdgcn_readlane(incl, 63);
+                E = carry + incl - e;                      // prefix BEFORE the window's own transition
+                total = __builtin_amdgcn_readlane(incl, 63);
                 const bool tested = q >= first_test && q < n_valid;
                 const bool under = tested && E < TE;
-                if (dist != nullptr && tested) dist[dist_base + q] = (double)(D0 + twoN * (int64_t)E) / gp.inv_scale[j];
-                const bool att = natt != 0 && tested && !under && E - TE < natt;
-                const uint64_t U = __ballot(under);
+                att = natt != 0 && tested && !under && E - TE < natt;
+                U = __ballot(under);
                 const uint64_t A = natt != 0 ? __ballot(att) : 0;
-                if ((U | A) == 0 && !in_run) return;       // fast path: nothing near the threshold
-
-                const int q0 = b << 6;
-                if (att) {
-                    DevRecord rec;
-                    rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8);
-                    rec.start = q; rec.end = q; rec.minE = E;
-                    rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
-                    emit_global(a, rec);
-                    atomicAdd(a.n_att, 1ull);
-                }
-                int cursor = 0;
-                while (cursor < 64) {
-                    const uint64_t rem = ~(uint64_t)0 << cursor;
-                    if (in_run) {
-                        const uint64_t nz = ~U & rem;
-                        const int end_lane = nz ? __builtin_ctzll(nz) : 64;
-                        if (end_lane > cursor) {
-                            const bool inseg = lane >= cursor && lane < end_lane;
-                            const int32_t segmin = wave_min_i32(inseg ? E : 0x7FFFFFFF);
-                            const uint64_t eq = __ballot(inseg && E == segmin);
-                            const int fl = __builtin_ctzll(eq), ll2 = 63 - __builtin_clzll(eq), pc = __builtin_popcountll(eq);
-                            if (nmin == 0 || segmin < minE) { minE = segmin; argf = q0 + fl; argl = q0 + ll2; nmin = pc; }
-                            else if (segmin == minE) { argl = q0 + ll2; nmin += pc; }
-                        }
-                        if (end_lane < 64) {
-                            const int qe = q0 + end_lane;
-                            const int32_t exitE = __builtin_amdgcn_readlane(E, end_lane);
-                            if (lane == 0) {
-                                DevRecord rec;
-                                rec.tile = tile; rec.kind_kfv = REC_RUN | (kid << 8);
-                                rec.start = run_start; rec.end = qe - 1; rec.minE = minE;
-                                rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
-                                rec.exitE = exitE; rec.has_exit = qe < n_valid ? 1 : 0;
-                                emit_global(a, rec);
-                            }
-                            in_run = 0;
-                            cursor = end_lane;
-                        } else {
-                            cursor = 64;
-                        }
-                    } else {
-                        const uint64_t nu = U & rem;
-                        if (!nu) break;
-                        cursor = __builtin_ctzll(nu);
-                        in_run = 1; run_start = q0 + cursor; nmin = 0; minE = 0; argf = argl = run_start;
-                    }
-                }
+                return (U | A) == 0;
             };
-            for (int b = 0; b < n_steps; b += 4) {
-                step(P0, b);
-                if (b + 1 < n_steps) step(P1, b + 1);
-                if (b + 2 < n_steps) step(P2, b + 2);
-                if (b + 3 < n_steps) step(P3, b + 3);
+            int b = 0;
+            while (b < n_steps) {
+                if (!DIST) {
+                    // ---- quiet loop: loads only -----------------------------------------------------------
+                    Inputs P0, P1, P2, P3;
+                    load_inputs(P0, b); load_inputs(P1, b + 1); load_inputs(P2, b + 2); load_inputs(P3, b + 3);
+                    // groups of four steps, straight-line: every prefetch load is issued unconditionally (steps past
+                    // the tile's end see no tested window and change nothing); a step that touches a dip ends the
+                    // loop with b and carry still at that step
+                    for (;;) {
+                        int32_t E, total; uint64_t U; bool att;
+                        const Inputs C0 = P0; load_inputs(P0, b + 4);
+                        if (!evaluate(C0, b, E, total, U, att)) break;
+                        carry += total;
+                        const Inputs C1 = P1; load_inputs(P1, b + 5);
+                        if (!evaluate(C1, b + 1, E, total, U, att)) { b += 1; break; }
+                        carry += total;
+                        const Inputs C2 = P2; load_inputs(P2, b + 6);
+                        if (!evaluate(C2, b + 2, E, total, U, att)) { b += 2; break; }
+                        carry += total;
+                        const Inputs C3 = P3; load_inputs(P3, b + 7);
+                        if (!evaluate(C3, b + 3, E, total, U, att)) { b += 3; break; }
+                        carry += total;
+                        b += 4;
+                        if (b >= n_steps) break;
+                    }
+                    if (b >= n_steps) break;
+                }
+                // ---- around a dip (or when distances are written): plain steps --------------------------------
+                for (int calm = 0; b < n_steps; b++) {
+                    Inputs C;
+                    load_inputs(C, b);
+                    int32_t E, total; uint64_t U; bool att;
+                    const bool q_ok = evaluate(C, b, E, total, U, att);
+                    carry += total;
+                    if constexpr (DIST) {
+                        const int q = (b << 6) + lane;
+                        if (dist != nullptr && q >= first_test && q < n_valid) dist[dist_base + q] = (double)(D0 + twoN * (int64_t)E) / gp.inv_scale[j];
+                    }
+                    if (!q_ok || st.in_run) {
+                        st = dip_step(st, E, U, att, (b << 6) + lane, b << 6, tile, kid, n_valid, a.recs, a.rec_count, a.rec_cap, a.n_att);
+                        calm = 0;
+                    } else if (!DIST && ++calm >= 2) { b++; break; }   // two quiet steps in a row: back to the prefetching loop
+                }
             }
-            if (in_run && lane == 0) {                     // the run reaches the tile's last window: the host joins it
+            if (st.in_run && lane == 0) {                  // the run reaches the tile's last window: the host joins it
                 DevRecord rec;
                 rec.tile = tile; rec.kind_kfv = REC_RUN | (kid << 8);
-                rec.start = run_start; rec.end = n_valid - 1; rec.minE = minE;
-                rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
+                rec.start = st.run_start; rec.end = n_valid - 1; rec.minE = st.minE;
+                rec.argf = st.argf; rec.argl = st.argl; rec.nmin = st.nmin;
                 rec.exitE = 0; rec.has_exit = 0;
                 emit_global(a, rec);
             }
@@ -223,12 +279,20 @@ template <int K>
 static hipError_t launch_pos_k(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st)
 {
     const size_t lds = (size_t)nj * ((size_t)4 << (2 * K));
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pos_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
     const int nw = 16;
     int64_t grid = ((int64_t)a.n_chunk_tiles + nw - 1) / nw;
     if (grid > 256 * 4) grid = 256 * 4;                    // waves loop over tiles
-    hipLaunchKernelGGL((pos_kernel<K>), dim3((unsigned)grid), dim3(64 * nw), lds, st, a, gp, j0, nj);
+    bool want_dist = false;
+    for (int u = 0; u < nj; u++) want_dist = want_dist || a.dist[j0 + u] != nullptr;
+    if (want_dist) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pos_kernel<K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((pos_kernel<K, true>), dim3((unsigned)grid), dim3(64 * nw), lds, st, a, gp, j0, nj);
+    } else {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pos_kernel<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((pos_kernel<K, false>), dim3((unsigned)grid), dim3(64 * nw), lds, st, a, gp, j0, nj);
+    }
     return hipGetLastError();
 }
 
