@@ -259,6 +259,20 @@ int kgma_align_hits_device(kgma_ctx *ctx, const kgma_genome *genome, const uint8
 int kgma_repack_scan_hits(kgma_ctx *ctx, kgma_genome *genome, int32_t mode, int64_t buff, int64_t genome_pos0,
                           uint32_t flags, kgma_hit *out, int64_t cap, int64_t *n);
 
+/* Reference preparation on the device: n sequences given as residue characters
+ * seqs[offsets[i] .. offsets[i+1]) (either case; anything outside A/C/G/T/N -> KGMA_E_BADBASE, the
+ * reference's KeyError), 1 <= k <= 10.
+ *   kgma_kmer_count_batch: bins[i*4^k + x] = kmer_count(seq_i, k)[x+1] (src/Kmers.jl:14-28; Float64 bins,
+ *     k-mer value = first base most significant; a sequence shorter than k counts nothing).
+ *   kgma_kmer_dist_batch:  out[i] = kmer_dist(seq_i, KFV, k) = (1/2k)*sqeuclidean(kmer_count(seq_i,k), KFV)
+ *     (src/Kmers.jl:58-60), as called per reference sequence by cluster_ref_API
+ *     (src/ReferenceGeneration.jl:101) and per trial by estimate_optimal_threshold
+ *     (src/DistanceTesting.jl:14,27).  Float64, fixed summation order: exact for integer-valued KFVs,
+ *     otherwise equal to the reference up to the rounding of its (unordered) @simd reduction. */
+int kgma_kmer_count_batch(kgma_ctx *ctx, int32_t k, const uint8_t *seqs, const int64_t *offsets, int64_t n, double *bins);
+int kgma_kmer_dist_batch(kgma_ctx *ctx, int32_t k, const double *kfv, const uint8_t *seqs, const int64_t *offsets, int64_t n,
+                         double *out);
+
 /* Host stream handle (hipStream_t) the context launches on, for callers that time with hipEvents. */
 void *kgma_stream(kgma_ctx *ctx);
 

@@ -45,6 +45,9 @@ hipError_t launch_fasta_scatter(const uint8_t *raw, int64_t n, const int64_t *bl
                                 const ContigDesc *cd, int n_rec, uint8_t *ascii, hipStream_t st);
 int scan_tile_stride_words(int nk);
 int scan_nblocks(int nk);
+int kdist_grid(int k, int64_t n_seqs);
+hipError_t launch_kdist(int mode, const uint8_t *seqs, const int64_t *off, int64_t n_seqs, int k, const double *ref,
+                        uint32_t *scratch, double scale, double *out, unsigned long long *first_bad, hipStream_t st);
 }  // namespace kgma
 
 using namespace kgma;
@@ -406,6 +409,67 @@ int kgma_align_hits_device(kgma_ctx *ctx, const kgma_genome *g, const uint8_t *c
         if (score_out) score_out[i] = out[(size_t)i * 4 + 2];
     }
     return KGMA_OK;
+}
+
+// kmer_count (mode 1) / kmer_dist against one KFV (mode 0) of n sequences: src/Kmers.jl:14-28,58-60.
+static int kmer_batch(kgma_ctx *ctx, int mode, int32_t k, const double *kfv, const uint8_t *seqs, const int64_t *offsets,
+                      int64_t n, double *out)
+{
+    if (!ctx) return KGMA_E_ARG;
+    if (n < 0 || !offsets || !out || (mode == 0 && !kfv)) return fail(ctx, KGMA_E_ARG, "null argument");
+    if (k < 1 || k > 10) return fail(ctx, KGMA_E_UNSUPPORTED, "k = %d: the device path supports 1 <= k <= 10 here", k);
+    for (int64_t i = 0; i < n; i++)
+        if (offsets[i + 1] < offsets[i]) return fail(ctx, KGMA_E_ARG, "offsets[%lld] > offsets[%lld]", (long long)i, (long long)(i + 1));
+    if (n == 0) return KGMA_OK;
+    const int64_t base = offsets[0], bytes = offsets[n] - base;
+    if (bytes > 0 && !seqs) return fail(ctx, KGMA_E_ARG, "null argument");
+    const int64_t nb = (int64_t)1 << (2 * k);
+    const int64_t out_n = mode == 0 ? n : n * nb;
+    if (out_n > ((int64_t)1 << 30)) return fail(ctx, KGMA_E_UNSUPPORTED, "%lld sequences x 4^%d bins in one call", (long long)n, k);
+    (void)hipSetDevice(ctx->device);
+    std::vector<int64_t> off((size_t)n + 1);
+    for (int64_t i = 0; i <= n; i++) off[(size_t)i] = offsets[i] - base;
+    uint8_t *d_seq = nullptr;
+    int64_t *d_off = nullptr;
+    double *d_ref = nullptr, *d_out = nullptr;
+    uint32_t *d_scr = nullptr;
+    unsigned long long *d_bad = nullptr, bad = NO_BAD;
+    const size_t scr_bytes = k > 7 ? (size_t)kdist_grid(k, n) * (size_t)nb * 4 : 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_seq), (size_t)std::max<int64_t>(bytes, 1));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_off), (size_t)(n + 1) * 8);
+    if (e == hipSuccess && mode == 0) e = hipMalloc(reinterpret_cast<void **>(&d_ref), (size_t)nb * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_out), (size_t)out_n * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_bad), 8);
+    if (e == hipSuccess && scr_bytes) e = hipMalloc(reinterpret_cast<void **>(&d_scr), scr_bytes);
+    if (e == hipSuccess && scr_bytes) e = hipMemsetAsync(d_scr, 0, scr_bytes, ctx->stream);
+    if (e == hipSuccess && bytes) e = hipMemcpyAsync(d_seq, seqs + base, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && mode == 0) e = hipMemcpyAsync(d_ref, kfv, (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bad, &bad, 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = launch_kdist(mode, d_seq, d_off, n, k, d_ref, d_scr, 1.0 / (2 * k), d_out, d_bad, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)out_n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    for (void *q : {(void *)d_seq, (void *)d_off, (void *)d_ref, (void *)d_out, (void *)d_bad, (void *)d_scr})
+        if (q) (void)hipFree(q);
+    if (e != hipSuccess) return fail(ctx, KGMA_E_HIP, "kmer batch failed: %s", hipGetErrorString(e));
+    if (bad != NO_BAD) {
+        const int64_t si = (int64_t)(std::upper_bound(off.begin(), off.end(), (int64_t)bad) - off.begin()) - 1;
+        return fail(ctx, KGMA_E_BADBASE, "sequence %lld position %lld: residue is not one of A/C/G/T/N (KeyError, Consts.jl:22-28)",
+                    (long long)si, (long long)((int64_t)bad - off[(size_t)si] + 1));
+    }
+    return KGMA_OK;
+}
+
+int kgma_kmer_dist_batch(kgma_ctx *ctx, int32_t k, const double *kfv, const uint8_t *seqs, const int64_t *offsets, int64_t n,
+                         double *out)
+{
+    return kmer_batch(ctx, 0, k, kfv, seqs, offsets, n, out);
+}
+
+int kgma_kmer_count_batch(kgma_ctx *ctx, int32_t k, const uint8_t *seqs, const int64_t *offsets, int64_t n, double *bins)
+{
+    return kmer_batch(ctx, 1, k, nullptr, seqs, offsets, n, bins);
 }
 
 // One findGenes step in one call: re-encode the resident residues (Consts.jl:22-28), scan, replay, and

@@ -97,6 +97,20 @@ function fetch_dists!(ctx::Context, kfv::Integer, dist_vec)
     append!(dist_vec, buf)
 end
 
+# kmer_dist(seq, KFV, k) (src/Kmers.jl:58-60) of many sequences against one KFV in one device batch:
+# what cluster_ref_API (ReferenceGeneration.jl:101) and estimate_optimal_threshold (DistanceTesting.jl:14,27)
+# compute one sequence at a time.
+function kmer_dist_batch(ctx::Context, seqs::Vector{<:AbstractString}, KFV::Vector{Float64}, k::Int)
+    length(KFV) == 4^k || error("the KFV must have 4^k entries")
+    text = Vector{UInt8}(join(seqs))
+    offsets = Int64[0; cumsum(Int64[ncodeunits(s) for s in seqs])]
+    out = Vector{Float64}(undef, length(seqs))
+    check(ctx, ccall((:kgma_kmer_dist_batch, libkgma), Cint,
+                     (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{UInt8}, Ptr{Int64}, Int64, Ptr{Float64}),
+                     ctx.h, k, KFV, text, offsets, length(seqs), out))
+    return out
+end
+
 # alignment callback: the library calls this in reference order with the candidate range and
 # expects the aligned range back (Alignment.jl:33-52 / OmnGenomeMiner.jl:130-136).
 mutable struct AlignState

@@ -30,6 +30,7 @@ EXPORTS = [
     "kgma_get_dips", "kgma_get_first_window", "kgma_get_dists", "kgma_get_stats", "kgma_stream",
     "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_header", "kgma_scan_kernel_name",
     "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips", "kgma_align_hits_device", "kgma_repack_scan_hits",
+    "kgma_kmer_count_batch", "kgma_kmer_dist_batch",
 ]
 
 
@@ -129,6 +130,8 @@ def load():
     L.kgma_get_dip_last_min.argtypes = [vp, P(i64), i64, P(i64)]
     L.kgma_replay_dips.argtypes = [vp, i32, i64, i64, C.c_uint32, i64, P(i64), P(i64), P(KgmaDip), P(i64), i64, ALIGN_FN, vp]
     L.kgma_host_semiglobal_cigar.argtypes = [C.c_char_p, i64, C.c_char_p, i64, i32, i32, C.c_char_p, i64, P(i64)]
+    L.kgma_kmer_count_batch.argtypes = [vp, i32, C.c_char_p, P(i64), i64, P(dbl)]
+    L.kgma_kmer_dist_batch.argtypes = [vp, i32, P(dbl), C.c_char_p, P(i64), i64, P(dbl)]
     L.kgma_stream.argtypes = [vp]
     L.kgma_stream.restype = vp
     L.kgma_scan_kernel_name.argtypes = [vp]
@@ -380,6 +383,33 @@ class Context:
                                                   _np_ptr(b, C.c_int64) if n else None, _np_ptr(first, C.c_int64),
                                                   _np_ptr(last, C.c_int64), _np_ptr(score, C.c_int64)))
         return first[:n], last[:n], score[:n]
+
+    @staticmethod
+    def _concat(seqs):
+        seqs = [bytes(x) for x in seqs]
+        off = np.zeros(len(seqs) + 1, dtype=np.int64)
+        np.cumsum([len(x) for x in seqs], out=off[1:])
+        return b"".join(seqs), off
+
+    def kmer_count_batch(self, seqs, k: int) -> np.ndarray:
+        """kmer_count (src/Kmers.jl:14-28) of every sequence on the device: Float64 array [n, 4^k]."""
+        text, off = self._concat(seqs)
+        n = off.size - 1
+        bins = np.zeros((max(n, 1), 4 ** k), dtype=np.float64)
+        self._check(load().kgma_kmer_count_batch(self._h, int(k), text, _np_ptr(off, C.c_int64), n, _np_ptr(bins, C.c_double)))
+        return bins[:n]
+
+    def kmer_dist_batch(self, seqs, kfv, k: int) -> np.ndarray:
+        """kmer_dist(seq, KFV, k) (src/Kmers.jl:58-60) of every sequence against one KFV on the device."""
+        ref = np.ascontiguousarray(kfv, dtype=np.float64)
+        if ref.size != 4 ** k:
+            raise ValueError("the KFV must have 4^k entries")
+        text, off = self._concat(seqs)
+        n = off.size - 1
+        out = np.zeros(max(n, 1), dtype=np.float64)
+        self._check(load().kgma_kmer_dist_batch(self._h, int(k), _np_ptr(ref, C.c_double), text, _np_ptr(off, C.c_int64), n,
+                                                _np_ptr(out, C.c_double)))
+        return out[:n]
 
     def step_hits(self, genome: "Genome", mode: int, buff: int = 50, genome_pos: int = 0, flags: int = 0) -> np.ndarray:
         """repack + scan + hits in ONE library call (kgma_repack_scan_hits); returns the hits as a structured

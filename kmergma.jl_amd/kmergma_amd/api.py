@@ -216,11 +216,13 @@ def findGenes(*, genome_path: str, ref_path: str, k: int = 6, KmerDistThr=0, buf
     if verbose:
         log.info("pre-processing references and parameters...")
     warn_helper(k, do_return_dists)
-    RV, windowsize, consensus_refseq, (_S, N) = refprep.gen_ref_ws_cons(ref_path, k, return_int=True)
+    ctx = ctx if ctx is not None else default_context()
+    # reference preparation: the k-mer counting and kmer_dist batches run on the device
+    RV, windowsize, consensus_refseq, (_S, N) = refprep.gen_ref_ws_cons(ref_path, k, return_int=True, ctx=ctx)
     if k >= windowsize:
         raise ValueError(f"the average reference sequence length {windowsize} exceeds/is equal to the chosen "
                          f"kmer length {k}. please reduce k. ")
-    est = refprep.estimate_optimal_threshold(RV, windowsize, buffer=KmerDist_threshold_buffer)
+    est = refprep.estimate_optimal_threshold(RV, windowsize, buffer=KmerDist_threshold_buffer, ctx=ctx)
     if KmerDistThr == 0:
         KmerDistThr = est
     elif KmerDistThr < est:   # (sic) API.jl:75-76
@@ -260,14 +262,15 @@ def findGenes_cluster_mode(*, genome_path: str, ref_path: str, cluster_cutoffs=(
     if verbose:
         log.info("pre-processing references and parameters...")
     warn_helper(k, do_return_dists)
+    ctx = ctx if ctx is not None else default_context()
     RVs, windowsizes, cons, invalids, ints = refprep.cluster_ref_API(ref_path, k, cutoffs=list(cluster_cutoffs),
-                                                                      return_int=True)
+                                                                      return_int=True, ctx=ctx)
     RVs, windowsizes, cons, ints = refprep.eliminate_null_params(RVs, windowsizes, cons, invalids, ints)
     if k >= min(windowsizes):
         raise ValueError("some/all of the average reference sequence lengths exceeds/is equal to the chosen "
                          f"kmer length {k}. please reduce k. ")
     KmerDistThrs = [float(x) for x in KmerDistThrs]
-    est = refprep.estimate_optimal_threshold(RVs, windowsizes, buffer=kmerDist_threshold_buffer)
+    est = refprep.estimate_optimal_threshold(RVs, windowsizes, buffer=kmerDist_threshold_buffer, ctx=ctx)
     if KmerDistThrs[0] == 0:
         KmerDistThrs = est
     else:

@@ -48,8 +48,10 @@ def kmer_indices(seq: bytes, k: int) -> np.ndarray:
     return idx
 
 
-def kmer_count(seq: bytes, k: int) -> np.ndarray:
-    """src/Kmers.jl:14-28 kmer_count: Float64 histogram of length 4^k."""
+def kmer_count(seq: bytes, k: int, ctx=None) -> np.ndarray:
+    """src/Kmers.jl:14-28 kmer_count: Float64 histogram of length 4^k (on the device when `ctx` is given)."""
+    if ctx is not None:
+        return ctx.kmer_count_batch([seq], k)[0]
     return np.bincount(kmer_indices(seq, k), minlength=4 ** k).astype(np.float64)
 
 
@@ -63,8 +65,12 @@ def sqeuclidean(a: np.ndarray, b: np.ndarray) -> float:
     return float(np.dot(d, d))
 
 
-def kmer_dist(seq1: bytes, other: Union[bytes, np.ndarray], k: int) -> float:
-    """src/Kmers.jl:54-60 kmer_dist (sequence vs sequence, or sequence vs KFV)."""
+def kmer_dist(seq1: bytes, other: Union[bytes, np.ndarray], k: int, ctx=None) -> float:
+    """src/Kmers.jl:54-60 kmer_dist (sequence vs sequence, or sequence vs KFV); with `ctx` both the
+    counting and the distance run on the device (kgma_kmer_count_batch / kgma_kmer_dist_batch)."""
+    if ctx is not None:
+        kfv = kmer_count(other, k, ctx) if isinstance(other, (bytes, bytearray)) else other
+        return float(ctx.kmer_dist_batch([seq1], kfv, k)[0])
     c1 = kmer_count(seq1, k)
     c2 = kmer_count(other, k) if isinstance(other, (bytes, bytearray)) else np.asarray(other, dtype=np.float64)
     return (1.0 / (2 * k)) * sqeuclidean(c1, c2)
@@ -126,21 +132,25 @@ def _julia_round_int(x: float) -> int:
     return int(np.rint(x))  # Julia round(): ties to even
 
 
-def gen_ref_ws_cons(reference_seqs, k: int, get_maxlen: bool = False, return_int: bool = False):
+def gen_ref_ws_cons(reference_seqs, k: int, get_maxlen: bool = False, return_int: bool = False, ctx=None):
     """src/ReferenceGeneration.jl:4-41.
 
     Returns (KFV, windowsize, consensus[, maxlen]); with return_int=True additionally
-    (S:int64[4^k], N) such that KFV == S * (1/N) elementwise.
+    (S:int64[4^k], N) such that KFV == S * (1/N) elementwise.  With `ctx` the k-mer counting of all
+    references is one device batch (integer counts: the sum is exact in any order).
     """
     recs = _records(reference_seqs)
     answer = np.zeros(4 ** k, dtype=np.float64)
     n, cumulative, maxlen = 0, 0, 0
     prof = Profile(1)
+    if ctx is not None and recs:
+        answer += ctx.kmer_count_batch([rec.sequence for rec in recs], k).sum(axis=0)
     for rec in recs:
         n += 1
         cumulative += len(rec.sequence)
         maxlen = max(maxlen, len(rec.sequence))
-        kmer_count_into(rec.sequence, k, answer)
+        if ctx is None:
+            kmer_count_into(rec.sequence, k, answer)
         prof.lengthen(len(rec.sequence))
         prof.add(rec.sequence)
     inv = 1.0 / n
@@ -163,29 +173,36 @@ def get_cluster_index(inp, cutoffs: Sequence) -> int:
 
 
 def cluster_ref_API(reference_seqs: str, k: int, cutoffs: Sequence = (7, 12, 20, 25),
-                    include_avg: bool = True, get_dists: bool = False, return_int: bool = False):
+                    include_avg: bool = True, get_dists: bool = False, return_int: bool = False, ctx=None):
     """src/ReferenceGeneration.jl:75-138.
 
     Returns (KFVs, windowsizes, consensus_vec, invalid_vec[, dists]); with return_int=True an
-    extra trailing element [(S_j, N_j), ...] (N_j = 0 for empty clusters).
+    extra trailing element [(S_j, N_j), ...] (N_j = 0 for empty clusters).  With `ctx` the distance
+    of every reference to the average KFV (:101) and the k-mer counts are device batches.
     """
     recs = _records(reference_seqs)
     average_KFV, average_len, average_cons, maxlen, (S_avg, N_avg) = gen_ref_ws_cons(
-        recs, k, get_maxlen=True, return_int=True)
+        recs, k, get_maxlen=True, return_int=True, ctx=ctx)
+    if ctx is not None and recs:
+        dev_dists = ctx.kmer_dist_batch([rec.sequence for rec in recs], average_KFV, k)
+        dev_counts = ctx.kmer_count_batch([rec.sequence for rec in recs], k)
     nc = len(cutoffs) + 1
     lens = [0] * nc
     KFVs = [np.zeros(4 ** k, dtype=np.float64) for _ in range(nc)]
     windowsizes = [0] * nc
     profiles = [Profile(maxlen) for _ in range(nc)]
     dists = []
-    for rec in recs:
-        d = kmer_dist(rec.sequence, average_KFV, k)
+    for ri, rec in enumerate(recs):
+        d = float(dev_dists[ri]) if ctx is not None else kmer_dist(rec.sequence, average_KFV, k)
         ci = get_cluster_index(d, cutoffs) - 1
         dists.append(d)
         profiles[ci].add(rec.sequence)
         windowsizes[ci] += len(rec.sequence)
         lens[ci] += 1
-        kmer_count_into(rec.sequence, k, KFVs[ci])
+        if ctx is not None:
+            KFVs[ci] += dev_counts[ri]
+        else:
+            kmer_count_into(rec.sequence, k, KFVs[ci])
     ints = []
     consensus_vec: List[bytes] = [b""] * nc
     invalid = [False] * nc
@@ -221,13 +238,14 @@ def eliminate_null_params(KFVs, windowsizes, consensus_vec, invalid_vec, ints=No
     return out
 
 
-def estimate_optimal_threshold(RV, average_length, seed: int = 42, num_trials: int = 100, buffer: float = 8):
+def estimate_optimal_threshold(RV, average_length, seed: int = 42, num_trials: int = 100, buffer: float = 8, ctx=None):
     """src/DistanceTesting.jl:8-32: mean kmer_dist of random sequences to the KFV, minus `buffer`.
 
     DEVIATION (documented in DESIGN.md): the reference draws the sequences from Julia's global
     RNG (`Random.seed!(42)`; `randdnaseq`), which cannot be reproduced outside Julia.  This uses
     numpy's PCG64 with the same seed, so the estimate agrees statistically (±~1) but not bitwise;
     pass explicit thresholds where bit-identical hits against the reference are required.
+    With `ctx` the num_trials distances are one device batch (kgma_kmer_dist_batch).
     """
     rng = np.random.default_rng(seed)
 
@@ -235,9 +253,10 @@ def estimate_optimal_threshold(RV, average_length, seed: int = 42, num_trials: i
         rv = np.asarray(rv, dtype=np.float64)
         k = int(round(np.log(rv.size) / np.log(4)))
         total = 0.0
-        for _ in range(num_trials):
-            seq = bytes(_BASES[i] for i in rng.integers(0, 4, size=length))
-            total += kmer_dist(seq, rv, k)
+        seqs = [bytes(_BASES[i] for i in rng.integers(0, 4, size=length)) for _ in range(num_trials)]
+        dists = ctx.kmer_dist_batch(seqs, rv, k) if ctx is not None else [kmer_dist(seq, rv, k) for seq in seqs]
+        for d in dists:                                  # summed in trial order (:13-15)
+            total += float(d)
         return total / num_trials - buffer
 
     if isinstance(average_length, (list, tuple, np.ndarray)):
