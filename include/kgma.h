@@ -273,6 +273,14 @@ int kgma_kmer_count_batch(kgma_ctx *ctx, int32_t k, const uint8_t *seqs, const i
 int kgma_kmer_dist_batch(kgma_ctx *ctx, int32_t k, const double *kfv, const uint8_t *seqs, const int64_t *offsets, int64_t n,
                          double *out);
 
+/* kgma_repack_scan_hits in two halves, for step loops that have other work to queue while the GPU scans
+ * (bench.py with several ranks: the hit exchange of step i overlaps the scan of step i+1).  kgma_step_begin
+ * hands the step to a helper thread owned by the context and returns at once; kgma_step_end waits for it
+ * and copies the hits out (same contract as kgma_repack_scan_hits for out/cap/n).  Between the two calls
+ * the caller must not use the context or the genome.  One step in flight per context. */
+int kgma_step_begin(kgma_ctx *ctx, kgma_genome *genome, int32_t mode, int64_t buff, int64_t genome_pos0, uint32_t flags);
+int kgma_step_end(kgma_ctx *ctx, kgma_hit *out, int64_t cap, int64_t *n);
+
 /* Host stream handle (hipStream_t) the context launches on, for callers that time with hipEvents. */
 void *kgma_stream(kgma_ctx *ctx);
 

@@ -10,13 +10,17 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -95,7 +99,23 @@ struct kgma_genome {
     int64_t device_bytes = 0;
 };
 
+// kgma_step_begin / kgma_step_end: one findGenes step run by a helper thread of the context, so that the
+// caller's thread can queue other work (the hit exchange of the previous step) while the GPU scans.
+struct StepWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool sleeping = false;
+    std::atomic<int> state{0};      // 0 idle, 1 job posted, 2 done, -1 quit
+    kgma_genome *g = nullptr;
+    int32_t mode = 0;
+    int64_t buff = 0, genome_pos0 = 0;
+    uint32_t flags = 0;
+    int rc = 0;
+};
+
 struct kgma_ctx {
+    StepWorker *worker = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evp0 = nullptr, evp1 = nullptr;
@@ -335,6 +355,17 @@ int kgma_create(int device_ordinal, kgma_ctx **out)
 void kgma_destroy(kgma_ctx *ctx)
 {
     if (!ctx) return;
+    if (StepWorker *w = ctx->worker) {
+        while (w->state.load(std::memory_order_acquire) == 1) std::this_thread::yield();    // a posted step runs to its end
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->state.store(-1, std::memory_order_release);
+        }
+        w->cv.notify_all();
+        w->th.join();
+        delete w;
+        ctx->worker = nullptr;
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (double *p : ctx->d_dist) if (p) (void)hipFree(p);
@@ -481,6 +512,66 @@ int kgma_repack_scan_hits(kgma_ctx *ctx, kgma_genome *g, int32_t mode, int64_t b
     int rc = kgma_genome_repack(ctx, g);
     if (rc) return rc;
     rc = kgma_scan(ctx, g, mode, buff, genome_pos0, flags, nullptr, nullptr);
+    if (rc) return rc;
+    return kgma_get_hits(ctx, out, cap, n);
+}
+
+// The same step in two halves.  kgma_step_begin hands (repack, scan, replay) to the context's helper thread
+// and returns at once; kgma_step_end waits for it and copies the hits out like kgma_get_hits.  Between the
+// two the caller must not touch the context or the genome.
+static void step_worker_main(kgma_ctx *ctx)
+{
+    StepWorker *w = ctx->worker;
+    (void)hipSetDevice(ctx->device);
+    for (;;) {
+        // a step follows the previous one within microseconds in a step loop: poll first, sleep after ~2 ms idle
+        int st = w->state.load(std::memory_order_acquire);
+        const double t0 = now_ms();
+        while (st != 1 && st != -1) {
+            if (now_ms() - t0 > 2.0) {
+                std::unique_lock<std::mutex> lk(w->mu);
+                w->sleeping = true;
+                w->cv.wait(lk, [&] { const int s = w->state.load(std::memory_order_acquire); return s == 1 || s == -1; });
+                w->sleeping = false;
+            }
+            st = w->state.load(std::memory_order_acquire);
+        }
+        if (st == -1) return;
+        int rc = kgma_genome_repack(ctx, w->g);
+        if (!rc) rc = kgma_scan(ctx, w->g, w->mode, w->buff, w->genome_pos0, w->flags, nullptr, nullptr);
+        w->rc = rc;
+        w->state.store(2, std::memory_order_release);
+    }
+}
+
+int kgma_step_begin(kgma_ctx *ctx, kgma_genome *g, int32_t mode, int64_t buff, int64_t genome_pos0, uint32_t flags)
+{
+    if (!ctx || !g) return KGMA_E_ARG;
+    if (!ctx->worker) {
+        ctx->worker = new StepWorker();
+        ctx->worker->th = std::thread(step_worker_main, ctx);
+    }
+    StepWorker *w = ctx->worker;
+    if (w->state.load(std::memory_order_acquire) != 0) return fail(ctx, KGMA_E_STATE, "kgma_step_begin: a step is already in flight");
+    w->g = g; w->mode = mode; w->buff = buff; w->genome_pos0 = genome_pos0; w->flags = flags;
+    bool wake;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->state.store(1, std::memory_order_release);
+        wake = w->sleeping;
+    }
+    if (wake) w->cv.notify_one();
+    return KGMA_OK;
+}
+
+int kgma_step_end(kgma_ctx *ctx, kgma_hit *out, int64_t cap, int64_t *n)
+{
+    if (!ctx || !n) return KGMA_E_ARG;
+    StepWorker *w = ctx->worker;
+    if (!w || w->state.load(std::memory_order_acquire) == 0) return fail(ctx, KGMA_E_STATE, "kgma_step_end without kgma_step_begin");
+    while (w->state.load(std::memory_order_acquire) != 2) { /* the caller would otherwise poll the stream itself */ }
+    const int rc = w->rc;
+    w->state.store(0, std::memory_order_release);
     if (rc) return rc;
     return kgma_get_hits(ctx, out, cap, n);
 }

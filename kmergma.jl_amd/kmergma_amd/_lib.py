@@ -30,7 +30,7 @@ EXPORTS = [
     "kgma_get_dips", "kgma_get_first_window", "kgma_get_dists", "kgma_get_stats", "kgma_stream",
     "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_header", "kgma_scan_kernel_name",
     "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips", "kgma_align_hits_device", "kgma_repack_scan_hits",
-    "kgma_kmer_count_batch", "kgma_kmer_dist_batch",
+    "kgma_kmer_count_batch", "kgma_kmer_dist_batch", "kgma_step_begin", "kgma_step_end",
 ]
 
 
@@ -130,6 +130,8 @@ def load():
     L.kgma_get_dip_last_min.argtypes = [vp, P(i64), i64, P(i64)]
     L.kgma_replay_dips.argtypes = [vp, i32, i64, i64, C.c_uint32, i64, P(i64), P(i64), P(KgmaDip), P(i64), i64, ALIGN_FN, vp]
     L.kgma_host_semiglobal_cigar.argtypes = [C.c_char_p, i64, C.c_char_p, i64, i32, i32, C.c_char_p, i64, P(i64)]
+    L.kgma_step_begin.argtypes = [vp, vp, i32, i64, i64, C.c_uint32]
+    L.kgma_step_end.argtypes = [vp, P(KgmaHit), i64, P(i64)]
     L.kgma_kmer_count_batch.argtypes = [vp, i32, C.c_char_p, P(i64), i64, P(dbl)]
     L.kgma_kmer_dist_batch.argtypes = [vp, i32, P(dbl), C.c_char_p, P(i64), i64, P(dbl)]
     L.kgma_stream.argtypes = [vp]
@@ -422,6 +424,26 @@ class Context:
         st = load().kgma_repack_scan_hits(self._h, genome._h, mode, buff, genome_pos, flags, self._step_ptr, buf.size,
                                           C.byref(self._step_n))
         if st != 0 and self._step_n.value > buf.size:          # more hits than the buffer holds: grow and fetch
+            buf = self._step_buf = np.zeros(int(self._step_n.value) * 2, dtype=HIT_DTYPE)
+            self._step_ptr = buf.ctypes.data_as(C.POINTER(KgmaHit))
+            st = load().kgma_get_hits(self._h, self._step_ptr, buf.size, C.byref(self._step_n))
+        self._check(st)
+        return buf[:self._step_n.value]
+
+    def step_begin(self, genome: "Genome", mode: int, buff: int = 50, genome_pos: int = 0, flags: int = 0) -> None:
+        """First half of step_hits (kgma_step_begin): the step runs on the context's helper thread while the
+        caller queues other work; nothing else may use the context or the genome until step_end()."""
+        self._check(load().kgma_step_begin(self._h, genome._h, mode, buff, genome_pos, flags))
+
+    def step_end(self) -> np.ndarray:
+        """Second half (kgma_step_end): waits for the step and returns its hits like step_hits."""
+        buf = getattr(self, "_step_buf", None)
+        if buf is None:
+            buf = self._step_buf = np.zeros(4096, dtype=HIT_DTYPE)
+            self._step_ptr = buf.ctypes.data_as(C.POINTER(KgmaHit))
+            self._step_n = C.c_int64(0)
+        st = load().kgma_step_end(self._h, self._step_ptr, buf.size, C.byref(self._step_n))
+        if st != 0 and self._step_n.value > buf.size:
             buf = self._step_buf = np.zeros(int(self._step_n.value) * 2, dtype=HIT_DTYPE)
             self._step_ptr = buf.ctypes.data_as(C.POINTER(KgmaHit))
             st = load().kgma_get_hits(self._h, self._step_ptr, buf.size, C.byref(self._step_n))

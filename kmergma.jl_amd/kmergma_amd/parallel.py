@@ -109,6 +109,12 @@ class HitGatherer:
     copies them to the host, fixes record indices / `genome_pos` and returns a structured array.  The
     raw 64-byte records are shipped as they come out of `kgma_get_hits`: no per-hit Python work.
     `gather_hits` above is the general (any count, list-of-dict) form of the same exchange.
+
+    The exchange is split in two so that it overlaps the next scan: `start` only ENQUEUES (pinned ->
+    device copy, the collective, device -> pinned copy on rank 0; on a stream of its own, the host does
+    not wait) and returns a slot; `finish(slot)` waits for that slot and merges.  A step loop calls
+    `start(i)` and then `finish(i-1)`: the collective of step i runs while the library scans step i+1.
+    Two slots are used alternately.  `gather` = `finish(start(...))`.
     """
 
     def __init__(self, device=None, group=None, capacity: int = 256):
@@ -121,50 +127,76 @@ class HitGatherer:
         self.dev = device if device is not None else torch.device("cpu")
         on_gpu = self.dev.type != "cpu"
         rows = 1 + self.cap
-        # two pinned send buffers used alternately: a rank that runs ahead must not overwrite a block whose
-        # host->device copy is still queued behind the previous step's collective
-        self.send_host = [torch.zeros((rows, 8), dtype=torch.int64, pin_memory=on_gpu) for _ in range(2)]
-        self.send_np = [t.numpy() for t in self.send_host]
-        self.send_dev = [torch.zeros((rows, 8), dtype=torch.int64, device=self.dev) for _ in range(2)] if on_gpu else self.send_host
-        self.copied = [None, None]
-        self.turn = 0
-        self.recv_all = torch.zeros((self.world, rows, 8), dtype=torch.int64, device=self.dev)
-        self.recv_list = list(self.recv_all.unbind(0))
-        self.recv_host = self.recv_all if not on_gpu else torch.zeros((self.world, rows, 8), dtype=torch.int64, pin_memory=True)
         self.on_gpu = on_gpu
         self.use_into_tensor = dist.get_backend(group) == "nccl"   # RCCL: straight into the stacked buffer
+        self.stream = torch.cuda.Stream(device=self.dev) if on_gpu else None
+        self.slots = []
+        for _ in range(2):
+            send_host = torch.zeros((rows, 8), dtype=torch.int64, pin_memory=on_gpu)
+            recv_all = torch.zeros((self.world, rows, 8), dtype=torch.int64, device=self.dev)
+            self.slots.append({
+                "send_host": send_host, "send_np": send_host.numpy(),
+                "send_dev": torch.zeros((rows, 8), dtype=torch.int64, device=self.dev) if on_gpu else send_host,
+                "recv_all": recv_all, "recv_list": list(recv_all.unbind(0)),
+                "recv_host": torch.zeros((self.world, rows, 8), dtype=torch.int64, pin_memory=True) if on_gpu else recv_all,
+                "done": None,       # GPU: event after the last queued operation of the slot; CPU: the collective's work handle
+                "busy": False,
+            })
+        self.turn = 0
 
-    def gather(self, hits: np.ndarray, contig_begin: int, genome_pos_local_advance: int):
-        """`hits`: structured array of the rank's kgma_hit records.  Returns the merged array on rank 0
-        (record indices and genome_pos made global), None elsewhere."""
+    def start(self, hits: np.ndarray, contig_begin: int, genome_pos_local_advance: int) -> int:
+        """Queue the exchange of this rank's `hits` (structured array of kgma_hit records); returns the slot."""
         n = int(hits.shape[0])
         if n > self.cap:
             raise RuntimeError(f"HitGatherer capacity {self.cap} < {n} hits: construct it with a larger capacity")
         t = self.turn
         self.turn ^= 1
-        if self.copied[t] is not None:
-            self.copied[t].synchronize()            # (normally long done)
-        buf = self.send_np[t]
+        sl = self.slots[t]
+        if sl["busy"]:
+            raise RuntimeError("HitGatherer: both slots are in flight (call finish() for the older one first)")
+        if self.on_gpu and sl["done"] is not None:
+            sl["done"].synchronize()                # the slot's previous use has left its buffers (normally long done)
+        buf = sl["send_np"]
         buf[0, 0] = n
         buf[0, 1] = int(genome_pos_local_advance)
         buf[0, 2] = int(contig_begin)
         if n:
             buf[1:1 + n] = np.ascontiguousarray(hits).view(np.int64).reshape(n, 8)
         if self.on_gpu:
-            self.send_dev[t].copy_(self.send_host[t], non_blocking=True)
-            ev = self.torch.cuda.Event()
-            ev.record(self.torch.cuda.current_stream(self.dev))
-            self.copied[t] = ev
-        if self.use_into_tensor:
-            self.dist.all_gather_into_tensor(self.recv_all, self.send_dev[t], group=self.group)
+            with self.torch.cuda.stream(self.stream):
+                sl["send_dev"].copy_(sl["send_host"], non_blocking=True)
+                if self.use_into_tensor:
+                    work = self.dist.all_gather_into_tensor(sl["recv_all"], sl["send_dev"], group=self.group, async_op=True)
+                else:
+                    work = self.dist.all_gather(sl["recv_list"], sl["send_dev"], group=self.group, async_op=True)
+                work.wait()                         # RCCL: orders self.stream after the collective, the host goes on
+                if self.rank == 0:
+                    sl["recv_host"].copy_(sl["recv_all"], non_blocking=True)
+                ev = self.torch.cuda.Event()
+                ev.record(self.stream)
+                sl["done"] = ev
         else:
-            self.dist.all_gather(self.recv_list, self.send_dev[t], group=self.group)
-        if self.rank != 0:
-            return None
+            sl["done"] = self.dist.all_gather(sl["recv_list"], sl["send_dev"], group=self.group, async_op=True)
+        sl["busy"] = True
+        return t
+
+    def finish(self, slot: int):
+        """Wait for the exchange queued in `slot`; returns the merged array on rank 0 (record indices and
+        genome_pos made global), None elsewhere."""
+        sl = self.slots[slot]
+        if not sl["busy"]:
+            raise RuntimeError("HitGatherer.finish: nothing in flight in this slot")
+        sl["busy"] = False
         if self.on_gpu:
-            self.recv_host.copy_(self.recv_all, non_blocking=True)
-            self.torch.cuda.current_stream(self.dev).synchronize()
-        blocks = self.recv_host.numpy()
+            if self.rank != 0:
+                return None                         # (start() waits for the event before the slot is reused)
+            sl["done"].synchronize()
+        else:
+            sl["done"].wait()
+            sl["done"] = None
+            if self.rank != 0:
+                return None
+        blocks = sl["recv_host"].numpy()
         parts = []
         gp_off = 0
         for r in range(self.world):
@@ -177,6 +209,10 @@ class HitGatherer:
             parts.append(rec)
             gp_off += adv
         return np.concatenate(parts) if parts else np.zeros(0, dtype=HIT_RECORD_DTYPE)
+
+    def gather(self, hits: np.ndarray, contig_begin: int, genome_pos_local_advance: int):
+        """Blocking form: `finish(start(...))`."""
+        return self.finish(self.start(hits, contig_begin, genome_pos_local_advance))
 
 
 # ------------------------------------------------------------------------------------------------

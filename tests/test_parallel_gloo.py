@@ -80,8 +80,7 @@ def _worker_fast(rank, world, port, q):
     from kmergma_amd import parallel as par
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     g = par.HitGatherer(device=None, capacity=4)
-    outs = []
-    for step in range(3):                       # buffers are reused across steps
+    def make(step):
         n = [2, 1][rank] if step != 1 else [0, 3][rank]
         hits = np.zeros(n, dtype=par.HIT_RECORD_DTYPE)
         hits["contig"] = np.arange(n)
@@ -90,11 +89,38 @@ def _worker_fast(rank, world, port, q):
         hits["dist"] = 1.5 + rank
         hits["D"] = 1000 + rank
         hits["flags"] = rank
-        out = g.gather(hits, [0, 3][rank], [4000, 5100][rank])
+        return hits
+
+    outs = []
+    for step in range(3):                       # buffers are reused across steps
+        out = g.gather(make(step), [0, 3][rank], [4000, 5100][rank])
         if rank == 0:
             outs.append(out.copy())
         else:
             assert out is None
+    # the pipelined form (start(i), then finish(i-1)) returns the same arrays one step later
+    piped, pending = [], None
+    for step in range(3):
+        slot = g.start(make(step), [0, 3][rank], [4000, 5100][rank])
+        if pending is not None:
+            piped.append(g.finish(pending))
+        pending = slot
+    piped.append(g.finish(pending))
+    if rank == 0:
+        assert all(np.array_equal(a, b) for a, b in zip(outs, piped)) and len(piped) == 3
+    else:
+        assert piped == [None, None, None]
+    try:                                        # a third start() without finish() is refused
+        g.start(make(0), 0, 0); g.start(make(0), 0, 0)
+        try:
+            g.start(make(0), 0, 0)
+            third = False
+        except RuntimeError:
+            third = True
+        g.finish(0); g.finish(1)
+    except Exception:
+        third = False
+    assert third
     try:
         g.gather(np.zeros(5, dtype=par.HIT_RECORD_DTYPE), 0, 0)
         overflow = False
