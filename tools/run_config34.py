@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2] and configs[3] on ONE MI355X: the GRCh38-size synthetic genome (25 records
+with the primary-assembly lengths, 3.09 Gb) scanned by findGenes' single engine (k=6, the
+84-gene fixture KFV, thr=30) and by the cluster engine (5 KFVs, W = 288,288,288,289,290, thr =
+37,33,38,34,28, buff=100).  Prints one JSON object; --out writes it to a file.
+
+usage: python tools/run_config34.py [--scale 1.0] [--reps 5] [--out profiles/r01e_config34.json]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "kmergma.jl_amd")]
+
+from kmergma_amd import _lib, workloads  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    data = os.path.join(ROOT, "tests", "data")
+    refs = workloads.fixture_refs(data, 6)
+    cl = workloads.fixture_clusters(data, 6)
+    ctx = _lib.Context(0)
+    g, plants, lens = workloads.make_grch38_like(ctx, refs["genes"], scale=args.scale)
+    bases = sum(lens)
+    out = {"genome": "GRCh38-size synthetic stand-in: %d records, %d bases, %d planted genes" % (len(lens), bases, len(plants))}
+
+    def run(name, mode, buff):
+        ms, wall = [], []
+        import time
+        for _ in range(args.reps):
+            t = time.perf_counter()
+            ctx.scan(g, mode, buff, 0, 0, None)
+            wall.append((time.perf_counter() - t) * 1e3)
+            ms.append(ctx.stats()["scan_ms"])
+        st = ctx.stats()
+        kms = sorted(ms)[len(ms) // 2]
+        out[name] = {
+            "kernel": ctx.kernel_name(), "n_launches": int(st["n_launches"]), "scan_kernels_ms_median": round(kms, 3),
+            "scan_call_wall_ms_min": round(min(wall), 3), "Gbp_per_s_kernels": round(bases / kms / 1e6, 1),
+            "Gbp_per_s_wall": round(bases / min(wall) / 1e6, 1),
+            "hbm_algorithmic_GBps": round(0.25 * bases / kms / 1e6, 1), "hbm_fraction_of_8TBps": round(0.25 * bases / kms / 1e6 / 8000.0, 5),
+            "n_hits": int(st["n_hits"]), "n_dips": int(st["n_dips"]), "n_tie_flagged": int(st["n_tie_flagged"]),
+            "n_at_threshold": int(st["n_at_threshold"]),
+        }
+
+    ctx.set_refs(6, [refs["RV"]], [refs["ws"]], [30.0], [refs["N"]])
+    ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)              # warm-up (tile table, pack)
+    run("config3_findGenes_k6_1kfv", _lib.MODE_SINGLE, 50)
+    ctx.set_refs(6, cl["KFVs"], cl["ws"], [37.0, 33.0, 38.0, 34.0, 28.0], cl["N"])
+    ctx.scan(g, _lib.MODE_OMN, 100, 0, 0, None)
+    run("config4_cluster_mode_k6_5kfv", _lib.MODE_OMN, 100)
+    print(json.dumps(out, indent=1))
+    if args.out:
+        with open(args.out, "w") as fh:
+            json.dump(out, fh, indent=1)
+    g.free()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
