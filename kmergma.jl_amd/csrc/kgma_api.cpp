@@ -42,9 +42,9 @@ hipError_t launch_align(const uint8_t *ascii, const AlignJob *jobs, int n_jobs, 
                         uint8_t *trace, int64_t trace_stride, int max_n, int64_t *out, hipStream_t st);
 hipError_t launch_fasta_count(const uint8_t *raw, int64_t n, uint32_t *counts, hipStream_t st);
 hipError_t launch_gather_ranges(const uint8_t *src, const int64_t *desc, int n, uint8_t *dst, hipStream_t st);
-hipError_t launch_tie_gather(DevRecord *recs, const unsigned int *rec_count, unsigned int rec_cap, const TileDesc *tiles,
-                             const ContigDesc *cd, const uint8_t *ascii, const int64_t *Wtab, uint8_t *aux,
-                             unsigned int *aux_used, unsigned int aux_cap, hipStream_t st);
+hipError_t launch_export(uint8_t *res, uint8_t *host, int64_t d0_slots, int64_t d0_used, unsigned int rec_cap, unsigned int inline_recs,
+                         int do_gather, const TileDesc *tiles, const ContigDesc *cd, const uint8_t *ascii, const int64_t *Wtab,
+                         unsigned int *done, hipStream_t st);
 hipError_t launch_fasta_scatter(const uint8_t *raw, int64_t n, const int64_t *block_base, const int64_t *rec_start,
                                 const ContigDesc *cd, int n_rec, uint8_t *ascii, hipStream_t st);
 int scan_tile_stride_words(int nk);
@@ -120,7 +120,10 @@ struct kgma_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evp0 = nullptr, evp1 = nullptr;
     std::string err;
-    uint8_t *h_pin = nullptr; size_t h_pin_cap = 0;     // pinned result staging
+    uint8_t *h_pin = nullptr; size_t h_pin_cap = 0;     // pinned mirror of the result block, written by export_kernel
+    uint8_t *h_pin_dev = nullptr;                        // the same memory as the device addresses it
+    unsigned int *d_done = nullptr;                      // export_kernel's workgroup ticket
+    bool counters_clean = false;                         // export_kernel left the block's counters and the ticket at zero
     char kernel_name[48] = "";
     uint8_t *d_gath = nullptr, *h_gath = nullptr; size_t gath_cap = 0;   // tie-replay residue gather: [desc | residues]
     uint64_t next_uid = 1;
@@ -376,6 +379,7 @@ void kgma_destroy(kgma_ctx *ctx)
     if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
     if (ctx->d_res) (void)hipFree(ctx->d_res);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->h_gath) (void)hipHostFree(ctx->h_gath);
     if (ctx->d_gath) (void)hipFree(ctx->d_gath);
     if (ctx->evp0) (void)hipEventDestroy(ctx->evp0);
@@ -1380,6 +1384,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         if (r2) return r2;
         if (ctx->d_res) { (void)hipFree(ctx->d_res); ctx->device_bytes -= ctx->res_bytes; }
         ctx->d_res = fresh; ctx->res_bytes = cap; ctx->res_d0_slots = d0_slots; ctx->rec_cap = (unsigned int)recs;
+        ctx->counters_clean = false;                     // a fresh block is not zeroed
         return KGMA_OK;
     };
     rc = res_reserve(n_tiles * ctx->m, std::max<int64_t>(ctx->rec_cap, 1 << 16));
@@ -1398,6 +1403,11 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         ctx->h_pin = nullptr; ctx->h_pin_cap = 0;
         HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pin), pin_need + (pin_need >> 2), hipHostMallocDefault));
         ctx->h_pin_cap = pin_need + (pin_need >> 2);
+        HIP_TRY(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_pin_dev), ctx->h_pin, 0));
+    }
+    if (!ctx->d_done) {
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_done), 16));
+        ctx->counters_clean = false;
     }
     unsigned int *h_nrecs = reinterpret_cast<unsigned int *>(ctx->h_pin);
     unsigned long long *h_natt = reinterpret_cast<unsigned long long *>(ctx->h_pin + 8);
@@ -1417,7 +1427,12 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         int64_t *d_D0 = reinterpret_cast<int64_t *>(ctx->d_res + 16);
         uint8_t *d_aux = ctx->d_res + 16 + ctx->res_d0_slots * 8;
         DevRecord *d_recs = reinterpret_cast<DevRecord *>(d_aux + KGMA_AUX_BYTES);
-        HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 16, ctx->stream));
+        // (the previous scan's export_kernel normally left the counters at zero: no memset between steps)
+        if (!ctx->counters_clean) {
+            HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 16, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_done, 0, 16, ctx->stream));
+        }
+        ctx->counters_clean = false;
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         ctx->stats.n_launches = 0;
         for (const Group &gr : groups) {
@@ -1488,19 +1503,18 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             ctx->stats.n_launches++;
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-        // residues under tied minima, gathered on the device behind the scan (spares the host a second
-        // round trip for the Float64 tie replay); skipped when the caller wants pure exact arithmetic
-        if (!(flags & KGMA_F_NO_TIE_RESOLVE))
-            HIP_TRY(ctx, launch_tie_gather(d_recs, reinterpret_cast<unsigned int *>(d_cnt), ctx->rec_cap, ctx->d_tiles, g->d_cd,
-                                           g->d_ascii, ctx->d_Wtab, d_aux, reinterpret_cast<unsigned int *>(d_cnt + 4),
-                                           (unsigned int)KGMA_AUX_BYTES, ctx->stream));
-        // everything the host needs comes back behind ONE synchronisation (records beyond the
-        // inline block need a second copy; that only happens for dip-dense inputs)
-        // (the host mirror has the same layout: counters | D0 slots | records)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_res,
-                                    16 + (size_t)ctx->res_d0_slots * 8 + KGMA_AUX_BYTES + std::min<size_t>(INLINE_RECS, ctx->rec_cap) * sizeof(DevRecord),
-                                    hipMemcpyDeviceToHost, ctx->stream));
+        // last kernel: residues under tied minima are gathered on the device behind the scan (spares the host
+        // a second round trip for the Float64 tie replay; skipped when the caller wants pure exact arithmetic),
+        // then everything the host needs is written to the pinned mirror from inside the kernel (same layout:
+        // counters | D0 slots | aux | first INLINE_RECS records; records beyond the inline block need a copy
+        // afterwards, which only happens for dip-dense inputs) and the counters are reset: ONE synchronisation,
+        // no copy-engine launch, no memset before the next scan
+        (void)d_aux; (void)d_D0;
+        HIP_TRY(ctx, launch_export(ctx->d_res, ctx->h_pin_dev, ctx->res_d0_slots, n_tiles * (int64_t)ctx->m, ctx->rec_cap,
+                                   (unsigned int)std::min<size_t>(INLINE_RECS, ctx->rec_cap), (flags & KGMA_F_NO_TIE_RESOLVE) ? 0 : 1,
+                                   ctx->d_tiles, g->d_cd, g->d_ascii, ctx->d_Wtab, ctx->d_done, ctx->stream));
         HIP_TRY(ctx, sync_spin(ctx->stream));
+        ctx->counters_clean = true;
         if (g->pack_pending) {
             float pms = 0;
             (void)hipEventElapsedTime(&pms, ctx->evp0, ctx->evp1);

@@ -69,15 +69,49 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
             const uint4 a = p[0], b = p[1];
             const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
             const int nvalid = (L - base0) < 32 ? (int)(L - base0) : 32;
+            // Four residues per 32-bit word at a time.  After folding case, (ch >> 1) & 7 is distinct for the five
+            // accepted letters (A 0, C 1, T 2, G 3, N 7): v_perm_b32 uses it as an index into two 8-byte tables,
+            // one giving the letter back (any difference = a residue outside A/C/G/T/N) and one giving the code
+            // as 0x00 / 0x0F / 0xF0 / 0xFF (low nibble = code bit 0, high nibble = code bit 1; N -> T's code 3).
+            // ANDing with one bit per byte and summing the bytes (v_sad_u8) collects four residues' plane bits.
+            uint32_t diff = 0, hw[8], lw[8];
 #pragma unroll
-            for (int i = 0; i < 32; i++) {
-                const uint32_t ch = ((x[i >> 2] >> (8 * (i & 3))) & 0xFFu) & 0xDFu;  // fold case
-                const uint32_t isA = ch == 'A', isC = ch == 'C', isG = ch == 'G';
-                const uint32_t isT = (ch == 'T') | (ch == 'N');
-                const uint32_t in = i < nvalid;
-                h |= ((isG | isT) & in) << i;
-                l |= ((isC | isT) & in) << i;
-                bad |= ((1u ^ (isA | isC | isG | isT)) & in) << i;
+            for (int j = 0; j < 8; j++) {
+                const uint32_t v = x[j] & 0xDFDFDFDFu;                       // fold case
+                const uint32_t sel = (v >> 1) & 0x07070707u;
+                const uint32_t letter = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, sel);   // idx 7 'N' | 3 'G' 2 'T' 1 'C' 0 'A'
+                const uint32_t code = __builtin_amdgcn_perm(0xFF000000u, 0xF0FF0F00u, sel);     // idx 7 -> 3 | G 2, T 3, C 1, A 0
+                diff |= v ^ letter;
+                // residue t of word j goes to bit 4*(j&1)+t of the plane byte: pick that bit out of the nibble that
+                // carries the plane's indicator
+                if (j & 1) {
+                    lw[j] = (code << 4) & 0x80402010u;
+                    hw[j] = code & 0x80402010u;
+                } else {
+                    lw[j] = code & 0x08040201u;
+                    hw[j] = (code >> 4) & 0x08040201u;
+                }
+            }
+            if (diff == 0 && nvalid == 32) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {                                // 8 residues -> one byte of each plane
+                    const uint32_t lb = __builtin_amdgcn_sad_u8(lw[2 * q + 1], 0u, __builtin_amdgcn_sad_u8(lw[2 * q], 0u, 0u));
+                    const uint32_t hb = __builtin_amdgcn_sad_u8(hw[2 * q + 1], 0u, __builtin_amdgcn_sad_u8(hw[2 * q], 0u, 0u));
+                    l |= lb << (8 * q);
+                    h |= hb << (8 * q);
+                }
+            } else {
+                // a record's last (partial) word, or a residue to report: one residue at a time
+#pragma unroll
+                for (int i = 0; i < 32; i++) {
+                    const uint32_t ch = ((x[i >> 2] >> (8 * (i & 3))) & 0xFFu) & 0xDFu;  // fold case
+                    const uint32_t isA = ch == 'A', isC = ch == 'C', isG = ch == 'G';
+                    const uint32_t isT = (ch == 'T') | (ch == 'N');
+                    const uint32_t in = i < nvalid;
+                    h |= ((isG | isT) & in) << i;
+                    l |= ((isC | isT) & in) << i;
+                    bad |= ((1u ^ (isA | isC | isG | isT)) & in) << i;
+                }
             }
         }
         if (bad) {
@@ -1037,11 +1071,11 @@ hipError_t launch_gather_ranges(const uint8_t *src, const int64_t *desc, int n, 
 // the scan kernel, looks at the records it produced and copies the residues of every RUN record with
 // nmin > 1 into the aux region of the result block (one wave per record; 16-byte slots).  The slot
 // index + 1 is stored in the record's has_exit word above bit 0.
-__global__ __launch_bounds__(256) void tie_gather_kernel(DevRecord *__restrict__ recs, const unsigned int *__restrict__ rec_count,
-                                                         unsigned int rec_cap, const TileDesc *__restrict__ tiles,
-                                                         const ContigDesc *__restrict__ cd, const uint8_t *__restrict__ ascii,
-                                                         const int64_t *__restrict__ Wtab, uint8_t *__restrict__ aux,
-                                                         unsigned int *__restrict__ aux_used, unsigned int aux_cap)
+__device__ __forceinline__ void tie_gather_body(DevRecord *__restrict__ recs, const unsigned int *__restrict__ rec_count,
+                                                unsigned int rec_cap, const TileDesc *__restrict__ tiles,
+                                                const ContigDesc *__restrict__ cd, const uint8_t *__restrict__ ascii,
+                                                const int64_t *__restrict__ Wtab, uint8_t *__restrict__ aux,
+                                                unsigned int *__restrict__ aux_used, unsigned int aux_cap)
 {
     unsigned int n = *rec_count;
     if (n > rec_cap) n = rec_cap;
@@ -1068,12 +1102,63 @@ __global__ __launch_bounds__(256) void tie_gather_kernel(DevRecord *__restrict__
     }
 }
 
-hipError_t launch_tie_gather(DevRecord *recs, const unsigned int *rec_count, unsigned int rec_cap, const TileDesc *tiles,
-                             const ContigDesc *cd, const uint8_t *ascii, const int64_t *Wtab, uint8_t *aux,
-                             unsigned int *aux_used, unsigned int aux_cap, hipStream_t st)
+// Last kernel of a scan: (1) the tie gather above (unless the caller wants pure exact arithmetic), (2) the
+// result block goes to its pinned host mirror from inside the kernel (same layout: counters | D0 slots | aux
+// | records; no copy engine launch behind the scan, no second synchronisation), (3) the counters are reset
+// for the next scan.  D0 was completed by the scan kernels, so every workgroup ships its share at once; the
+// counters, the aux bytes and the inline records are shipped by whichever workgroup finishes LAST (ticket in
+// `done`), reading past its own L1 because other workgroups wrote them in this launch.
+__global__ __launch_bounds__(256) void export_kernel(uint8_t *__restrict__ res, uint8_t *__restrict__ host, int64_t d0_slots,
+                                                     int64_t d0_used, unsigned int rec_cap, unsigned int inline_recs, int do_gather,
+                                                     const TileDesc *__restrict__ tiles, const ContigDesc *__restrict__ cd,
+                                                     const uint8_t *__restrict__ ascii, const int64_t *__restrict__ Wtab,
+                                                     unsigned int aux_cap, unsigned int *__restrict__ done)
 {
-    hipLaunchKernelGGL(tie_gather_kernel, dim3(64), dim3(256), 0, st, recs, rec_count, rec_cap, tiles, cd, ascii, Wtab, aux,
-                       aux_used, aux_cap);
+    unsigned int *cnt = reinterpret_cast<unsigned int *>(res);
+    uint8_t *aux = res + 16 + d0_slots * 8;
+    DevRecord *recs = reinterpret_cast<DevRecord *>(aux + KGMA_AUX_BYTES);
+    if (do_gather) tie_gather_body(recs, cnt, rec_cap, tiles, cd, ascii, Wtab, aux, cnt + 1, aux_cap);
+    {   // D0: 8-byte slots at the same offset in both blocks
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(res + 16);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(host + 16);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d0_used; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    }
+    __shared__ unsigned int ticket;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = atomicAdd(done, 1u);
+    __syncthreads();
+    if (ticket != gridDim.x - 1) return;
+    __threadfence();
+    auto ld = [](const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const unsigned long long *r64 = reinterpret_cast<const unsigned long long *>(res);
+    unsigned long long *h64 = reinterpret_cast<unsigned long long *>(host);
+    const unsigned long long c0 = ld(r64), c1 = ld(r64 + 1);
+    unsigned int n = (unsigned int)c0, used = (unsigned int)(c0 >> 32);
+    if (n > rec_cap) n = rec_cap;
+    if (n > inline_recs) n = inline_recs;
+    if (used > aux_cap) used = aux_cap;
+    const int64_t aux_w0 = (16 + d0_slots * 8) >> 3, aux_words = (used + 7) >> 3;
+    for (int64_t i = threadIdx.x; i < aux_words; i += blockDim.x) h64[aux_w0 + i] = ld(r64 + aux_w0 + i);
+    const int64_t rec_w0 = aux_w0 + (KGMA_AUX_BYTES >> 3), rec_words = ((int64_t)n * (int64_t)sizeof(DevRecord) + 7) >> 3;
+    for (int64_t i = threadIdx.x; i < rec_words; i += blockDim.x) h64[rec_w0 + i] = ld(r64 + rec_w0 + i);
+    if (threadIdx.x == 0) {
+        h64[0] = c0;
+        h64[1] = c1;
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(res), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(res) + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+hipError_t launch_export(uint8_t *res, uint8_t *host, int64_t d0_slots, int64_t d0_used, unsigned int rec_cap, unsigned int inline_recs,
+                         int do_gather, const TileDesc *tiles, const ContigDesc *cd, const uint8_t *ascii, const int64_t *Wtab,
+                         unsigned int *done, hipStream_t st)
+{
+    int64_t grid = (d0_used * 8) >> 16;                      // ~64 KiB of D0 per workgroup, 64 ... 1024 workgroups
+    grid = grid < 64 ? 64 : grid > 1024 ? 1024 : grid;
+    hipLaunchKernelGGL(export_kernel, dim3((unsigned)grid), dim3(256), 0, st, res, host, d0_slots, d0_used, rec_cap, inline_recs,
+                       do_gather, tiles, cd, ascii, Wtab, (unsigned int)KGMA_AUX_BYTES, done);
     return hipGetLastError();
 }
 
