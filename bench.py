@@ -50,7 +50,7 @@ def pmc_profile(kernel_name, length):
     timed process): HBM bytes per launch of the scan kernel (FETCH_SIZE x 1 KiB x 2, the gfx950 correction
     of MI355X_MICROARCH.md, + WRITE_SIZE x 1 KiB) and the VALU / LDS occupancy that actually bind the
     kernel.  Only reported when the summary was taken on the same kernel and workload."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01d_scan_pmc_summary.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01f_scan_pmc_summary.json")
     try:
         with open(path) as f:
             prof = json.load(f)
@@ -63,7 +63,7 @@ def pmc_profile(kernel_name, length):
                  "lds_inst_per_64_windows": round(d["lds_instructions_per_64_windows"], 2),
                  "lds_active_frac": round(d["lds_active_fraction_of_kernel"], 4),
                  "lds_bank_conflict_frac_of_lds_cycles": round(d["lds_bank_conflict_cycles"] / d["lds_active_cycles"], 4)}
-        return round(d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]), "profiles/r01d_scan_pmc_summary.json", extra
+        return round(d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]), "profiles/r01f_scan_pmc_summary.json", extra
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None, None, None
 
