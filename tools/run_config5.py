@@ -1,10 +1,17 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[4] on ONE MI355X: synthetic 100 Gb random-DNA genome (100 records x 1e9
-bases, generated on the device), 8 reference clusters at k=7 (findGenes_cluster_mode path).
-The 8-GPU form of this config shards the 100 records across ranks (bench.py --gpus 8 pattern); a
-single GPU holds the whole genome (100 GB ASCII + 25 GB bit-planes of 288 GB).
+"""BASELINE.json configs[4]: synthetic 100 Gb random-DNA genome (100 records x 1e9 bases, generated on
+the device), 8 reference clusters at k=7 (findGenes_cluster_mode path).
+
+One process: a single MI355X holds the whole genome (100 GB ASCII + 25 GB bit-planes of 288 GB).
+Under torch.distributed.run (one rank per GPU) the 100 records are sharded across the ranks
+(parallel.shard_contigs: contiguous, balanced by bases), every rank generates and scans its own records
+(the generator is keyed by record index, so the shards are the records of the one-process run), and the
+hits are gathered on rank 0 with parallel.gather_hits (RCCL; record indices and genome_pos made global);
+throughput = all bases / the slowest rank's scan time.
 
 usage: python tools/run_config5.py [--gb 100] [--out profiles/r01_config5_1gpu.json]
+       python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/run_config5.py [--gb 100]
+(KGMA_BENCH_BACKEND=gloo KGMA_BENCH_DEVICE=0 rehearse the sharded form on a one-GPU box.)
 """
 import argparse
 import json
@@ -39,42 +46,95 @@ def main():
     rec_len = int(args.gb * 1e9 / n_rec)
     lens = [rec_len] * n_rec
     genes = workloads.fixture_refs(os.path.join(ROOT, "tests", "data"), 6)["genes"]
-    ctx = _lib.Context(0)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dev_index = int(os.environ.get("KGMA_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    backend = os.environ.get("KGMA_BENCH_BACKEND", "nccl")
+    dist = dev = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        from kmergma_amd import parallel
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        rec0, rec1 = parallel.shard_contigs(lens, world)[rank]
+    else:
+        rec0, rec1 = 0, n_rec
+    my_lens = lens[rec0:rec1]
+    ctx = _lib.Context(dev_index)
     ctx.set_refs(k, KFVs, ws, thr, N)
     t0 = time.perf_counter()
-    g = ctx.genome_synthetic(lens, 100)
+    # the generator hashes seed + (record + 1) * K (kgma_kernels.hip synth_word): shifting the seed by rec0 * K makes
+    # local record c - rec0 the genome's record c
+    g = ctx.genome_synthetic(my_lens, (100 + rec0 * 0xD1B54A32D192ED03) & (2 ** 64 - 1))
     plants = workloads.planted_genes(genes, lens, args.plants, 105, max_rate=0.10)
-    for c, pos, data in plants:
+    my_plants = [(c - rec0, pos, data) for c, pos, data in plants if rec0 <= c < rec1]
+    for c, pos, data in my_plants:
         g.poke(c, pos, data)
     g.repack()
     ctx.scan_device(g, _lib.MODE_OMN, 0)          # warm-up (also completes the pack)
     t_gen = time.perf_counter() - t0
+    genome_pos0 = 0                                # shard-local; gather_hits makes it global
     times = []
     for _ in range(2):
+        if world > 1:
+            dist.barrier()
         t1 = time.perf_counter()
-        ctx.scan(g, _lib.MODE_OMN, 100, 0, 0, None)
+        ctx.scan(g, _lib.MODE_OMN, 100, genome_pos0, 0, None)
         times.append(time.perf_counter() - t1)
     st = ctx.stats()
     hits = ctx.hits_array()
-    bases = st["bases_scanned"]
     kernel_s = st["scan_ms"] * 1e-3
-    found = 0
+    wall_s = min(times)
+    bases = st["bases_scanned"]
+    n_hits_total = int(len(hits))
     by_c = {}
     for h in hits:
-        by_c.setdefault(int(h["contig"]), []).append(int(h["cmi"]) + 1)
+        by_c.setdefault(int(h["contig"]) + rec0, []).append(int(h["cmi"]) + 1)
+    if world > 1:
+        import torch
+        from kmergma_amd import parallel
+        cpu = backend != "nccl"
+        t = torch.tensor([kernel_s, wall_s], dtype=torch.float64, device="cpu" if cpu else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                       # the slowest rank
+        kernel_s, wall_s = float(t[0]), float(t[1])
+        b = torch.tensor([bases], dtype=torch.int64, device="cpu" if cpu else dev)
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        bases = int(b[0])
+        scale = {j + 1: 2.0 * k * N[j] ** 2 for j in range(len(N))}
+        merged = parallel.gather_hits(ctx.hits(), rec0, parallel.genome_pos_advance(my_lens, False, 0),
+                                      lambda kfv: scale.get(kfv, scale[1]), device=None if cpu else dev)
+        if rank == 0:
+            n_hits_total = len(merged)
+            by_c = {}
+            for h in merged:
+                by_c.setdefault(int(h["contig"]), []).append(int(h["cmi"]) + 1)
+    if rank != 0:
+        g.free()
+        ctx.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    found = 0
     for c, pos, data in plants:
         if any(abs(s - pos) <= 60 for s in by_c.get(c, [])):
             found += 1
     out = {
-        "config": "BASELINE.json configs[4] on one MI355X: %d records x %d bases, k=7, 8 KFVs" % (n_rec, rec_len),
+        "config": "BASELINE.json configs[4] on %d MI355X rank(s): %d records x %d bases, k=7, 8 KFVs" % (world, n_rec, rec_len),
+        "n_ranks": world, "backend": backend if world > 1 else None,
         "windowsizes": [int(w) for w in ws], "cluster_sizes": N, "thresholds": [round(t, 3) for t in thr],
         "bases": int(bases), "n_tiles": int(st["n_tiles"]), "n_launches": int(st["n_launches"]),
-        "scan_kernels_s": round(kernel_s, 4), "scan_wall_s": round(min(times), 4),
-        "Gbp_per_s_kernels": round(bases / kernel_s / 1e9, 2), "Gbp_per_s_wall": round(bases / min(times) / 1e9, 2),
+        "scan_kernels_s": round(kernel_s, 4), "scan_wall_s": round(wall_s, 4),
+        "Gbp_per_s_kernels": round(bases / kernel_s / 1e9, 2), "Gbp_per_s_wall": round(bases / wall_s / 1e9, 2),
         "hbm_algorithmic_GBps": round(0.25 * bases / kernel_s / 1e9, 2),
         "hbm_fraction_of_8TBps": round(0.25 * bases / kernel_s / 8e12, 5),
         "pack_ms": round(st["pack_ms"], 2), "generate_and_pack_s": round(t_gen, 2),
-        "n_hits": int(len(hits)), "n_dips": int(st["n_dips"]), "planted": len(plants), "planted_found": found,
+        "n_hits": n_hits_total, "n_dips_rank0": int(st["n_dips"]), "planted": len(plants), "planted_found": found,
         "device_GB": round(st["device_bytes"] / 1e9, 1),
     }
     print(json.dumps(out, indent=1))
@@ -83,6 +143,9 @@ def main():
             json.dump(out, fh, indent=1)
     g.free()
     ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
