@@ -602,3 +602,30 @@ def test_two_kernel_cluster_path(ctx, data_dir, genes, k, two, monkeypatch):
     assert [h["D"] for h in hits] == [h["D"] for h in ohi]
     for j in range(m):
         assert np.array_equal(dists[j], oD[j] / (2.0 * k * c["N"][j] ** 2))
+
+
+def test_dip_dense_records_export_and_overflow(alp_ref, force_kernel):
+    """A threshold at the typical distance of random sequence: far more dip fragments than the inline block
+    of the in-kernel result export (4096 records) and than a fresh context's record capacity (65536), so the
+    copy of the records beyond the inline block and the overflow retry (grow, rescan) both run.  Exact
+    arithmetic: hits and per-record first-window values bit-identical to the integer oracle."""
+    k, W, N, S = alp_ref["k"], alp_ref["ws"], alp_ref["N"], alp_ref["S"]
+    thr = refprep.estimate_optimal_threshold(alp_ref["RV"], W, num_trials=20, buffer=0)     # mean distance of random sequence
+    rng = np.random.default_rng(77)
+    contigs = [random_dna(rng, 12_000_000), random_dna(rng, 400), random_dna(rng, 2_000_000)]
+    T = orc.int_threshold(thr, k, N)
+    ohi, _, oD1 = orc.single_scan_int(contigs, S, N, k, W, T, 50, hit_cap=1 << 18)
+    for kernel in ("stream", "bitslice"):
+        force_kernel(kernel)
+        c = _lib.Context(0)                                # fresh context: initial record capacity
+        try:
+            hits, _, D1, stats, _ = _scan_single(c, contigs, alp_ref, thr, 50, no_tie_resolve=True)
+            assert stats["n_dips"] > 90000, stats["n_dips"]
+            assert np.array_equal(D1, oD1)
+            assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi]
+            assert [h["D"] for h in hits] == [h["D"] for h in ohi]
+            # a second scan in the same (now grown) context gives the same answer
+            hits2, *_ = _scan_single(c, contigs, alp_ref, thr, 50, no_tie_resolve=True)
+            assert [hit_key(h) for h in hits2] == [hit_key(h) for h in ohi]
+        finally:
+            c.close()
