@@ -134,7 +134,7 @@ struct kgma_ctx {
     std::vector<KfvInfo> kfv;
     int32_t *d_Stab = nullptr;        // m x 4^k, device index order (first base least significant)
     int32_t *d_StabC = nullptr;       // the same tables in the stream kernel's index order ((hi bits << k) | lo bits)
-    int64_t *d_Wtab = nullptr;        // window size per KFV (tie_gather_kernel)
+    int64_t *d_Wtab = nullptr;        // window size per KFV (export_kernel's tie gather)
     int16_t *d_diff = nullptr; int64_t diff_cap = 0;   // two-kernel cluster path: per-window self-match differences of a tile chunk
     // scan scratch
     TileDesc *d_tiles = nullptr; int64_t tiles_cap = 0;

@@ -95,7 +95,7 @@ constexpr int KGMA_STREAM_MIN_WINDOWS = 2048;                  // shorter stream
 constexpr int KGMA_STREAM_MAX_WINDOWS = 1 << 20;
 constexpr int KGMA_STREAM_MAX_K = 7;                           // 4^k 16-bit counters per wave must fit the LDS
 
-// Aux region of the result block: residues under tied minima, gathered on the device (tie_gather_kernel)
+// Aux region of the result block: residues under tied minima, gathered on the device (export_kernel)
 constexpr int KGMA_AUX_BYTES = 64 << 10;
 constexpr int KGMA_AUX_MAX_RANGE = 4096;                       // longest residue range gathered speculatively
 
