@@ -140,7 +140,7 @@ def main():
 
     gatherer = None
     if world > 1:
-        gatherer = parallel.HitGatherer(device=dev if backend == "nccl" else None, capacity=256)
+        gatherer = parallel.HitGatherer(device=dev if backend == "nccl" else None, capacity=512)
         gp_advance = parallel.genome_pos_advance([length], True, refs["ws"])
 
     pending = [None]
