@@ -140,6 +140,11 @@ def main():
 
     gatherer = None
     if world > 1:
+        # the exchange's RCCL kernel is queued while the next scan runs and its workgroups wait on their peers while
+        # resident: leave it 8 CUs (one per XCD), so that it runs beside the scan instead of between two scans, where
+        # its resident workgroups would push some of the next scan's workgroups into a second round (costs 8/256 of
+        # the scan rate; KGMA_BENCH_RESERVED_CUS overrides)
+        ctx.set_reserved_cus(int(os.environ.get("KGMA_BENCH_RESERVED_CUS", "8")))
         gatherer = parallel.HitGatherer(device=dev if backend == "nccl" else None, capacity=512)
         gp_advance = parallel.genome_pos_advance([length], True, refs["ws"])
 

@@ -281,6 +281,13 @@ int kgma_kmer_dist_batch(kgma_ctx *ctx, int32_t k, const double *kfv, const uint
 int kgma_step_begin(kgma_ctx *ctx, kgma_genome *genome, int32_t mode, int64_t buff, int64_t genome_pos0, uint32_t flags);
 int kgma_step_end(kgma_ctx *ctx, kgma_hit *out, int64_t cap, int64_t *n);
 
+/* The count-table stream kernel sizes its streams so that one round of workgroups fills every CU of the chip
+ * (one workgroup takes a CU's whole LDS).  A caller that runs other kernels beside the scan -- the RCCL
+ * collective of a multi-rank step loop, whose workgroups wait on their peers while resident -- reserves `n`
+ * CUs for them (0..128; default 0): the scan then uses 256 - n workgroups per round, so that neither kernel
+ * waits for the other's workgroups to retire.  Takes effect at the next scan. */
+int kgma_set_reserved_cus(kgma_ctx *ctx, int32_t n);
+
 /* Host stream handle (hipStream_t) the context launches on, for callers that time with hipEvents. */
 void *kgma_stream(kgma_ctx *ctx);
 

@@ -124,6 +124,7 @@ struct kgma_ctx {
     uint8_t *h_pin_dev = nullptr;                        // the same memory as the device addresses it
     unsigned int *d_done = nullptr;                      // export_kernel's workgroup ticket
     bool counters_clean = false;                         // export_kernel left the block's counters and the ticket at zero
+    int reserved_cus = 0;                                // CUs the stream kernel leaves free (kgma_set_reserved_cus)
     char kernel_name[48] = "";
     uint8_t *d_gath = nullptr, *h_gath = nullptr; size_t gath_cap = 0;   // tie-replay residue gather: [desc | residues]
     uint64_t next_uid = 1;
@@ -578,6 +579,14 @@ int kgma_step_end(kgma_ctx *ctx, kgma_hit *out, int64_t cap, int64_t *n)
     w->state.store(0, std::memory_order_release);
     if (rc) return rc;
     return kgma_get_hits(ctx, out, cap, n);
+}
+
+int kgma_set_reserved_cus(kgma_ctx *ctx, int32_t n)
+{
+    if (!ctx) return KGMA_E_ARG;
+    if (n < 0 || n > 128) return fail(ctx, KGMA_E_ARG, "reserved CUs must be 0..128");
+    ctx->reserved_cus = n;
+    return KGMA_OK;
 }
 
 void *kgma_stream(kgma_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
@@ -1241,7 +1250,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         }
     const int64_t nc = g->n_contigs;
     const bool want_dists = (flags & KGMA_F_RETURN_DISTS) != 0;
-    const int geom_version = use_stream ? 2 : 1;
+    const int geom_version = use_stream ? 2 + 16 * ctx->reserved_cus : 1;
     snprintf(ctx->kernel_name, sizeof ctx->kernel_name, use_stream ? "stream_kernel<%d>" : "scan_kernel<%d>", k);   // (+ pos_kernel for multi-KFV groups)
 
     ctx->dips.clear();
@@ -1287,7 +1296,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         // chip (256 CUs x waves per workgroup) a whole number of equally long streams
         int64_t P;
         if (use_stream) {
-            const int64_t slots = (int64_t)256 * stream_nw;
+            const int64_t slots = (int64_t)(256 - ctx->reserved_cus) * stream_nw;      // (kgma_set_reserved_cus)
             const int64_t rounds = std::max<int64_t>(1, (total_nwin + slots * KGMA_STREAM_MAX_WINDOWS - 1) / (slots * KGMA_STREAM_MAX_WINDOWS));
             P = (total_nwin + slots * rounds - 1) / (slots * rounds);
             P = ((P + 63) / 64) * 64;

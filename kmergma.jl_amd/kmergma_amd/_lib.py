@@ -30,7 +30,7 @@ EXPORTS = [
     "kgma_get_dips", "kgma_get_first_window", "kgma_get_dists", "kgma_get_stats", "kgma_stream",
     "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_header", "kgma_scan_kernel_name",
     "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips", "kgma_align_hits_device", "kgma_repack_scan_hits",
-    "kgma_kmer_count_batch", "kgma_kmer_dist_batch", "kgma_step_begin", "kgma_step_end",
+    "kgma_kmer_count_batch", "kgma_kmer_dist_batch", "kgma_step_begin", "kgma_step_end", "kgma_set_reserved_cus",
 ]
 
 
@@ -130,6 +130,7 @@ def load():
     L.kgma_get_dip_last_min.argtypes = [vp, P(i64), i64, P(i64)]
     L.kgma_replay_dips.argtypes = [vp, i32, i64, i64, C.c_uint32, i64, P(i64), P(i64), P(KgmaDip), P(i64), i64, ALIGN_FN, vp]
     L.kgma_host_semiglobal_cigar.argtypes = [C.c_char_p, i64, C.c_char_p, i64, i32, i32, C.c_char_p, i64, P(i64)]
+    L.kgma_set_reserved_cus.argtypes = [vp, i32]
     L.kgma_step_begin.argtypes = [vp, vp, i32, i64, i64, C.c_uint32]
     L.kgma_step_end.argtypes = [vp, P(KgmaHit), i64, P(i64)]
     L.kgma_kmer_count_batch.argtypes = [vp, i32, C.c_char_p, P(i64), i64, P(dbl)]
@@ -429,6 +430,10 @@ class Context:
             st = load().kgma_get_hits(self._h, self._step_ptr, buf.size, C.byref(self._step_n))
         self._check(st)
         return buf[:self._step_n.value]
+
+    def set_reserved_cus(self, n: int) -> None:
+        """Leave `n` CUs free of scan workgroups (kgma_set_reserved_cus): for callers that run a collective beside the scan."""
+        self._check(load().kgma_set_reserved_cus(self._h, int(n)))
 
     def step_begin(self, genome: "Genome", mode: int, buff: int = 50, genome_pos: int = 0, flags: int = 0) -> None:
         """First half of step_hits (kgma_step_begin): the step runs on the context's helper thread while the

@@ -629,3 +629,23 @@ def test_dip_dense_records_export_and_overflow(alp_ref, force_kernel):
             assert [hit_key(h) for h in hits2] == [hit_key(h) for h in ohi]
         finally:
             c.close()
+
+
+def test_reserved_cus_change_geometry_not_results(alp_ref, genes):
+    """kgma_set_reserved_cus: the stream kernel leaves CUs free for a collective that runs beside it; the streams
+    get longer, the results stay bit-identical."""
+    rng = np.random.default_rng(5)
+    contigs, _ = make_genome(rng, [14_000_000, 500, 3_000_000], genes, n_plants_per_mb=20)
+    c = _lib.Context(0)
+    try:
+        h0, _, D0, s0, _ = _scan_single(c, contigs, alp_ref, 30.0, no_tie_resolve=True)
+        c.set_reserved_cus(8)
+        h1, _, D1, s1, _ = _scan_single(c, contigs, alp_ref, 30.0, no_tie_resolve=True)
+        assert c.kernel_name().startswith("stream_kernel")
+        assert s0["n_tiles"] > 248 * 16 >= s1["n_tiles"]      # one stream per wave slot: 16 waves per CU at k = 6
+        assert [hit_key(h) for h in h0] == [hit_key(h) for h in h1] and [h["D"] for h in h0] == [h["D"] for h in h1]
+        assert np.array_equal(D0, D1)
+        with pytest.raises(_lib.KgmaError):
+            c.set_reserved_cus(200)
+    finally:
+        c.close()
