@@ -68,8 +68,10 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) * 1e3 / steps
 
-    for mode in ("none", "blocking", "pipelined", "async", "none", "async"):
-        print(f"{mode:10s} {run(mode):.4f} ms/step", flush=True)
+    for reserved in (0, 8):                       # kgma_set_reserved_cus: CUs left free for the collective
+        ctx.set_reserved_cus(reserved)
+        for mode in ("none", "blocking", "pipelined", "async", "none", "async"):
+            print(f"reserved CUs {reserved}: {mode:10s} {run(mode):.4f} ms/step", flush=True)
     genome.free()
     ctx.close()
     dist.destroy_process_group()
