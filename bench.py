@@ -99,7 +99,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)          # 0.1 s: the first ~100 steps run below the steady clocks
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=150)
     ap.add_argument("--length", type=int, default=0, help="record length per rank (default chr22-size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
