@@ -60,8 +60,20 @@ enum {
 enum {
     KGMA_F_RETURN_DISTS = 1u << 0,  /* do_return_dists: keep the per-window distances on the device
                                        for kgma_get_dists (8 B per window per KFV)                   */
-    KGMA_F_NO_TIE_RESOLVE = 1u << 1 /* keep exact-arithmetic tie-breaking (first tied window) instead of
+    KGMA_F_NO_TIE_RESOLVE = 1u << 1,/* keep exact-arithmetic tie-breaking (first tied window) instead of
                                        replaying the reference's Float64 rounding over tied minima   */
+    KGMA_F_CHAIN_REPLAY = 1u << 2   /* (kgma_scan) decide every rounding-dependent choice the way the
+                                       reference's running Float64 value does: for each (record, KFV) in
+                                       which exact arithmetic has a tie -- equal minima, a minimum equal
+                                       to the stale running minimum, a window exactly at the threshold --
+                                       the host re-runs the reference's Float64 update from the record's
+                                       first window (GenomeMiner.jl:46-47,70-77) on its threads and takes
+                                       the decisions from those values.  Costs host time per flagged
+                                       record (about 2 ns per window and KFV; kgma_stats.chain_ms); no dip
+                                       is left KGMA_HIT_TIE / KGMA_HIT_AT_THRESHOLD.  The first window's
+                                       sqeuclidean is summed left to right (Julia leaves the order of its
+                                       @simd reduction to the machine).  Ignored with KGMA_F_NO_TIE_RESOLVE
+                                       and by kgma_replay_dips (no residues on that rank).             */
 };
 
 /* flags in kgma_hit.flags / kgma_dip.flags */
@@ -73,9 +85,12 @@ enum {
                                       within a relative 2^-30 of thr (the guard band described at
                                       kgma_set_refs): whether the reference sees it below thr is
                                       Float64 rounding noise; the library counts it as NOT below       */
-    KGMA_HIT_TIE_RESOLVED = 1u << 2 /* a tie of the kind above, decided the way the reference's Float64
+    KGMA_HIT_TIE_RESOLVED = 1u << 2,/* a tie of the kind above, decided the way the reference's Float64
                                       update decides it (host replay over the tied stretch; the order is
                                       independent of the chain's history, see kgma_api.cpp)           */
+    KGMA_HIT_CHAIN = 1u << 3        /* the dip belongs to a (record, KFV) pair decided by the Float64 chain
+                                      replay (KGMA_F_CHAIN_REPLAY): window choice, threshold side and
+                                      kgma_hit.dist are the reference's running Float64 value          */
 };
 
 typedef struct kgma_ctx kgma_ctx;
@@ -121,6 +136,9 @@ typedef struct {
     double replay_ms;          /* host time of the hit state machine                            */
     int64_t device_bytes;      /* device memory held by the context + current genome            */
     int32_t n_tiles, n_launches;
+    double chain_ms;           /* host time of the Float64 chain replay (KGMA_F_CHAIN_REPLAY), 0 if none ran   */
+    int64_t n_chain_pairs;     /* (record, KFV) pairs it re-ran                                                */
+    int64_t chain_windows;     /* windows it walked (sum over the pairs)                                       */
 } kgma_stats;
 
 /* Host-side stand-in for `pairalign` + `cigar_to_UnitRange` (src/Alignment.jl:33-52,

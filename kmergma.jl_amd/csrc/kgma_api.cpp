@@ -26,6 +26,7 @@
 
 #include "../../include/kgma.h"
 #include "kgma_device.h"
+#include "kgma_chain.h"
 
 namespace kgma {
 hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc *cd, int n_contigs,
@@ -117,6 +118,7 @@ struct StepWorker {
 struct kgma_ctx {
     StepWorker *worker = nullptr;
     int device = 0;
+    int n_cus = 256;                                     // hipDeviceAttributeMultiprocessorCount (CPX / partitioned modes expose fewer)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evp0 = nullptr, evp1 = nullptr;
     std::string err;
@@ -156,6 +158,12 @@ struct kgma_ctx {
     std::vector<kgma_dip> dips;
     std::vector<int64_t> dip_argl;           // last window attaining the minimum (parallel to dips)
     std::vector<int64_t> dip_aux;            // byte offset of the dip's tied-stretch residues in the aux copy, or -1
+    // Float64 chain replay (KGMA_F_CHAIN_REPLAY, kgma_chain.cpp)
+    struct AttWin { int32_t contig, kfv; int64_t pos; };   // kfv 0-based
+    std::vector<AttWin> att;                 // tested windows inside the threshold guard band, sorted by (record, KFV, window)
+    std::vector<uint8_t> chain_pair;         // [m][records]: this (record, KFV) was decided by the chain replay
+    std::vector<double> firstF;              // [m][records]: chain value of the first window (chain pairs only)
+    std::vector<double> dip_fmin, dip_fexit; // parallel to dips: chain values of the minimum / the exit window (chain pairs only)
     const uint8_t *aux_host = nullptr;       // aux region of the last scan (pinned staging)
     unsigned int aux_used = 0;
     std::vector<kgma_hit> hits;
@@ -228,12 +236,31 @@ uint32_t stream_index_of(uint32_t v, int k)
 }
 
 // The scan is latency-critical (a chr22-size step is ~0.3 ms): poll the stream instead of sleeping in
-// hipStreamSynchronize (interrupt wake-up costs 10-20 us per synchronisation).
+// hipStreamSynchronize (interrupt wake-up costs 10-20 us per synchronisation).  The poll is bounded: after
+// 2 ms of spinning the thread yields between polls (a long scan does not burn a core), and after
+// KGMA_SYNC_TIMEOUT_S seconds (default 600) it gives up with hipErrorLaunchTimeOut -- the caller gets
+// KGMA_E_HIP, the stream is left as it is for kgma_destroy, nothing is re-executed.
+double sync_timeout_ms()
+{
+    static const double v = [] {
+        const char *e = getenv("KGMA_SYNC_TIMEOUT_S");
+        const double s = e ? atof(e) : 600.0;
+        return (s > 0 ? s : 600.0) * 1e3;
+    }();
+    return v;
+}
+
 hipError_t sync_spin(hipStream_t st)
 {
-    for (;;) {
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    for (int it = 0;; it++) {
         const hipError_t e = hipStreamQuery(st);
         if (e != hipErrorNotReady) return e;
+        if ((it & 63) != 63) continue;
+        const double ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+        if (ms > sync_timeout_ms()) return hipErrorLaunchTimeOut;
+        if (ms > 2.0) std::this_thread::sleep_for(std::chrono::microseconds(ms > 50.0 ? 200 : 20));
     }
 }
 
@@ -346,6 +373,10 @@ int kgma_create(int device_ordinal, kgma_ctx **out)
     kgma_ctx *ctx = new (std::nothrow) kgma_ctx();
     if (!ctx) return KGMA_E_NOMEM;
     ctx->device = device_ordinal;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0) ctx->n_cus = cus;
+    }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreate(&ctx->evp0) != hipSuccess || hipEventCreate(&ctx->evp1) != hipSuccess) {
@@ -574,7 +605,11 @@ int kgma_step_end(kgma_ctx *ctx, kgma_hit *out, int64_t cap, int64_t *n)
     if (!ctx || !n) return KGMA_E_ARG;
     StepWorker *w = ctx->worker;
     if (!w || w->state.load(std::memory_order_acquire) == 0) return fail(ctx, KGMA_E_STATE, "kgma_step_end without kgma_step_begin");
-    while (w->state.load(std::memory_order_acquire) != 2) { /* the caller would otherwise poll the stream itself */ }
+    {   // the caller would otherwise poll the stream itself; after 2 ms the poll yields between looks
+        const double t0 = now_ms();
+        for (int it = 0; w->state.load(std::memory_order_acquire) != 2; it++)
+            if ((it & 255) == 255 && now_ms() - t0 > 2.0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
     const int rc = w->rc;
     w->state.store(0, std::memory_order_release);
     if (rc) return rc;
@@ -584,7 +619,7 @@ int kgma_step_end(kgma_ctx *ctx, kgma_hit *out, int64_t cap, int64_t *n)
 int kgma_set_reserved_cus(kgma_ctx *ctx, int32_t n)
 {
     if (!ctx) return KGMA_E_ARG;
-    if (n < 0 || n > 128) return fail(ctx, KGMA_E_ARG, "reserved CUs must be 0..128");
+    if (n < 0 || n > ctx->n_cus / 2) return fail(ctx, KGMA_E_ARG, "reserved CUs must be 0..%d (half of the device's %d CUs)", ctx->n_cus / 2, ctx->n_cus);
     ctx->reserved_cus = n;
     return KGMA_OK;
 }
@@ -1145,6 +1180,13 @@ int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
     ctx->dips.clear();
     ctx->dip_argl.clear();
     ctx->dip_aux.clear();
+    ctx->att.clear();
+    ctx->chain_pair.clear();
+    ctx->firstF.clear();
+    ctx->dip_fmin.clear();
+    ctx->dip_fexit.clear();
+    for (const Frag &f : fr)                                   // (sorted by record, KFV, window)
+        if (f.kind == REC_ATT) ctx->att.push_back(kgma_ctx::AttWin{f.contig, f.kfv, f.start});
     int64_t n_tie = 0;
     size_t i = 0;
     const size_t n = fr.size();
@@ -1250,7 +1292,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         }
     const int64_t nc = g->n_contigs;
     const bool want_dists = (flags & KGMA_F_RETURN_DISTS) != 0;
-    const int geom_version = use_stream ? 2 + 16 * ctx->reserved_cus : 1;
+    const int geom_version = use_stream ? 2 + 16 * ctx->reserved_cus + 16 * 1024 * ctx->n_cus : 1;
     snprintf(ctx->kernel_name, sizeof ctx->kernel_name, use_stream ? "stream_kernel<%d>" : "scan_kernel<%d>", k);   // (+ pos_kernel for multi-KFV groups)
 
     ctx->dips.clear();
@@ -1296,7 +1338,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         // chip (256 CUs x waves per workgroup) a whole number of equally long streams
         int64_t P;
         if (use_stream) {
-            const int64_t slots = (int64_t)(256 - ctx->reserved_cus) * stream_nw;      // (kgma_set_reserved_cus)
+            const int64_t slots = (int64_t)std::max(1, ctx->n_cus - ctx->reserved_cus) * stream_nw;      // (kgma_set_reserved_cus)
             const int64_t rounds = std::max<int64_t>(1, (total_nwin + slots * KGMA_STREAM_MAX_WINDOWS - 1) / (slots * KGMA_STREAM_MAX_WINDOWS));
             P = (total_nwin + slots * rounds - 1) / (slots * rounds);
             P = ((P + 63) / 64) * 64;
@@ -1374,6 +1416,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         ctx->D0.assign((size_t)ctx->m, -1);
         ctx->firstD.assign((size_t)ctx->m * (size_t)nc, -1);
         ctx->dips.clear(); ctx->dip_argl.clear(); ctx->dip_aux.clear();
+        ctx->att.clear(); ctx->chain_pair.clear(); ctx->firstF.clear(); ctx->dip_fmin.clear(); ctx->dip_fexit.clear();
         ctx->last_mode = mode;
         ctx->have_dists = want_dists;
         return KGMA_OK;
@@ -1788,13 +1831,18 @@ static int replay_hits(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_
             int64_t currmin_pos = 1;                                   // window whose value currminim holds
             bool stop = true;
             uint32_t cur_flags = 0;
+            // a record decided by the Float64 chain replay compares the chain's values, like the reference
+            const bool ch = !ctx->chain_pair.empty() && ctx->chain_pair[(size_t)c] != 0;
+            double currmin_f = ch ? ctx->firstF[(size_t)c] : 0.0;
             while (di < ctx->dips.size() && ctx->dips[di].contig < c) di++;
             for (; di < ctx->dips.size() && ctx->dips[di].contig == c; di++) {
                 kgma_dip &d = ctx->dips[di];
-                bool improved = d.D_min < currmin;                     // :83-87 (strict running minimum)
+                bool improved = ch ? ctx->dip_fmin[di] < currmin_f : d.D_min < currmin;   // :83-87 (strict running minimum)
                 int64_t best_pos = d.argmin;
                 uint32_t dflags = d.flags;
-                if (resolve && improved && (d.flags & KGMA_HIT_TIE)) {
+                if (ch) {
+                    // nothing to decide: argmin is the first window attaining the chain's minimum
+                } else if (resolve && improved && (d.flags & KGMA_HIT_TIE)) {
                     // (A) several separated windows attain the dip's minimum
                     const TieResolver::Result r = tr.replay(0, c, d.argmin, d.D_min, d.argmin, ctx->dip_argl[di], d.D_min, false, tr.prefetched(di));
                     if (r.ok && !r.sensitive) {
@@ -1816,6 +1864,7 @@ static int replay_hits(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_
                 d.flags = dflags;
                 if (improved) {
                     currmin = d.D_min;
+                    if (ch) currmin_f = ctx->dip_fmin[di];
                     currmin_pos = best_pos;
                     d.argmin = best_pos;
                     CMI = best_pos + k - 2;                            // i_left of the best window
@@ -1834,10 +1883,11 @@ static int replay_hits(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_
                         kgma_hit h;
                         memset(&h, 0, sizeof h);
                         h.contig = (int32_t)c; h.kfv = 0; h.cmi = CMI; h.lo = lo; h.hi = hi;
-                        h.genome_pos = genome_pos; h.D = currmin; h.dist = (double)currmin / scale;
+                        h.genome_pos = genome_pos; h.D = currmin; h.dist = ch ? currmin_f : (double)currmin / scale;
                         h.flags = cur_flags | (d.flags & KGMA_HIT_AT_THRESHOLD);
                         ctx->hits.push_back(h);
                         currmin = d.D_exit;                            // :102
+                        if (ch) currmin_f = ctx->dip_fexit[di];
                         currmin_pos = d.exit_pos;
                     }
                 }
@@ -1852,6 +1902,8 @@ static int replay_hits(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_
         std::vector<uint32_t> cflags((size_t)m);
         std::vector<kgma_dip *> evs;
         std::vector<int64_t> min_pos((size_t)m, 1);
+        std::vector<double> curr_mins_f((size_t)m, 0.0);
+        std::vector<char> chj((size_t)m, 0);
         for (int64_t c = 0; c < nc; c++) {
             const int64_t L = ctx->contig_len[(size_t)c];
             while (di < ctx->dips.size() && ctx->dips[di].contig < c) di++;
@@ -1860,6 +1912,8 @@ static int replay_hits(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_
                 for (int j = 0; j < m; j++) {                          // :61-82
                     curr_mins[(size_t)j] = ctx->firstD[(size_t)j * (size_t)nc + (size_t)c];
                     CMIs[(size_t)j] = 1; stops[(size_t)j] = 1; cflags[(size_t)j] = 0; min_pos[(size_t)j] = 1;
+                    chj[(size_t)j] = !ctx->chain_pair.empty() && ctx->chain_pair[(size_t)j * (size_t)nc + (size_t)c] != 0;
+                    curr_mins_f[(size_t)j] = chj[(size_t)j] ? ctx->firstF[(size_t)j * (size_t)nc + (size_t)c] : 0.0;
                 }
                 evs.clear();
                 for (; di < ctx->dips.size() && ctx->dips[di].contig == c; di++) evs.push_back(&ctx->dips[di]);
@@ -1874,10 +1928,13 @@ static int replay_hits(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_
                     const int j = d.kfv - 1;
                     const KfvInfo &f = ctx->kfv[(size_t)j];
                     const size_t dix = (size_t)(dp - ctx->dips.data());
-                    bool improved = d.D_min < curr_mins[(size_t)j];    // :114-119
+                    const bool ch = chj[(size_t)j] != 0;
+                    bool improved = ch ? ctx->dip_fmin[dix] < curr_mins_f[(size_t)j] : d.D_min < curr_mins[(size_t)j];    // :114-119
                     int64_t best_pos = d.argmin;
                     uint32_t dflags = d.flags;
-                    if (resolve && improved && (d.flags & KGMA_HIT_TIE)) {
+                    if (ch) {
+                        // decided by the Float64 chain replay
+                    } else if (resolve && improved && (d.flags & KGMA_HIT_TIE)) {
                         const TieResolver::Result r = tr.replay(j, c, d.argmin, d.D_min, d.argmin, ctx->dip_argl[dix], d.D_min, false, tr.prefetched(dix));
                         if (r.ok && !r.sensitive) {
                             best_pos = r.pos;
@@ -1897,6 +1954,7 @@ static int replay_hits(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_
                     d.flags = dflags;
                     if (improved) {
                         curr_mins[(size_t)j] = d.D_min;
+                        if (ch) curr_mins_f[(size_t)j] = ctx->dip_fmin[dix];
                         min_pos[(size_t)j] = best_pos;
                         d.argmin = best_pos;
                         CMIs[(size_t)j] = best_pos - 1;                // i = window start - 1
@@ -1916,11 +1974,12 @@ static int replay_hits(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_
                                 memset(&h, 0, sizeof h);
                                 h.contig = (int32_t)c; h.kfv = j + 1; h.cmi = CMI; h.lo = lo; h.hi = hi;
                                 h.genome_pos = genome_pos; h.D = curr_mins[(size_t)j];
-                                h.dist = (double)h.D / (2.0 * (double)k * (double)f.N * (double)f.N);
+                                h.dist = ch ? curr_mins_f[(size_t)j] : (double)h.D / (2.0 * (double)k * (double)f.N * (double)f.N);
                                 h.flags = cflags[(size_t)j] | (d.flags & KGMA_HIT_AT_THRESHOLD);
                                 ctx->hits.push_back(h);
                                 prev_lo = lo; prev_hi = hi;            // :152
                                 curr_mins[(size_t)j] = d.D_exit;       // :153
+                                if (ch) curr_mins_f[(size_t)j] = ctx->dip_fexit[dix];
                                 min_pos[(size_t)j] = d.exit_pos;
                             }
                         }
@@ -1938,11 +1997,228 @@ static int replay_hits(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_
     return KGMA_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Float64 chain replay (KGMA_F_CHAIN_REPLAY): for the (record, KFV) pairs in which exact arithmetic leaves a
+// decision to the rounding of the reference's running Float64 value, re-run that value from the record's
+// first window (kgma_chain.cpp, host threads) and rebuild the pair's dips from the chain's values at the
+// windows the device scan found -- every dip of the pair and every window inside the threshold guard band.
+// A pair is selected when (1) one of its dips still carries KGMA_HIT_TIE after the local tie resolver or
+// KGMA_HIT_AT_THRESHOLD, (2) it has a tested window inside the guard band, or (3) two of its dips (or a
+// dip and the first window) have the same exact minimum -- the superset of "a dip's minimum equals the
+// stale running minimum" (GenomeMiner.jl:93-103), which is only known once the hit state machine runs.
+// Every other pair has no exact tie anywhere, so exact arithmetic and the chain decide alike.
+// ------------------------------------------------------------------------------------------
+static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
+{
+    const double t0 = now_ms();
+    const int k = ctx->k, m = ctx->m;
+    const int64_t nc = (int64_t)ctx->contig_len.size();
+    ctx->stats.chain_ms = 0; ctx->stats.n_chain_pairs = 0; ctx->stats.chain_windows = 0;
+    // (A) ties inside one dip are decided where that is provably independent of the chain's history
+    {
+        TieResolver tr{ctx, g, {}, {}, {}, nullptr, {}, {}};
+        tr.prefetch();
+        for (size_t i = 0; i < ctx->dips.size(); i++) {
+            kgma_dip &d = ctx->dips[i];
+            if (!(d.flags & KGMA_HIT_TIE)) continue;
+            const TieResolver::Result r = tr.replay(d.kfv - 1, d.contig, d.argmin, d.D_min, d.argmin, ctx->dip_argl[i], d.D_min, false,
+                                                    tr.prefetched(i));
+            if (r.ok && !r.sensitive) {
+                d.argmin = r.pos;
+                d.flags = (d.flags & ~(uint32_t)KGMA_HIT_TIE) | KGMA_HIT_TIE_RESOLVED;
+            }
+        }
+    }
+    // ---- select the pairs ------------------------------------------------------------------
+    struct Pair { int32_t c, j; size_t d0, d1, a0, a1; std::vector<ChainInterval> iv; std::vector<double> val; int64_t last; };
+    std::vector<Pair> pairs;
+    {
+        size_t di = 0, ai = 0;
+        const size_t nd = ctx->dips.size(), na = ctx->att.size();
+        std::vector<int64_t> mins;
+        while (di < nd || ai < na) {
+            int32_t c, j;
+            const bool dip_first = di < nd && (ai >= na || ctx->dips[di].contig < ctx->att[ai].contig ||
+                                               (ctx->dips[di].contig == ctx->att[ai].contig && ctx->dips[di].kfv - 1 <= ctx->att[ai].kfv));
+            if (dip_first) { c = ctx->dips[di].contig; j = ctx->dips[di].kfv - 1; }
+            else { c = ctx->att[ai].contig; j = ctx->att[ai].kfv; }
+            Pair p{c, j, di, di, ai, ai, {}, {}, 0};
+            while (p.d1 < nd && ctx->dips[p.d1].contig == c && ctx->dips[p.d1].kfv - 1 == j) p.d1++;
+            while (p.a1 < na && ctx->att[p.a1].contig == c && ctx->att[p.a1].kfv == j) p.a1++;
+            di = p.d1; ai = p.a1;
+            bool need = p.a1 > p.a0;
+            mins.clear();
+            mins.push_back(ctx->firstD[(size_t)j * (size_t)nc + (size_t)c]);
+            for (size_t u = p.d0; u < p.d1; u++) {
+                if (ctx->dips[u].flags & (KGMA_HIT_TIE | KGMA_HIT_AT_THRESHOLD)) need = true;
+                mins.push_back(ctx->dips[u].D_min);
+            }
+            if (!need) {
+                std::sort(mins.begin(), mins.end());
+                need = std::adjacent_find(mins.begin(), mins.end()) != mins.end();
+            }
+            if (need) pairs.push_back(std::move(p));
+        }
+    }
+    ctx->dip_fmin.assign(ctx->dips.size(), 0.0);
+    ctx->dip_fexit.assign(ctx->dips.size(), 0.0);
+    ctx->chain_pair.assign((size_t)m * (size_t)nc, 0);
+    ctx->firstF.assign((size_t)m * (size_t)nc, 0.0);
+    if (pairs.empty()) { ctx->stats.chain_ms = now_ms() - t0; return KGMA_OK; }
+
+    // ---- sample windows of every pair: its dips (start .. exit) and its guard-band windows (+ the next) ----
+    for (Pair &p : pairs) {
+        const int64_t nwin = ctx->contig_nwin[(size_t)p.c];
+        std::vector<ChainInterval> iv;
+        iv.push_back(ChainInterval{1, 1});
+        for (size_t u = p.d0; u < p.d1; u++) {
+            const kgma_dip &d = ctx->dips[u];
+            iv.push_back(ChainInterval{d.start, d.exit_pos ? d.exit_pos : d.end});
+        }
+        for (size_t u = p.a0; u < p.a1; u++) iv.push_back(ChainInterval{ctx->att[u].pos, std::min<int64_t>(ctx->att[u].pos + 1, nwin)});
+        std::sort(iv.begin(), iv.end(), [](const ChainInterval &a, const ChainInterval &b) { return a.lo < b.lo; });
+        for (const ChainInterval &x : iv) {
+            if (!p.iv.empty() && x.lo <= p.iv.back().hi + 1) p.iv.back().hi = std::max(p.iv.back().hi, x.hi);
+            else p.iv.push_back(x);
+        }
+        int64_t n = 0;
+        for (const ChainInterval &x : p.iv) n += x.hi - x.lo + 1;
+        p.val.assign((size_t)n, 0.0);
+        p.last = p.iv.back().hi;
+        if (p.iv.front().lo < 1 || p.last > nwin) return fail(ctx, KGMA_E_HIP, "internal: chain replay window outside record %d", p.c);
+    }
+
+    // ---- run the chains, records in batches of bounded host memory ---------------------------
+    int n_threads = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("KGMA_CHAIN_THREADS")) n_threads = atoi(e);
+    n_threads = std::max(1, std::min(n_threads, 64));
+    (void)hipSetDevice(ctx->device);
+    const int64_t BATCH_BYTES = (int64_t)2 << 30;
+    size_t pi = 0;
+    int64_t windows = 0;
+    while (pi < pairs.size()) {
+        std::vector<std::vector<uint8_t>> bufs;
+        std::vector<ChainJob> jobs;
+        int64_t bytes = 0;
+        size_t pj = pi;
+        while (pj < pairs.size() && (pj == pi || bytes < BATCH_BYTES)) {
+            // all pairs of one record share its residues
+            const int32_t c = pairs[pj].c;
+            size_t pe = pj;
+            int64_t need = 0;
+            while (pe < pairs.size() && pairs[pe].c == c) {
+                need = std::max(need, ctx->kfv[(size_t)pairs[pe].j].W + pairs[pe].last - 1);
+                pe++;
+            }
+            need = std::min(need, g->cd[(size_t)c].len);
+            bufs.emplace_back((size_t)need);
+            if (hipMemcpy(bufs.back().data(), g->d_ascii + g->cd[(size_t)c].ascii_off, (size_t)need, hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(ctx, KGMA_E_HIP, "chain replay: cannot read the residues of record %d", c);
+            for (size_t u = pj; u < pe; u++) {
+                Pair &p = pairs[u];
+                ChainJob J;
+                J.seq = bufs.back().data(); J.n_res = need; J.ref = ctx->kfv[(size_t)p.j].ref.data(); J.k = k;
+                J.W = ctx->kfv[(size_t)p.j].W; J.last_window = p.last; J.iv = p.iv.data(); J.n_iv = p.iv.size();
+                J.out = p.val.data(); J.n_out = 0; J.ok = false;
+                jobs.push_back(J);
+                windows += p.last;
+            }
+            bytes += need;
+            pj = pe;
+        }
+        run_chain_jobs(jobs.data(), jobs.size(), n_threads);
+        for (size_t u = 0; u < jobs.size(); u++)
+            if (!jobs[u].ok || jobs[u].n_out != (int64_t)pairs[pi + u].val.size())
+                return fail(ctx, KGMA_E_HIP, "internal: chain replay of record %d KFV %d failed", pairs[pi + u].c, pairs[pi + u].j + 1);
+        pi = pj;
+    }
+
+    // ---- rebuild the dips of the chain pairs from the chain values ---------------------------
+    struct DipX { kgma_dip d; int64_t argl, aux; double fmin, fexit; };
+    std::vector<DipX> all;
+    all.reserve(ctx->dips.size() + 16);
+    {
+        std::vector<char> replaced(ctx->dips.size(), 0);
+        for (const Pair &p : pairs)
+            for (size_t u = p.d0; u < p.d1; u++) replaced[u] = 1;
+        for (size_t u = 0; u < ctx->dips.size(); u++)
+            if (!replaced[u]) all.push_back(DipX{ctx->dips[u], ctx->dip_argl[u], ctx->dip_aux[u], 0.0, 0.0});
+    }
+    for (const Pair &p : pairs) {
+        const KfvInfo &f = ctx->kfv[(size_t)p.j];
+        const double scale = 2.0 * (double)k * (double)f.N * (double)f.N;
+        const int64_t nwin = ctx->contig_nwin[(size_t)p.c];
+        ctx->chain_pair[(size_t)p.j * (size_t)nc + (size_t)p.c] = 1;
+        ctx->firstF[(size_t)p.j * (size_t)nc + (size_t)p.c] = p.val[0];
+        bool in_run = false;
+        DipX cur{};
+        int64_t prev_w = 0;
+        size_t vi = 0;
+        auto close_run = [&](int64_t exit_pos, double fexit) {
+            cur.d.exit_pos = exit_pos;
+            cur.fexit = fexit;
+            cur.d.D_exit = exit_pos ? (int64_t)std::llround(fexit * scale) : 0;
+            cur.d.D_min = (int64_t)std::llround(cur.fmin * scale);
+            cur.argl = cur.d.argmin;
+            all.push_back(cur);
+            in_run = false;
+        };
+        for (const ChainInterval &x : p.iv) {
+            for (int64_t w = x.lo; w <= x.hi; w++, vi++) {
+                const double v = p.val[vi];
+                const bool under = w >= 2 && v < f.thr;            // GenomeMiner.jl:82 / OmnGenomeMiner.jl:113 (the first window is never tested)
+                if (in_run && w != prev_w + 1)                     // a run never reaches the end of a sampled interval
+                    return fail(ctx, KGMA_E_HIP, "internal: chain replay lost the exit of a dip (record %d KFV %d window %lld)", p.c, p.j + 1, (long long)prev_w);
+                if (under) {
+                    if (!in_run) {
+                        in_run = true;
+                        memset(&cur.d, 0, sizeof cur.d);
+                        cur.d.contig = p.c; cur.d.kfv = p.j + 1; cur.d.start = w; cur.d.argmin = w;
+                        cur.d.flags = KGMA_HIT_CHAIN;
+                        cur.fmin = v; cur.aux = -1;
+                    } else if (v < cur.fmin) { cur.fmin = v; cur.d.argmin = w; }   // strict: the first window attaining the minimum
+                    cur.d.end = w;
+                } else if (in_run) {
+                    close_run(w, v);
+                }
+                prev_w = w;
+            }
+        }
+        if (in_run) {
+            if (prev_w != nwin)
+                return fail(ctx, KGMA_E_HIP, "internal: chain replay lost the exit of a dip (record %d KFV %d window %lld)", p.c, p.j + 1, (long long)prev_w);
+            close_run(0, 0.0);                                         // still open at the record end: dropped by the state machine
+        }
+    }
+    std::stable_sort(all.begin(), all.end(), [](const DipX &a, const DipX &b) {
+        if (a.d.contig != b.d.contig) return a.d.contig < b.d.contig;
+        if (a.d.kfv != b.d.kfv) return a.d.kfv < b.d.kfv;
+        return a.d.start < b.d.start;
+    });
+    const size_t n = all.size();
+    ctx->dips.resize(n); ctx->dip_argl.resize(n); ctx->dip_aux.resize(n); ctx->dip_fmin.resize(n); ctx->dip_fexit.resize(n);
+    for (size_t u = 0; u < n; u++) {
+        ctx->dips[u] = all[u].d; ctx->dip_argl[u] = all[u].argl; ctx->dip_aux[u] = all[u].aux;
+        ctx->dip_fmin[u] = all[u].fmin; ctx->dip_fexit[u] = all[u].fexit;
+    }
+    ctx->stats.n_dips = (int64_t)n;
+    ctx->stats.n_chain_pairs = (int64_t)pairs.size();
+    ctx->stats.chain_windows = windows;
+    ctx->stats.chain_ms = now_ms() - t0;
+    (void)mode;
+    return KGMA_OK;
+}
+
 int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, int64_t genome_pos0,
               uint32_t flags, kgma_align_fn align, void *align_user)
 {
-    const int rc = kgma_scan_device(ctx, g, mode, flags);
+    int rc = kgma_scan_device(ctx, g, mode, flags);
     if (rc) return rc;
+    ctx->stats.chain_ms = 0; ctx->stats.n_chain_pairs = 0; ctx->stats.chain_windows = 0;
+    if ((flags & KGMA_F_CHAIN_REPLAY) && !(flags & KGMA_F_NO_TIE_RESOLVE)) {
+        rc = chain_decide(ctx, g, mode);
+        if (rc) return rc;
+    }
     return replay_hits(ctx, g, mode, buff, genome_pos0, flags, align, align_user);
 }
 
@@ -2008,6 +2284,7 @@ int kgma_replay_dips(kgma_ctx *ctx, int32_t mode, int64_t buff, int64_t genome_p
     ctx->dips.assign(dips, dips + n_dips);
     ctx->dip_argl.assign(dip_last_min, dip_last_min + n_dips);
     ctx->dip_aux.assign((size_t)n_dips, -1);
+    ctx->att.clear(); ctx->chain_pair.clear(); ctx->firstF.clear(); ctx->dip_fmin.clear(); ctx->dip_fexit.clear();
     for (int64_t i = 1; i < n_dips; i++) {
         const kgma_dip &a = dips[i - 1], &b = dips[i];
         const bool ordered = a.contig < b.contig || (a.contig == b.contig && (a.kfv < b.kfv || (a.kfv == b.kfv && a.start < b.start)));
@@ -2018,6 +2295,7 @@ int kgma_replay_dips(kgma_ctx *ctx, int32_t mode, int64_t buff, int64_t genome_p
             return fail(ctx, KGMA_E_ARG, "kgma_replay_dips: dip %lld refers to record %d / KFV %d", (long long)i, dips[i].contig, dips[i].kfv);
     ctx->tiles.clear();
     ctx->contig_tile_base.assign((size_t)n_records, -1);
+    ctx->tk_uid = 0;            // the scan's cached tile geometry is gone: the next scan rebuilds it
     ctx->have_dists = false;
     ctx->last_mode = mode;
     ctx->stats.n_dips = n_dips;
@@ -2051,7 +2329,8 @@ int kgma_get_first_window(kgma_ctx *ctx, int32_t kfv, int64_t *out, int64_t cap,
 {
     if (!ctx || !n) return KGMA_E_ARG;
     if (ctx->last_mode < 0) return fail(ctx, KGMA_E_STATE, "no scan has been run");
-    if (kfv < 1 || kfv > ctx->m) return fail(ctx, KGMA_E_ARG, "kfv %d out of range", kfv);
+    const int m_scanned = ctx->last_mode == KGMA_MODE_SINGLE ? 1 : ctx->m;      // the single engine evaluates KFV 1 only
+    if (kfv < 1 || kfv > m_scanned) return fail(ctx, KGMA_E_ARG, "kfv %d out of range (the last scan evaluated %d KFV(s))", kfv, m_scanned);
     const int64_t nc = (int64_t)ctx->contig_len.size();
     *n = nc;
     if (!out) return KGMA_OK;

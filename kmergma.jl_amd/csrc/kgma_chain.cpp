@@ -1,0 +1,131 @@
+// kgma_chain.cpp -- host-side Float64 chain replay: the tie decider of libkgma (KGMA_F_CHAIN_REPLAY).
+//
+// The device evaluates every window's distance in exact integers.  The reference keeps ONE running
+// Float64 value per record and KFV (src/GenomeMiner.jl:46-47,70-77; src/OmnGenomeMiner.jl:73-74,101-108)
+// and decides `kmerDist < thr` / `kmerDist < currminim` on that value, so where exact distances TIE
+// (equal minima, a minimum equal to the stale running minimum, a window exactly at the threshold) its
+// decision is the rounding the chain has accumulated since the record's first window.  For the
+// (record, KFV) pairs that contain such a tie, this module re-runs that chain -- the reference's update
+// in the reference's operation order, sequential IEEE-754 Float64 from the record's first window -- and
+// returns the chain values at the windows the host needs (every dip of the pair, every window at the
+// threshold); kgma_api.cpp then takes the reference's decisions from those values.  Pairs are
+// independent and run on a pool of host threads.
+//
+// Not a scan path: the windows to look at come from the device scan; nothing here finds dips by itself.
+// Stated convention: Distances.sqeuclidean (the first window's distance) is a `@simd` reduction whose
+// order Julia leaves to the machine; it is summed left to right here (exact, hence order-free, whenever
+// the KFV is dyadic, e.g. N a power of two).
+
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "kgma_chain.h"
+
+namespace kgma {
+
+namespace {
+
+struct CodeTable {
+    uint8_t c[256];
+    CodeTable()
+    {
+        memset(c, 3, sizeof c);                       // T, N (src/Consts.jl:22-28); other residues were rejected before
+        c[(int)'A'] = c[(int)'a'] = 0;
+        c[(int)'C'] = c[(int)'c'] = 1;
+        c[(int)'G'] = c[(int)'g'] = 2;
+    }
+};
+const CodeTable CODE;
+
+void chain_one(ChainJob &J)
+{
+    J.ok = false;
+    const int k = J.k;
+    const int64_t W = J.W, NB = (int64_t)1 << (2 * k);
+    const uint64_t mask = (uint64_t)NB - 1;
+    const int64_t last = J.last_window;
+    if (k < 1 || W < k || last < 1 || J.n_res < W + last - 1 || J.n_iv == 0) return;
+    const uint8_t *s = J.seq;
+    const double *ref = J.ref;
+    std::vector<int32_t> cnt((size_t)NB, 0);
+    // first window: kmer_count! (src/Kmers.jl:33-44) and the sqeuclidean call site (GenomeMiner.jl:46-47)
+    uint64_t km = 0;
+    for (int64_t i = 0; i < W; i++) {
+        km = ((km << 2) & mask) | CODE.c[s[i]];
+        if (i >= k - 1) cnt[(size_t)km]++;
+    }
+    double sq = 0.0;
+    for (int64_t x = 0; x < NB; x++) {
+        const double d = ref[x] - (double)cnt[(size_t)x];
+        sq += d * d;
+    }
+    const double SF = 1.0 / (double)k;                 // src/API.jl:86,204
+    double dist = (SF * 0.5) * sq;                     // GenomeMiner.jl:29,46-47 / OmnGenomeMiner.jl:73-74
+    uint64_t left = 0, right = 0;
+    for (int64_t i = 0; i < k - 1; i++) left = (left << 2) | CODE.c[s[i]];
+    for (int64_t i = W - k + 1; i < W; i++) right = (right << 2) | CODE.c[s[i]];
+
+    const ChainInterval *iv = J.iv;
+    size_t ii = 0;
+    double *o = J.out;
+    int64_t cur_lo = iv[0].lo, cur_hi = iv[0].hi;
+    auto sample = [&](int64_t w, double v) {
+        if (w < cur_lo) return;
+        *o++ = v;
+        if (w == cur_hi) {
+            ii++;
+            if (ii < J.n_iv) { cur_lo = iv[ii].lo; cur_hi = iv[ii].hi; }
+            else { cur_lo = INT64_MAX; cur_hi = INT64_MAX; }
+        }
+    };
+    sample(1, dist);
+    const uint8_t *pl = s + (k - 1), *pr = s + W;
+    for (int64_t w = 2; w <= last; w++) {              // roll window w-1 -> w  (GenomeMiner.jl:60-77)
+        left = ((left << 2) & mask) | CODE.c[*pl++];
+        right = ((right << 2) & mask) | CODE.c[*pr++];
+        if (left != right) {
+            const int32_t cl = cnt[(size_t)left], cr = cnt[(size_t)right];
+            double t = (double)(1 + cr);               // Int (single engine) or Float64 (cluster engine) counts: same value
+            t = t + ref[left];
+            t = t - ref[right];
+            t = t - (double)cl;
+            dist += SF * t;
+            cnt[(size_t)left] = cl - 1;
+            cnt[(size_t)right] = cr + 1;
+        }
+        sample(w, dist);
+    }
+    J.n_out = (int64_t)(o - J.out);
+    J.ok = true;
+}
+
+}  // namespace
+
+void run_chain_jobs(ChainJob *jobs, size_t n_jobs, int n_threads)
+{
+    if (n_jobs == 0) return;
+    if (n_threads < 1) n_threads = 1;
+    if ((size_t)n_threads > n_jobs) n_threads = (int)n_jobs;
+    if (n_threads == 1) {
+        for (size_t i = 0; i < n_jobs; i++) chain_one(jobs[i]);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_jobs) return;
+            chain_one(jobs[i]);
+        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)n_threads - 1);
+    for (int t = 1; t < n_threads; t++) pool.emplace_back(worker);
+    worker();
+    for (std::thread &th : pool) th.join();
+}
+
+}  // namespace kgma

@@ -19,8 +19,8 @@ KGMA_OK = 0
 KGMA_E_ARG, KGMA_E_NODEVICE, KGMA_E_HIP, KGMA_E_BADBASE, KGMA_E_BOUNDS = 1, 2, 3, 4, 5
 KGMA_E_UNSUPPORTED, KGMA_E_OVERFLOW, KGMA_E_NOMEM, KGMA_E_STATE = 6, 7, 8, 9
 MODE_SINGLE, MODE_OMN = 0, 1
-F_RETURN_DISTS, F_NO_TIE_RESOLVE = 1, 2
-HIT_TIE, HIT_AT_THRESHOLD, HIT_TIE_RESOLVED = 1, 2, 4
+F_RETURN_DISTS, F_NO_TIE_RESOLVE, F_CHAIN_REPLAY = 1, 2, 4
+HIT_TIE, HIT_AT_THRESHOLD, HIT_TIE_RESOLVED, HIT_CHAIN = 1, 2, 4, 8
 
 EXPORTS = [
     "kgma_version", "kgma_status_string", "kgma_last_error", "kgma_create", "kgma_destroy",
@@ -50,7 +50,8 @@ class KgmaStats(C.Structure):
     _fields_ = [("bases_scanned", C.c_int64), ("windows_scanned", C.c_int64), ("n_dips", C.c_int64),
                 ("n_hits", C.c_int64), ("n_tie_flagged", C.c_int64), ("n_at_threshold", C.c_int64),
                 ("pack_ms", C.c_double), ("scan_ms", C.c_double), ("replay_ms", C.c_double),
-                ("device_bytes", C.c_int64), ("n_tiles", C.c_int32), ("n_launches", C.c_int32)]
+                ("device_bytes", C.c_int64), ("n_tiles", C.c_int32), ("n_launches", C.c_int32),
+                ("chain_ms", C.c_double), ("n_chain_pairs", C.c_int64), ("chain_windows", C.c_int64)]
 
 
 HIT_DTYPE = np.dtype([("contig", "<i4"), ("kfv", "<i4"), ("cmi", "<i8"), ("lo", "<i8"), ("hi", "<i8"),

@@ -68,11 +68,19 @@ def test_config2_chr22_size_full_parity(ctx, refs):
     # default mode: ties decided like the reference's Float64 update
     ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)
     hits_f, dips_f = ctx.hits(), ctx.dips()
-    if [hit_key(h) for h in hits_f] != [hit_key(h) for h in ohits]:
-        assert any(d["flags"] & (_lib.HIT_TIE | _lib.HIT_AT_THRESHOLD) for d in dips_f)
-    for a, b in zip(hits_f, ohits):
-        if hit_key(a) == hit_key(b):
+    assert len(hits_f) == len(ohits)
+    for a, b in zip(hits_f, ohits):                       # per hit: identical, or stemming from a flagged dip
+        if hit_key(a) != hit_key(b):
+            assert a["flags"] & (_lib.HIT_TIE | _lib.HIT_AT_THRESHOLD)
+        else:
             assert abs(a["dist"] - b["dist"]) <= 1e-6 * b["dist"]
+    # chain replay: identical to the Float64 oracle, nothing left flagged
+    ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_CHAIN_REPLAY, None)
+    hits_c, st_c = ctx.hits(), ctx.stats()
+    assert [hit_key(h) for h in hits_c] == [hit_key(h) for h in ohits]
+    assert st_c["n_tie_flagged"] == 0
+    assert not any(d["flags"] & (_lib.HIT_TIE | _lib.HIT_AT_THRESHOLD) for d in ctx.dips())
+    print("chr22-size: chain pairs", st_c["n_chain_pairs"], "chain ms", round(st_c["chain_ms"], 1))
     assert len(hits) >= 40 and _assert_planted_found(hits, plants, W, k) >= 0.7 * len(plants)
     # idempotence: a second scan of the resident genome gives identical records
     ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_NO_TIE_RESOLVE, None)
@@ -106,12 +114,17 @@ def test_config3_grch38_size_full_parity(ctx, refs):
     g, plants, lens = workloads.make_grch38_like(ctx, refs["genes"], seed=38)
     ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)
     hits_f, dips_f = ctx.hits(), ctx.dips()
+    ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_CHAIN_REPLAY, None)
+    hits_c, dips_c, st_c = ctx.hits(), ctx.dips(), ctx.stats()
     ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_NO_TIE_RESOLVE, None)
     hits, st = ctx.hits(), ctx.stats()
     assert st["bases_scanned"] == sum(lens)
     seqs = _fetch_all(g, lens)
     g.free()
     ohits, _ = orc.single_scan(seqs, refs["RV"], k, W, 30.0, 50, hit_cap=1 << 18)
+    assert [hit_key(h) for h in hits_c] == [hit_key(h) for h in ohits]     # chain replay: identical, nothing flagged
+    assert st_c["n_tie_flagged"] == 0 and not any(d["flags"] & 3 for d in dips_c)
+    print("GRCh38-size: chain pairs", st_c["n_chain_pairs"], "chain ms", round(st_c["chain_ms"], 1))
     bad = [(a, b) for a, b in zip(hits_f, ohits) if hit_key(a) != hit_key(b)]
     assert len(hits_f) == len(ohits)
     for a, b in bad:
@@ -125,6 +138,103 @@ def test_config3_grch38_size_full_parity(ctx, refs):
     assert len(hits) >= 300 and _assert_planted_found(hits, plants, W, k) >= 0.7 * len(plants)
     # genome_pos bookkeeping over 25 records
     assert hits[-1]["genome_pos"] == sum(lens[:hits[-1]["contig"]])
+
+
+def test_config4_cluster_mode_default_and_chain_vs_float_oracle(ctx):
+    """configs[3] (cluster mode, 5 KFVs) on a 463 Mb stand-in (GRCh38 lengths x 0.15): the mode users get
+    (default, local tie resolver) and the chain-replay mode against the reference-order Float64 oracle.
+    The single-sequence clusters (N = 1: coarse distance lattice) make a quarter of the dips exact ties."""
+    import time
+    c = workloads.fixture_clusters(DATA, 6)
+    thr = [37, 33, 38, 34, 28]
+    ctx.set_refs(6, c["KFVs"], c["ws"], thr, c["N"])
+    from kmergma_amd import fasta
+    genes = [r.sequence.upper() for r in fasta.read_fasta(os.path.join(DATA, "Alp_V_ref.fasta"))]
+    g, plants, lens = workloads.make_grch38_like(ctx, genes, seed=45, n_plants=256, scale=0.15)
+    assert sum(lens) >= 400_000_000
+    ctx.scan(g, _lib.MODE_OMN, 100, 0, 0, None)
+    hits_f, dips_f, st_f = ctx.hits(), ctx.dips(), ctx.stats()
+    t0 = time.perf_counter()
+    ctx.scan(g, _lib.MODE_OMN, 100, 0, _lib.F_CHAIN_REPLAY, None)
+    t_chain = time.perf_counter() - t0
+    hits_c, dips_c, st_c = ctx.hits(), ctx.dips(), ctx.stats()
+    seqs = _fetch_all(g, lens)
+    g.free()
+    ohits, _ = orc.omn_scan(seqs, c["KFVs"], 6, c["ws"], thr, 100, 0, hit_cap=1 << 18)
+    kc, kf, ko = [hit_key(h) for h in hits_c], [hit_key(h) for h in hits_f], [hit_key(h) for h in ohits]
+    n_flagged = sum(1 for d in dips_f if d["flags"] & (_lib.HIT_TIE | _lib.HIT_AT_THRESHOLD))
+    n_diff_default = len(set(kf) ^ set(ko))
+    print(f"config 4 (463 Mb): {len(dips_f)} dips, {n_flagged} flagged in default mode, {n_diff_default} hits differ from the "
+          f"Float64 oracle in default mode; chain replay: {st_c['n_chain_pairs']} (record, KFV) pairs, "
+          f"{st_c['chain_windows'] / 1e6:.0f} M windows, {st_c['chain_ms']:.0f} ms of {t_chain * 1e3:.0f} ms; 0 differ")
+    assert kc == ko                                        # chain replay: identical to the reference-order oracle
+    assert st_c["n_tie_flagged"] == 0 and not any(d["flags"] & 3 for d in dips_c)
+    for a, b in zip(hits_c, ohits):
+        assert abs(a["dist"] - b["dist"]) <= 1e-6 * b["dist"]
+        if a["flags"] & _lib.HIT_CHAIN:
+            assert a["dist"] == b["dist"]
+    # default mode: the number of differing hits is bounded by the number of flagged dips, and no record
+    # without a flagged dip differs
+    assert n_diff_default <= 2 * n_flagged
+    flagged_recs = {d["contig"] for d in dips_f if d["flags"] & (_lib.HIT_TIE | _lib.HIT_AT_THRESHOLD)}
+    for key in set(kf) ^ set(ko):
+        assert key[0] in flagged_recs
+    assert len(hits_c) >= 100
+
+
+def test_config5_k7_eight_kfvs_50mb(ctx):
+    """configs[4]'s workload (k = 7, the fixture clustered into 8 KFVs = KGMA_MAX_GROUP) on a 52 Mb genome with
+    N runs, through the one-kernel and the two-kernel cluster path: hits and EVERY distance against the
+    exact-integer oracle, default-mode and chain-replay hits against the Float64 oracle."""
+    from kmergma_amd import fasta, refprep
+    k = 7
+    tf = os.path.join(DATA, "Alp_V_ref.fasta")
+    cutoffs = [6, 7, 7.7, 8.5, 9.5, 12, 22]
+    KFVs, ws, cons, inv, ints = refprep.cluster_ref_API(tf, k, cutoffs=cutoffs, include_avg=False, return_int=True)
+    KFVs, ws, cons, ints = refprep.eliminate_null_params(KFVs, ws, cons, inv, ints)
+    S = [x for x, _ in ints]; N = [n for _, n in ints]
+    assert len(ws) == 8
+    # thresholds as tools/run_config5.py derives them (random-sequence mean minus 7), rounded to halves so that
+    # several of them sit exactly on the distance lattice of the single-sequence clusters (guard band in use)
+    thr = [round(2 * float(t)) / 2 for t in refprep.estimate_optimal_threshold(KFVs, ws, buffer=7, num_trials=30)]
+    genes = [r.sequence.upper() for r in fasta.read_fasta(tf)]
+    lens = [30_000_000, 17_000_000, 5_000_000, 300, 12]
+    g = ctx.genome_synthetic(lens, 500)
+    g.poke(0, 1, b"N" * 200_000)
+    g.poke(0, 7_000_001, b"N" * 50_000)
+    g.poke(1, 16_900_000, b"n" * 100_000)                  # lower-case N run reaching the record end
+    plants = workloads.planted_genes(genes, lens, 120, 501, max_rate=0.08)
+    for c, pos, data in plants:
+        g.poke(c, pos, data)
+    g.repack()
+    seqs = _fetch_all(g, lens)
+    T = [orc.int_threshold(t, k, n) for t, n in zip(thr, N)]
+    ohi, oD = orc.omn_scan_int(seqs, S, N, k, ws, T, 100, 77, return_D=True, hit_cap=1 << 16)
+    ohits, _ = orc.omn_scan(seqs, KFVs, k, ws, thr, 100, 77, hit_cap=1 << 16)
+    assert len(ohi) >= 40
+    ctx.set_refs(k, KFVs, ws, thr, N)
+    old = os.environ.get("KGMA_TWOKERNEL")
+    try:
+        for two in ("0", "1"):
+            os.environ["KGMA_TWOKERNEL"] = two
+            ctx.scan(g, _lib.MODE_OMN, 100, 77, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
+            hits = ctx.hits()
+            assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi], f"two-kernel={two}"
+            assert [h["D"] for h in hits] == [h["D"] for h in ohi]
+            for j in range(8):
+                d = ctx.dists(j + 1)
+                assert np.array_equal(d, oD[j] / (2.0 * k * N[j] ** 2)), f"two-kernel={two} KFV {j + 1}"
+                del d
+            ctx.scan(g, _lib.MODE_OMN, 100, 77, _lib.F_CHAIN_REPLAY, None)
+            hits_c, st_c = ctx.hits(), ctx.stats()
+            assert [hit_key(h) for h in hits_c] == [hit_key(h) for h in ohits], f"two-kernel={two}"
+            assert st_c["n_tie_flagged"] == 0
+    finally:
+        if old is None:
+            os.environ.pop("KGMA_TWOKERNEL", None)
+        else:
+            os.environ["KGMA_TWOKERNEL"] = old
+    g.free()
 
 
 def test_config4_cluster_mode_400mb(ctx):
