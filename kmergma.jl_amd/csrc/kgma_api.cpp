@@ -2053,7 +2053,25 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
                 if (ctx->dips[u].flags & (KGMA_HIT_TIE | KGMA_HIT_AT_THRESHOLD)) need = true;
                 mins.push_back(ctx->dips[u].D_min);
             }
-            if (!need) {
+            if (!need && mode == KGMA_MODE_SINGLE) {
+                // the single engine's alignment does not feed back (GenomeMiner.jl:96-99): with no other tie in
+                // the pair its state machine is a function of the dips alone, so "a dip's minimum equals the
+                // running minimum" is found by running it (GenomeMiner.jl:82-104)
+                const int64_t W = ctx->kfv[0].W;
+                int64_t currmin = mins[0], CMI = 2, goal_ind = 0;
+                bool stop = true;
+                for (size_t u = p.d0; u < p.d1 && !need; u++) {
+                    const kgma_dip &d = ctx->dips[u];
+                    if (d.D_min == currmin) need = true;
+                    if (d.D_min < currmin) { currmin = d.D_min; CMI = d.argmin + k - 2; stop = false; }
+                    if (d.exit_pos == 0 || stop) continue;
+                    stop = true;
+                    CMI += 1;
+                    if (CMI > goal_ind) { goal_ind = CMI + W - 1; currmin = d.D_exit; }
+                }
+            } else if (!need) {
+                // cluster engine: whether a hit is emitted (and the running minimum reset) depends on the
+                // alignment callback (OmnGenomeMiner.jl:126,139,152): take the superset "two equal minima"
                 std::sort(mins.begin(), mins.end());
                 need = std::adjacent_find(mins.begin(), mins.end()) != mins.end();
             }
@@ -2205,7 +2223,6 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
     ctx->stats.n_chain_pairs = (int64_t)pairs.size();
     ctx->stats.chain_windows = windows;
     ctx->stats.chain_ms = now_ms() - t0;
-    (void)mode;
     return KGMA_OK;
 }
 

@@ -139,6 +139,10 @@ class HitGatherer:
                 "send_dev": torch.zeros((rows, 8), dtype=torch.int64, device=self.dev) if on_gpu else send_host,
                 "recv_all": recv_all, "recv_list": list(recv_all.unbind(0)),
                 "recv_host": torch.zeros((self.world, rows, 8), dtype=torch.int64, pin_memory=True) if on_gpu else recv_all,
+                # every rank reads the header rows back (64 B per rank): a capacity overflow anywhere is raised
+                # on ALL ranks after the collective, never before it (a one-sided raise would leave the others
+                # blocked in the next collective)
+                "hdr_host": torch.zeros((self.world, 8), dtype=torch.int64, pin_memory=True) if on_gpu else None,
                 "done": None,       # GPU: event after the last queued operation of the slot; CPU: the collective's work handle
                 "busy": False,
             })
@@ -147,8 +151,7 @@ class HitGatherer:
     def start(self, hits: np.ndarray, contig_begin: int, genome_pos_local_advance: int) -> int:
         """Queue the exchange of this rank's `hits` (structured array of kgma_hit records); returns the slot."""
         n = int(hits.shape[0])
-        if n > self.cap:
-            raise RuntimeError(f"HitGatherer capacity {self.cap} < {n} hits: construct it with a larger capacity")
+        n_send = min(n, self.cap)        # an overflow is reported through the header and raised by finish() on every rank
         t = self.turn
         self.turn ^= 1
         sl = self.slots[t]
@@ -160,8 +163,8 @@ class HitGatherer:
         buf[0, 0] = n
         buf[0, 1] = int(genome_pos_local_advance)
         buf[0, 2] = int(contig_begin)
-        if n:
-            buf[1:1 + n] = np.ascontiguousarray(hits).view(np.int64).reshape(n, 8)
+        if n_send:
+            buf[1:1 + n_send] = np.ascontiguousarray(hits[:n_send]).view(np.int64).reshape(n_send, 8)
         if self.on_gpu:
             with self.torch.cuda.stream(self.stream):
                 sl["send_dev"].copy_(sl["send_host"], non_blocking=True)
@@ -172,6 +175,7 @@ class HitGatherer:
                 work.wait()                         # RCCL: orders self.stream after the collective, the host goes on
                 if self.rank == 0:
                     sl["recv_host"].copy_(sl["recv_all"], non_blocking=True)
+                sl["hdr_host"].copy_(sl["recv_all"][:, 0, :], non_blocking=True)
                 ev = self.torch.cuda.Event()
                 ev.record(self.stream)
                 sl["done"] = ev
@@ -188,21 +192,23 @@ class HitGatherer:
             raise RuntimeError("HitGatherer.finish: nothing in flight in this slot")
         sl["busy"] = False
         if self.on_gpu:
-            if self.rank != 0:
-                return None                         # (start() waits for the event before the slot is reused)
             sl["done"].synchronize()
+            counts = sl["hdr_host"].numpy()[:, 0]
         else:
             sl["done"].wait()
             sl["done"] = None
-            if self.rank != 0:
-                return None
+            counts = sl["recv_all"].numpy()[:, 0, 0]
+        over = [(r, int(c)) for r, c in enumerate(counts) if int(c) > self.cap]
+        if over:                                    # every rank sees the same headers: all raise together
+            raise RuntimeError("HitGatherer capacity %d exceeded: %s; construct it with a larger capacity"
+                               % (self.cap, ", ".join("rank %d has %d hits" % rc for rc in over)))
+        if self.rank != 0:
+            return None
         blocks = sl["recv_host"].numpy()
         parts = []
         gp_off = 0
         for r in range(self.world):
             cnt, adv, begin = int(blocks[r, 0, 0]), int(blocks[r, 0, 1]), int(blocks[r, 0, 2])
-            if cnt > self.cap:
-                raise RuntimeError(f"rank {r} reported {cnt} hits, capacity {self.cap}")
             rec = blocks[r, 1:1 + cnt].copy().reshape(-1).view(HIT_RECORD_DTYPE)
             rec["contig"] += begin              # shard-local record index -> genome record index
             rec["genome_pos"] += gp_off         # genome_pos continues across shards
@@ -368,9 +374,23 @@ def scan_sharded(ctx, records: Sequence[bytes], mode: int, buff: int = 50, genom
     ws = [ctx.ws[0]] if mode_single else list(ctx.ws)
     lengths = [len(r) for r in records]
     plan = plan_slices(lengths, world, mode_single, ws, ctx.k, min_windows)
-    payload = local_scan(ctx, records, plan[rank], mode, flags)
+    # a rank-local failure (a residue outside A/C/G/T/N in this rank's slices, a record shorter than k-1, a
+    # record-buffer overflow) must not leave the other ranks blocked in the collective: it travels with the
+    # payload, the collective completes, and EVERY rank raises the first error in record order
+    try:
+        payload = local_scan(ctx, records, plan[rank], mode, flags)
+        payload["error"] = None
+    except _lib.KgmaError as e:
+        first_rec = min((c for (c, _, _) in plan[rank]), default=0)
+        payload = dict(slices=list(plan[rank]), dips=np.zeros(0, dtype=_lib.DIP_DTYPE), last_min=np.zeros(0, dtype=np.int64),
+                       first_D={}, error=(type(e).__name__, int(e.status), e.message, int(first_rec), int(rank)))
     gathered = [None] * world
     dist.all_gather_object(gathered, payload, group=group)
+    errors = sorted((p["error"] for p in gathered if p.get("error")), key=lambda t: (t[3], t[4]))
+    if errors:
+        name, status, message, _rec, erank = errors[0]
+        cls = {"BadBaseError": _lib.BadBaseError, "RecordBoundsError": _lib.RecordBoundsError}.get(name, _lib.KgmaError)
+        raise cls(status, f"(rank {erank}, slice-local coordinates) {message}")
     if rank != 0:
         return []
     m = 1 if mode_single else len(ctx.ws)

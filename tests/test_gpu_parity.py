@@ -716,3 +716,26 @@ def test_reserved_cus_change_geometry_not_results(alp_ref, genes):
             c.set_reserved_cus(200)
     finally:
         c.close()
+
+
+def test_scan_replay_dips_scan_same_genome(ctx, alp_ref, genes):
+    """kgma_replay_dips overwrites the context's record tables: the next scan of the SAME genome must
+    rebuild its tile geometry instead of trusting the cached key."""
+    rng = np.random.default_rng(77)
+    contigs, _ = make_genome(rng, [120000, 40000], genes, n_plants_per_mb=150)
+    ctx.set_refs(6, [alp_ref["RV"]], [alp_ref["ws"]], [30.0], [alp_ref["N"]])
+    g = ctx.genome_from_host(contigs)
+    ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)
+    first = ctx.hits()
+    dips, last_min = ctx.dips_array().copy(), ctx.dip_last_min().copy()
+    fD = ctx.first_window(1).reshape(1, -1)
+    assert len(first) > 5
+    ctx.replay_dips(_lib.MODE_SINGLE, 50, 0, 0, [len(c) for c in contigs], fD, dips, last_min)
+    assert [hit_key(h) for h in ctx.hits()] == [hit_key(h) for h in first]
+    ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)
+    assert ctx.hits() == first
+    with pytest.raises(_lib.KgmaError):      # the single engine evaluates KFV 1 only
+        ctx.set_refs(6, [alp_ref["RV"], alp_ref["RV"]], [alp_ref["ws"]] * 2, [30.0, 30.0], [alp_ref["N"]] * 2)
+        ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)
+        ctx.first_window(2)
+    g.free()

@@ -121,11 +121,15 @@ def _worker_fast(rank, world, port, q):
     except Exception:
         third = False
     assert third
+    # a capacity overflow on ONE rank (rank 1) is raised on EVERY rank, after the collective has completed
     try:
-        g.gather(np.zeros(5, dtype=par.HIT_RECORD_DTYPE), 0, 0)
+        g.gather(np.zeros(5 if rank == 1 else 1, dtype=par.HIT_RECORD_DTYPE), 0, 0)
         overflow = False
-    except RuntimeError:
-        overflow = True
+    except RuntimeError as e:
+        overflow = "rank 1 has 5 hits" in str(e)
+    assert overflow
+    out = g.gather(make(0), [0, 3][rank], [4000, 5100][rank])      # the gatherer stays usable afterwards
+    assert (out is not None) == (rank == 0)
     if rank == 0:
         q.put((outs, overflow))
     dist.barrier()

@@ -12,6 +12,18 @@ import os
 import shutil
 
 
+def source_hash():
+    """sha256 over the device sources, as bench.py computes it: the summary is only valid for that build."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kmergma.jl_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def norm(name):
     return name.replace("void ", "").split("(")[0]
 
@@ -20,8 +32,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("src")
     ap.add_argument("dst_prefix")
-    ap.add_argument("--length", type=int, default=50818468)
+    ap.add_argument("--length", type=int, default=100_000_000_000, help="bases per launch of the scan kernel")
+    ap.add_argument("--records", type=int, default=100)
     ap.add_argument("--windowsize", type=int, default=289)
+    ap.add_argument("--workload", default="bench.py default: one synthetic 100 Gb genome (100 records x 1e9 bases) on one GPU")
     ap.add_argument("--kernel", default="stream_kernel")
     args = ap.parse_args()
     stats_csv = glob.glob(os.path.join(args.src, "trace", "*", "*_kernel_stats.csv"))[0]
@@ -42,7 +56,7 @@ def main():
                     acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             for k, v in acc.items():
                 means[k] = sum(v) / len(v)
-    windows = args.length - args.windowsize + 1
+    windows = args.length - args.records * (args.windowsize - 1)
     d = {}
     if "FETCH_SIZE" in means:
         d["hbm_read_bytes_corrected"] = means["FETCH_SIZE"] * 1024 * 2
@@ -67,10 +81,17 @@ def main():
         d["lds_active_cycles"] = means["SQ_LDS_IDX_ACTIVE"]
         if "gpu_cycles" in d:
             d["lds_active_fraction_of_kernel"] = means["SQ_LDS_IDX_ACTIVE"] / (d["gpu_cycles"] * 256.0)
+        if "SQ_LDS_BANK_CONFLICT" in means and means["SQ_LDS_IDX_ACTIVE"] > 0:
+            d["lds_bank_conflict_fraction_of_lds_cycles"] = means["SQ_LDS_BANK_CONFLICT"] / means["SQ_LDS_IDX_ACTIVE"]
+    if "SQ_WAIT_ANY" in means and "SQ_WAVE_CYCLES" in means and means["SQ_WAVE_CYCLES"] > 0:
+        d["wait_any_fraction_of_wave_cycles"] = means["SQ_WAIT_ANY"] / means["SQ_WAVE_CYCLES"]
+    if "SQ_ACTIVE_INST_VALU" in means and "gpu_cycles" in d:
+        d["valu_busy_fraction_of_kernel"] = means["SQ_ACTIVE_INST_VALU"] * 4.0 / (d["gpu_cycles"] * 1024.0)
     out = {
-        "command": "tools/profile_bench.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline (defaults) and one "
-                   "rocprofv3 --pmc <set> --kernel-trace pass per counter set with --steps 3 --warmup 1; summarised by tools/summarize_profile.py",
-        "kernel": kernel_full, "workload": "bench.py default: chr22-size synthetic record, %d bases" % args.length,
+        "command": "tools/profile_bench.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-secondary --no-cpu-baseline "
+                   "(defaults) and one rocprofv3 --pmc <set> --kernel-trace pass per counter set with --steps 2 --warmup 1; "
+                   "summarised by tools/summarize_profile.py",
+        "kernel": kernel_full, "workload": args.workload, "bases_per_launch": args.length, "source_hash": source_hash(),
         "per_launch_mean": means, "kernel_trace": trace, "derived": d,
     }
     with open(args.dst_prefix + "_scan_pmc_summary.json", "w") as fh:
