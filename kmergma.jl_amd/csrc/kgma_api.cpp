@@ -36,6 +36,8 @@ hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int
 hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 int stream_waves(int k, int nk, int n_kfv, int n_sizes);
+int stream_slots_per_cu(int k, int nk, int n_kfv, int n_sizes, bool s16, int64_t n_ref);
+bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref);
 hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
 int pos_tables_per_pass(int k);
 int64_t align_trace_bytes(int m, int n);
@@ -71,6 +73,7 @@ struct KfvInfo {
     int64_t T = 0;       // below thr  <=>  D < T
     int64_t T_hi = -1;   // T <= D <= T_hi: at threshold (guard band, usually empty)
     int64_t sumS2 = 0;
+    int64_t Smax = 0;
     std::vector<int64_t> S;   // natural k-mer order
     std::vector<double> ref;  // the KFV as given (Float64), for the tie resolver
 };
@@ -685,6 +688,7 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
                 return fail(ctx, KGMA_E_UNSUPPORTED, "KFV %d entry %lld (%.17g) times N=%lld is not a non-negative integer", j + 1,
                             (long long)x, r[x], (long long)N);
             f.S[(size_t)x] = (int64_t)rv;
+            f.Smax = std::max(f.Smax, (int64_t)rv);
             s2 += (__int128)f.S[(size_t)x] * f.S[(size_t)x];
         }
         // the device keeps E = (D - D0)/(2N) and N*diff in int32
@@ -1280,20 +1284,28 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         if (!strcmp(kv, "bitslice")) use_stream = false;
         if (!strcmp(kv, "stream")) use_stream = k <= KGMA_STREAM_MAX_K;
     }
-    int stream_nw = 16;
+    int stream_nw = 1 << 20;         // streams resident per CU (smallest over the launch groups)
     if (use_stream)
         for (const Group &gr : groups) {
             int n_sizes = 0;
             int64_t prev = -1;
             for (int j : gr.kfvs) { if (ctx->kfv[(size_t)j].W != prev) n_sizes++; prev = ctx->kfv[(size_t)j].W; }
-            const int nw = stream_waves(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), n_sizes);
+            bool s16 = true;
+            for (int j : gr.kfvs) s16 = s16 && ctx->kfv[(size_t)j].Smax <= 32767;
+            const int nw = stream_slots_per_cu(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), n_sizes, s16, ctx->kfv[(size_t)gr.kfvs.front()].N);
             if (nw < 1) use_stream = false;
             stream_nw = std::min(stream_nw, nw);
         }
     const int64_t nc = g->n_contigs;
     const bool want_dists = (flags & KGMA_F_RETURN_DISTS) != 0;
-    const int geom_version = use_stream ? 2 + 16 * ctx->reserved_cus + 16 * 1024 * ctx->n_cus : 1;
-    snprintf(ctx->kernel_name, sizeof ctx->kernel_name, use_stream ? "stream_kernel<%d>" : "scan_kernel<%d>", k);   // (+ pos_kernel for multi-KFV groups)
+    const int geom_version = use_stream ? 2 + 16 * ctx->reserved_cus + 16 * 1024 * ctx->n_cus + (stream_nw << 24) : 1;
+    {
+        bool s8 = use_stream;
+        if (use_stream)
+            for (const Group &gr : groups)
+                s8 = s8 && stream8_applies(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), ctx->kfv[(size_t)gr.kfvs.front()].N);
+        snprintf(ctx->kernel_name, sizeof ctx->kernel_name, s8 ? "stream8_kernel<%d>" : use_stream ? "stream_kernel<%d>" : "scan_kernel<%d>", k);   // (+ pos_kernel for multi-KFV groups)
+    }
 
     ctx->dips.clear();
     ctx->hits.clear();
@@ -1510,6 +1522,8 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
                 gp.T_hi[u] = f.T_hi;
                 gp.sumS2[u] = f.sumS2;
                 gp.inv_scale[u] = 2.0 * (double)k * (double)f.N * (double)f.N;
+                if (u == 0) gp.s_fits_i16 = 1;
+                if (f.Smax > 32767) gp.s_fits_i16 = 0;
                 a.dist[u] = want_dists ? ctx->d_dist[(size_t)j] : nullptr;
             }
             a.planes = g->d_planes;

@@ -27,6 +27,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include <type_traits>
 
@@ -493,6 +494,338 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// stream8_kernel: the same stream kernel for ONE KFV with 8-BIT counters (4 per dword): a wave's table is
+// 4^k bytes (4 KiB at k = 6), so that 32 waves (two 16-wave workgroups) are resident per CU instead of 16 --
+// the step is a chain of dependent LDS round trips, and twice the waves hide twice the latency.
+//
+// A window of n <= 383 k-mers holds at most ONE k-mer with 192 or more copies, so counts beyond a byte are
+// a wave-uniform affair: the wave tracks that one "heavy" k-mer H and its exact count in scalar registers.
+//   * The packed dword is an exact integer (adds and subtracts carry / borrow consistently), so when H's
+//     count passes 255 its carry sits in the next byte of the dword: a lane whose k-mer is that neighbour
+//     subtracts the carry, a lane whose k-mer is H takes the count from the scalar register.
+//   * A k-mer becomes a candidate when an ENTERING lane reads a start-of-step count >= 128 (a count grows
+//     by at most 64 per step, so an untracked k-mer never exceeds 191 at the start of a step and 255 inside
+//     it); of H and the candidates the one with the largest end-of-step count is tracked next -- two k-mers
+//     cannot both end a step with >= 192 copies.  Below 128 the wave leaves heavy mode.
+//   * Lanes that touch H's dword always go through the correction loop (a carry toggle and a real touch of
+//     the neighbour byte could otherwise cancel in the returned old value).
+// All of this is off the fast path: random sequence never has a candidate, and the fast path pays one
+// compare + one scalar branch for it.  Low-complexity stretches (homopolymer / N runs, tandem repeats) do.
+// Further differences from stream_kernel: the step's k-mers are cut out of the plane words BEFORE the next
+// step's loads are issued into the same registers (no register rotation), the S table is kept as int16 when
+// every entry fits (8 KiB instead of 16 KiB at k = 6), 24-bit multiply for N * diff.
+// ------------------------------------------------------------------------------------------
+template <int K, bool S16>
+__global__ __launch_bounds__(1024, 8) void stream8_kernel(ScanArgs a, GroupParams gp)
+{
+    constexpr int NB = 1 << (2 * K);
+    constexpr uint32_t KM = (1u << K) - 1u;
+    extern __shared__ uint32_t smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = uni((int)(threadIdx.x >> 6));
+
+    // ---- LDS: [S table: int16 or int32 per k-mer] then per wave [NB byte counters]
+    constexpr size_t tab_words = S16 ? NB / 2 : NB;
+    int32_t *sTab32 = reinterpret_cast<int32_t *>(smem);
+    int16_t *sTab16 = reinterpret_cast<int16_t *>(smem);
+    uint32_t *C = smem + tab_words + (size_t)wave * (NB / 4);
+    {
+        const int32_t *Sg = a.Stab + (size_t)(gp.kfv_id[0] - 1) * NB;
+        for (int i = threadIdx.x; i < NB; i += blockDim.x) {
+            if constexpr (S16) sTab16[i] = (int16_t)Sg[i];
+            else sTab32[i] = Sg[i];
+        }
+        __syncthreads();
+    }
+    const int tile = wave * (int)gridDim.x + (int)blockIdx.x;         // streams are dealt to workgroups round-robin
+    if (tile >= a.n_tiles) return;                                    // (after the only workgroup barrier)
+
+    for (int i = lane; i < NB / 4; i += 64) C[i] = 0;
+    int32_t st[ST_WORDS];
+#pragma unroll
+    for (int i = 0; i < ST_WORDS; i++) st[i] = 0;
+    int32_t h_carry = 0, h_TE = 0;
+    bool in_run_flag = false, has_att = false;
+    const bool want_dist = a.dist[0] != nullptr;
+    // heavy k-mer (wave-uniform)
+    bool heavy = false;
+    uint32_t Hkey = 0, hcnt = 0;
+
+    const TileDesc td = a.tiles[tile];
+    const int n_valid = td.n_valid, first_test = td.first_test;
+    const int nk = gp.nk;
+    const uint2 *g2 = reinterpret_cast<const uint2 *>(a.planes) + td.word_base;
+    const int n_pos = n_valid + nk - 1;
+    const int n_blocks = (n_pos + 63) >> 6;
+    const int32_t Nj = gp.N[0];
+    const int64_t twoN = 2 * (int64_t)Nj;
+    const int kid = gp.kfv_id[0];
+
+    const int e_word = lane >> 5;
+    const uint32_t e_sh = (uint32_t)(lane & 31);
+    const int l_word = (lane - nk) >> 5;                              // floor: may be negative
+    const uint32_t l_sh = (uint32_t)((lane - nk) & 31);
+
+    // plane words of the NEXT step, loaded one step ahead.  Steady steps address them as a wave-uniform base
+    // (scalar registers, advanced by 16 bytes per step) plus a per-lane constant 32-bit offset, so that the
+    // loads need no address arithmetic on the vector unit; warm-up steps clamp the leaving words at the
+    // stream's first word.
+    uint2 pe0, pe1, pl0, pl1;
+    const int lw_min = (0 - nk) >> 5;                                 // l_word of lane 0 (the smallest)
+    const uint32_t e_off = (uint32_t)e_word * 8u, l_off = (uint32_t)(l_word - lw_min) * 8u;
+    const char *gbytes = reinterpret_cast<const char *>(g2);
+    auto prefetch_steady = [&](const int b) {                         // needs 2 b + lw_min >= 0
+        const char *be = gbytes + (size_t)b * 16;
+        const char *bl = gbytes + ((int64_t)b * 16 + (int64_t)lw_min * 8);
+        const uint4 ve = *reinterpret_cast<const uint4 *>(be + e_off);
+        const uint4 vl = *reinterpret_cast<const uint4 *>(bl + l_off);
+        pe0 = make_uint2(ve.x, ve.y); pe1 = make_uint2(ve.z, ve.w);
+        pl0 = make_uint2(vl.x, vl.y); pl1 = make_uint2(vl.z, vl.w);
+    };
+    auto prefetch = [&](const int b) {
+        pe0 = g2[2 * b + e_word];
+        pe1 = g2[2 * b + e_word + 1];
+        int wi = 2 * b + l_word;
+        wi = wi < 0 ? 0 : wi;                                         // warm-up lanes have no leaving k-mer yet
+        pl0 = g2[wi];
+        pl1 = g2[wi + 1];
+    };
+    prefetch(0);
+    const int neg_lane = -lane;
+
+    auto step = [&](const int b, auto generic_tag) {
+        constexpr bool GENERIC = decltype(generic_tag)::value;
+        const int p = (b << 6) + lane;
+        uint32_t kp, ks;
+        {
+            const uint32_t hh = __builtin_amdgcn_alignbit(pe1.x, pe0.x, e_sh) & KM;
+            const uint32_t ll = __builtin_amdgcn_alignbit(pe1.y, pe0.y, e_sh) & KM;
+            kp = (hh << K) | ll;
+            const uint32_t h2 = __builtin_amdgcn_alignbit(pl1.x, pl0.x, l_sh) & KM;
+            const uint32_t l2 = __builtin_amdgcn_alignbit(pl1.y, pl0.y, l_sh) & KM;
+            ks = (h2 << K) | l2;
+        }
+        asm volatile("" : "+v"(kp), "+v"(ks));                        // the k-mers are cut before the loads below overwrite their words
+        // (the plane array is padded past the last record; b + 1 >= b_warm makes every leaving word index >= 0)
+        if constexpr (GENERIC) { if (2 * (b + 1) + lw_min >= 0) prefetch_steady(b + 1); else prefetch(b + 1); }
+        else prefetch_steady(b + 1);
+        bool haveL = true;
+        if constexpr (GENERIC) { haveL = p >= nk; ks = haveL ? ks : kp; }
+        const bool differ = kp != ks;                                 // GenomeMiner.jl:66: nothing happens if left == right
+        const bool actE = differ || !haveL, actL = differ && haveL;
+        // lane masks as scalar values (v_cmp straight into a scalar pair; no ballot of a combined predicate)
+        uint64_t AE = __builtin_amdgcn_uicmp(kp, ks, 33 /* ne */), AL = AE;
+        if constexpr (GENERIC) { AE = __ballot(actE); AL = __ballot(actL); }
+
+        // ---- every LDS operation of the step back to back ------------------------------------------
+        const uint8_t *Cb = reinterpret_cast<const uint8_t *>(C);
+        uint32_t cp = Cb[kp], cs = Cb[ks];                            // counts at the start of the step (raw bytes)
+        const uint32_t shp = 8u * (kp & 3u), shs = 8u * (ks & 3u);
+        // this lane's transition; the old values tell whether another lane touched the k-mer.  Lanes without a
+        // transition (left == right: homopolymer / N runs) issue nothing: 64 lanes adding 0 to one address would
+        // serialise in the LDS for nothing
+        uint32_t wop = 0, wos = 0;
+        if (actE) wop = atomicAdd(&C[kp >> 2], 1u << shp);
+        if (actL) wos = atomicSub(&C[ks >> 2], 1u << shs);
+        int32_t Sr, Sl;
+        if constexpr (S16) { Sr = sTab16[kp]; Sl = sTab16[ks]; }
+        else { Sr = sTab32[kp]; Sl = sTab32[ks]; }
+
+        // ---- exact counts of the entering / leaving k-mer in THIS lane's window ---------------------
+        int32_t cP, cS;
+        {
+            const uint32_t oldp = (wop >> shp) & 0xFFu, olds = (wos >> shs) & 0xFFu;
+            uint64_t pendE = __builtin_amdgcn_uicmp(oldp, cp, 33 /* ne */) & AE;
+            uint64_t pendL = __builtin_amdgcn_uicmp(olds, cs, 33 /* ne */) & AL;
+            const uint64_t cand0 = __builtin_amdgcn_uicmp(cp, 127u, 34 /* ugt */);
+            if (__builtin_expect(heavy || cand0 != 0, 0)) {
+                uint32_t best_key = 0, best_end = 0;
+                if (heavy) {
+                    const bool isHp = kp == Hkey, isHs = ks == Hkey;
+                    const bool nb_ok = (Hkey & 3u) != 3u;                 // H in the top byte: its carry leaves the dword
+                    const bool nxp = nb_ok && kp == Hkey + 1u, nxs = nb_ok && ks == Hkey + 1u;
+                    const uint32_t carry = hcnt >> 8;
+                    cp = isHp ? hcnt : (nxp ? cp - carry : cp);
+                    cs = isHs ? hcnt : (nxs ? cs - carry : cs);
+                    pendE |= __builtin_amdgcn_uicmp((kp ^ Hkey) >> 2, 0u, 32 /* eq */) & AE;
+                    pendL |= __builtin_amdgcn_uicmp((ks ^ Hkey) >> 2, 0u, 32 /* eq */) & AL;
+                    best_key = Hkey;
+                    best_end = hcnt + (uint32_t)__builtin_popcountll(__ballot(isHp) & AE) - (uint32_t)__builtin_popcountll(__ballot(isHs) & AL);
+                }
+                uint64_t cm = __ballot(cp >= 128u && !(heavy && kp == Hkey));
+                for (int it = 0; it < 64 && cm != 0; it++) {
+                    const int l0 = __builtin_ctzll(cm);
+                    const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)kp, l0);
+                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cp, l0);
+                    const uint64_t ex = __ballot(kp == x), lx = __ballot(ks == x);
+                    const uint32_t end = c0 + (uint32_t)__builtin_popcountll(ex & AE) - (uint32_t)__builtin_popcountll(lx & AL);
+                    if (end > best_end) { best_end = end; best_key = x; }
+                    cm &= ~ex;
+                }
+                heavy = best_end >= 128u;
+                Hkey = best_key; hcnt = best_end;
+            }
+            int32_t corrP = 0, corrS = 0;
+            if (pendE | pendL) {
+                for (int it = 0; it < 128 && (pendE | pendL) != 0; it++) {
+                    uint32_t x0;
+                    if (pendE) x0 = (uint32_t)__builtin_amdgcn_readlane((int)kp, __builtin_ctzll(pendE));
+                    else x0 = (uint32_t)__builtin_amdgcn_readlane((int)ks, __builtin_ctzll(pendL));
+                    const uint64_t eqP = __builtin_amdgcn_uicmp(kp, x0, 32 /* eq */), eqS = __builtin_amdgcn_uicmp(ks, x0, 32 /* eq */);
+                    // transitions of lower lanes happen before this lane's window: #entries - #exits among them.
+                    // #exits below = lane - #non-exits below, so one chain of four v_mbcnt started at -lane gives the difference
+                    const uint64_t ME = eqP & AE, MLn = ~(eqS & AL);
+                    uint32_t v = __builtin_amdgcn_mbcnt_lo((uint32_t)ME, (uint32_t)neg_lane);
+                    v = __builtin_amdgcn_mbcnt_hi((uint32_t)(ME >> 32), v);
+                    v = __builtin_amdgcn_mbcnt_lo((uint32_t)MLn, v);
+                    v = __builtin_amdgcn_mbcnt_hi((uint32_t)(MLn >> 32), v);
+                    corrP = kp == x0 ? (int32_t)v : corrP;
+                    corrS = ks == x0 ? (int32_t)v : corrS;
+                    pendE &= ~eqP;
+                    pendL &= ~eqS;
+                }
+            }
+            cP = (int32_t)cp + corrP;
+            cS = (int32_t)cs + corrS;
+        }
+        // left == right: same k-mer, same count, difference 0; otherwise c[l] - 1 - c[r]
+        const int32_t dd = cS - cP - (differ ? 1 : 0);
+        // GenomeMiner.jl:67-68 times 2kN^2 / 2N.  Without a transition the two k-mers are equal (Sl == Sr,
+        // dd == 0) except in the warm-up, where there is no leaving k-mer at all.
+        int32_t e = Sl - Sr - __mul24(Nj, dd);
+        if constexpr (GENERIC) e = actL ? e : 0;
+
+        if constexpr (GENERIC) {
+            if ((b << 6) < nk) {                                      // warm-up steps: first-window D
+                const bool wu = p < nk;
+                const int64_t ssum = wave_sum_i64(wu ? (int64_t)Sr : 0);
+                const int64_t psum = wave_sum_i64(wu ? (int64_t)cP : 0);
+                int64_t sumS = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_SUMHI]) << 32) | (uint32_t)uni(st[ST_SUMLO])) + ssum;
+                const int32_t pairs = uni(st[ST_PAIRS]) + (int32_t)psum;
+                st[ST_SUMLO] = (int32_t)(uint32_t)sumS;
+                st[ST_SUMHI] = (int32_t)(uint32_t)((uint64_t)sumS >> 32);
+                st[ST_PAIRS] = pairs;
+                if (nk - 1 < (b << 6) + 64) {                         // last warm-up position is in this step
+                    const int64_t D0 = gp.sumS2[0] - twoN * sumS + (int64_t)Nj * Nj * ((int64_t)nk + 2 * (int64_t)pairs);
+                    if (lane == 0) a.D0out[(size_t)(kid - 1) * a.n_tiles + tile] = D0;
+                    st[ST_D0LO] = (int32_t)(uint32_t)D0;
+                    st[ST_D0HI] = (int32_t)(uint32_t)((uint64_t)D0 >> 32);
+                    const int64_t num = gp.T[0] - D0;
+                    int64_t TE64 = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
+                    const int64_t numh = gp.T_hi[0] - D0;
+                    const int64_t TH64 = numh >= 0 ? numh / twoN : -((-numh + twoN - 1) / twoN);
+                    int64_t na = gp.T_hi[0] >= gp.T[0] ? TH64 - TE64 + 1 : 0;
+                    if (na < 0) na = 0;
+                    if (na > 0x3FFFFFFF) na = 0x3FFFFFFF;
+                    if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; na = 0; }
+                    if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; na = 0; }
+                    h_TE = uni((int32_t)TE64);
+                    st[ST_NATT] = (int32_t)na;
+                    has_att = uni((int32_t)na) != 0;
+                }
+            }
+        }
+
+        const int32_t E = wave_incl_scan(e) + h_carry;
+        h_carry = __builtin_amdgcn_readlane(E, 63);
+        const int32_t TE = h_TE;
+        const int q = p - nk + 1;                                     // window start (local) this transition leads to
+        bool tested = true;
+        if constexpr (GENERIC) tested = q >= first_test && q < n_valid;
+        const bool under = tested && E < TE;
+        if (want_dist) {
+            if (tested) {
+                const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
+                a.dist[0][td.dist_base + q] = (double)(D0 + twoN * (int64_t)E) / gp.inv_scale[0];
+            }
+        }
+        bool att = false;
+        uint64_t A = 0;
+        if (has_att) {                                                // (only when the threshold sits on the distance lattice)
+            att = tested && !under && E - TE < uni(st[ST_NATT]);
+            A = __ballot(att);
+        }
+        const uint64_t U = __ballot(under);
+        int in_run = in_run_flag ? 1 : 0;
+        if ((U | A) == 0 && !in_run) return;                          // fast path: nothing near the threshold
+
+        // ---- a dip touches this step: walk its runs (wave-uniform) ----------------------------
+        const int q0 = (b << 6) - nk + 1;                             // window of lane 0
+        if (att) {
+            DevRecord rec;
+            rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8);
+            rec.start = q; rec.end = q; rec.minE = E;
+            rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
+            emit_global(a, rec);
+            atomicAdd(a.n_att, 1ull);
+        }
+        int run_start = uni(st[ST_START]), minE = uni(st[ST_MINE]), argf = uni(st[ST_ARGF]), argl = uni(st[ST_ARGL]),
+            nmin = uni(st[ST_NMIN]);
+        int cursor = 0;
+        while (cursor < 64) {
+            const uint64_t rem = ~(uint64_t)0 << cursor;
+            if (in_run) {
+                const uint64_t nz = ~U & rem;
+                const int end_lane = nz ? __builtin_ctzll(nz) : 64;
+                if (end_lane > cursor) {
+                    const bool inseg = lane >= cursor && lane < end_lane;
+                    const int32_t segmin = wave_min_i32(inseg ? E : 0x7FFFFFFF);
+                    const uint64_t eq = __ballot(inseg && E == segmin);
+                    const int fl = __builtin_ctzll(eq), ll2 = 63 - __builtin_clzll(eq), pc = __builtin_popcountll(eq);
+                    if (nmin == 0 || segmin < minE) { minE = segmin; argf = q0 + fl; argl = q0 + ll2; nmin = pc; }
+                    else if (segmin == minE) { argl = q0 + ll2; nmin += pc; }
+                }
+                if (end_lane < 64) {
+                    const int qe = q0 + end_lane;
+                    const int32_t exitE = __builtin_amdgcn_readlane(E, end_lane);
+                    if (lane == 0) {
+                        DevRecord rec;
+                        rec.tile = tile; rec.kind_kfv = REC_RUN | (kid << 8);
+                        rec.start = run_start; rec.end = qe - 1; rec.minE = minE;
+                        rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
+                        rec.exitE = exitE; rec.has_exit = qe < n_valid ? 1 : 0;
+                        emit_global(a, rec);
+                    }
+                    in_run = 0;
+                    cursor = end_lane;
+                } else {
+                    cursor = 64;
+                }
+            } else {
+                const uint64_t nu = U & rem;
+                if (!nu) break;
+                cursor = __builtin_ctzll(nu);
+                in_run = 1; run_start = q0 + cursor; nmin = 0; minE = 0; argf = argl = run_start;
+            }
+        }
+        in_run_flag = in_run != 0;
+        st[ST_START] = run_start; st[ST_MINE] = minE; st[ST_ARGF] = argf; st[ST_ARGL] = argl; st[ST_NMIN] = nmin;
+    };
+
+    int b_warm = (nk + 63) >> 6;
+    if (b_warm > n_blocks) b_warm = n_blocks;
+    int b_tail = n_valid + nk - 65;                                   // steps b <= b_tail/64 have all windows < n_valid
+    b_tail = b_tail >= 0 ? (b_tail >> 6) + 1 : 0;
+    if (b_tail < b_warm) b_tail = b_warm;
+    if (b_tail > n_blocks) b_tail = n_blocks;
+    int b = 0;
+    for (; b < b_warm; b++) step(b, std::true_type{});
+    for (; b < b_tail; b++) step(b, std::false_type{});
+    for (; b < n_blocks; b++) step(b, std::true_type{});
+
+    if (in_run_flag && lane == 0) {                                   // run still open at the end of the stream
+        DevRecord rec;
+        rec.tile = tile; rec.kind_kfv = REC_RUN | (kid << 8);
+        rec.start = st[ST_START]; rec.end = n_valid - 1; rec.minE = st[ST_MINE];
+        rec.argf = st[ST_ARGF]; rec.argl = st[ST_ARGL]; rec.nmin = st[ST_NMIN];
+        rec.exitE = 0; rec.has_exit = 0;
+        emit_global(a, rec);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // geometry + launch
 // ------------------------------------------------------------------------------------------
@@ -544,8 +877,88 @@ static hipError_t launch_stream_k(const ScanArgs &a, const GroupParams &gp, hipS
     return hipGetLastError();
 }
 
+// ---- 8-bit counter kernel: one KFV, k = 5 or 6, at most 383 k-mers per window --------------------
+constexpr int KGMA_STREAM8_MAX_NK = 383;
+
+static bool stream8_env_on()                         // KGMA_STREAM8=0 (testing): keep the 16-bit counter kernel; read at every scan
+{
+    const char *e = getenv("KGMA_STREAM8");
+    return !(e && atoi(e) == 0);
+}
+
+// (N < 2^22: the kernel multiplies N by a count difference with the 24-bit multiplier)
+bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref)
+{
+    return stream8_env_on() && n_kfv == 1 && (k == 5 || k == 6) && nk <= KGMA_STREAM8_MAX_NK && n_ref < ((int64_t)1 << 22);
+}
+
+static size_t stream8_lds(int k, bool s16, int nw)
+{
+    const size_t NB = (size_t)1 << (2 * k);
+    return NB * (s16 ? 2 : 4) + (size_t)nw * NB;
+}
+
+template <int K, bool S16>
+static const void *stream8_fn() { return reinterpret_cast<const void *>(&stream8_kernel<K, S16>); }
+
+static const void *stream8_fn_of(int k, bool s16)
+{
+    if (k == 5) return s16 ? stream8_fn<5, true>() : stream8_fn<5, false>();
+    return s16 ? stream8_fn<6, true>() : stream8_fn<6, false>();
+}
+
+// waves per workgroup and workgroups per CU: two 16-wave workgroups when the LDS holds them (asked of the
+// runtime, which knows the allocation granule), else the largest workgroup that still runs two per CU
+void stream8_geometry(int k, bool s16, int *nw_out, int *blocks_out)
+{
+    static int cache[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};     // [k-5][s16] -> {nw, blocks}
+    int *c = cache[k - 5][s16 ? 1 : 0];
+    if (c[0] == 0) {
+        int best_nw = 16, best_blocks = 1;
+        for (int nw = 16; nw >= 12; nw--) {
+            const size_t lds = stream8_lds(k, s16, nw);
+            int blocks = 0;
+            if (hipFuncSetAttribute(stream8_fn_of(k, s16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, stream8_fn_of(k, s16), 64 * nw, lds) != hipSuccess) continue;
+            if (blocks > 2) blocks = 2;                                   // 32 waves per CU
+            if (blocks * nw > best_blocks * best_nw) { best_blocks = blocks; best_nw = nw; }
+            if (blocks >= 2) break;
+        }
+        (void)hipGetLastError();
+        c[0] = best_nw; c[1] = best_blocks;
+    }
+    *nw_out = c[0]; *blocks_out = c[1];
+}
+
+template <int K>
+static hipError_t launch_stream8_k(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+{
+    const bool s16 = gp.s_fits_i16 != 0;
+    int nw = 16, blocks = 1;
+    stream8_geometry(K, s16, &nw, &blocks);
+    const size_t lds = stream8_lds(K, s16, nw);
+    const unsigned grid = (unsigned)((a.n_tiles + nw - 1) / nw);
+    hipError_t e = hipFuncSetAttribute(stream8_fn_of(K, s16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (s16) hipLaunchKernelGGL((stream8_kernel<K, true>), dim3(grid), dim3((unsigned)(64 * nw)), lds, st, a, gp);
+    else hipLaunchKernelGGL((stream8_kernel<K, false>), dim3(grid), dim3((unsigned)(64 * nw)), lds, st, a, gp);
+    return hipGetLastError();
+}
+
+// streams resident per CU (what the host sizes the streams for)
+int stream_slots_per_cu(int k, int nk, int n_kfv, int n_sizes, bool s16, int64_t n_ref)
+{
+    if (stream8_applies(k, nk, n_kfv, n_ref)) {
+        int nw = 16, blocks = 1;
+        stream8_geometry(k, s16, &nw, &blocks);
+        return nw * blocks;
+    }
+    return stream_waves(k, nk, n_kfv, n_sizes);
+}
+
 hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
 {
+    if (stream8_applies(gp.k, gp.nk, gp.n_kfv, gp.N[0])) return gp.k == 5 ? launch_stream8_k<5>(a, gp, st) : launch_stream8_k<6>(a, gp, st);
     switch (gp.k) {
     case 2: return launch_stream_k<2>(a, gp, st);
     case 3: return launch_stream_k<3>(a, gp, st);

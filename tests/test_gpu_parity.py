@@ -515,10 +515,27 @@ def test_both_kernels_single(ctx, alp_ref, genes, force_kernel):
     a[20000:20700] = b"ACGT" * 175
     contigs[0] = bytes(a)
     _assert_single_parity(ctx, contigs, alp_ref, 30.0)
-    assert ctx.kernel_name().startswith("stream_kernel")
+    assert ctx.kernel_name().startswith("stream8_kernel")          # 8-bit counters: the default at k = 6, one KFV
     force_kernel("bitslice")
     _assert_single_parity(ctx, contigs, alp_ref, 30.0)
     assert ctx.kernel_name().startswith("scan_kernel")
+
+
+def test_stream_kernel_16bit_counters_single(ctx, alp_ref, genes, monkeypatch):
+    """KGMA_STREAM8=0 (read at every scan): the 16-bit counter stream kernel, which still serves windows of more
+    than 383 k-mers, must agree at k = 6 too."""
+    rng = np.random.default_rng(32)
+    contigs, _ = make_genome(rng, [90000, 5000], genes, n_plants_per_mb=150)
+    a = bytearray(contigs[0])
+    a[3000:3400] = b"A" * 400
+    a[20000:20600] = b"CA" * 300
+    contigs[0] = bytes(a)
+    monkeypatch.setenv("KGMA_STREAM8", "0")
+    _assert_single_parity(ctx, contigs, alp_ref, 30.0)
+    assert ctx.kernel_name().startswith("stream_kernel")
+    monkeypatch.delenv("KGMA_STREAM8")
+    _assert_single_parity(ctx, contigs, alp_ref, 30.0)
+    assert ctx.kernel_name().startswith("stream8_kernel")
 
 
 @pytest.mark.parametrize("k", [5, 6, 7])
@@ -708,8 +725,9 @@ def test_reserved_cus_change_geometry_not_results(alp_ref, genes):
         h0, _, D0, s0, _ = _scan_single(c, contigs, alp_ref, 30.0, no_tie_resolve=True)
         c.set_reserved_cus(8)
         h1, _, D1, s1, _ = _scan_single(c, contigs, alp_ref, 30.0, no_tie_resolve=True)
-        assert c.kernel_name().startswith("stream_kernel")
-        assert s0["n_tiles"] > 248 * 16 >= s1["n_tiles"]      # one stream per wave slot: 16 waves per CU at k = 6
+        assert c.kernel_name().startswith("stream")
+        slots = 32 if c.kernel_name().startswith("stream8") else 16     # streams resident per CU at k = 6
+        assert s0["n_tiles"] > 248 * slots >= s1["n_tiles"]   # one stream per wave slot
         assert [hit_key(h) for h in h0] == [hit_key(h) for h in h1] and [h["D"] for h in h0] == [h["D"] for h in h1]
         assert np.array_equal(D0, D1)
         with pytest.raises(_lib.KgmaError):
@@ -739,3 +757,45 @@ def test_scan_replay_dips_scan_same_genome(ctx, alp_ref, genes):
         ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)
         ctx.first_window(2)
     g.free()
+
+
+def _low_complexity_genome(rng, n_total, W):
+    """Random sequence with homopolymer runs, short-period tandem repeats and N runs of lengths around the
+    8-bit counter's corners (128, 192, 256 copies of one k-mer; runs longer than the window), some of them
+    preceded by the residue that makes the neighbouring byte of the count table (carry path)."""
+    a = bytearray(random_dna(rng, n_total))
+    pos = 500
+    units = [b"A", b"C", b"G", b"T", b"N", b"AC", b"GT", b"AT", b"ACG", b"AAC", b"ACGT", b"AACC", b"AAAAAC", b"ACGTTGCA"]
+    lengths = [100, 127, 128, 129, 133, 180, 191, 192, 193, 200, 250, 255, 256, 257, 262, 283, 284, 285, 290, 300,
+               W - 1, W, W + 1, W + 60, W + 64, W + 65, 2 * W, 700, 1500]
+    while pos + 2500 < n_total:
+        u = units[int(rng.integers(0, len(units)))]
+        ln = lengths[int(rng.integers(0, len(lengths)))]
+        run = (u * (ln // len(u) + 1))[:ln]
+        if rng.random() < 0.5:
+            run = bytes([b"ACGT"[int(rng.integers(0, 4))]]) + run      # a different residue in front: neighbour k-mer of the run's
+        a[pos:pos + len(run)] = run
+        pos += len(run) + int(rng.integers(1, 900))
+    return bytes(a)
+
+
+@pytest.mark.parametrize("k,gene_len", [(6, 289), (6, 388), (6, 389), (5, 150), (5, 387), (6, 120)])
+def test_stream8_heavy_kmers(ctx, k, gene_len):
+    """8-bit counter stream kernel (k = 5, 6; <= 383 k-mers per window): windows in which ONE k-mer has 128 ...
+    n copies (homopolymers, tandem repeats, N runs), counts crossing 255 (carry into the neighbouring byte),
+    two k-mers with n/2 copies each (dinucleotide repeats).  Every distance against the integer oracle."""
+    from kmergma_amd.fasta import Record
+    from tests.helpers import mutate
+    rng = np.random.default_rng(1000 * k + gene_len)
+    base = random_dna(rng, gene_len)
+    refs = [Record(f"g{i}", mutate(rng, base, 0.03)) for i in range(6)]
+    RV, ws, cons, (S, N) = refprep.gen_ref_ws_cons(refs, k, return_int=True)
+    assert ws == gene_len
+    ref = dict(RV=RV, ws=ws, S=S, N=N, k=k)
+    g1 = _low_complexity_genome(rng, 400_000, ws)
+    g2 = b"A" * 70_000 + random_dna(rng, 3000) + b"AC" * 20_000 + b"T" * 300 + random_dna(rng, 5000) + b"N" * 10_000
+    thr = float(np.median([orc.kmer_dist_kfv(random_dna(rng, ws), RV, k) for _ in range(20)])) - 4.0
+    _assert_single_parity(ctx, [g1, g2, base + g1[:5000]], ref, thr)
+    n = ws - k + 1
+    name = ctx.kernel_name()
+    assert name.startswith("stream8_kernel") == (n <= 383), (name, n)
