@@ -62,11 +62,15 @@ def _assert_single_parity(ctx, contigs, ref, thr, buff=50, align=None):
         assert np.max(np.abs(d - od) / np.maximum(od, 1e-300)) < REL_TOL
     unresolved = sum(1 for x in dips if x["flags"] & (_lib.HIT_TIE | _lib.HIT_AT_THRESHOLD))
     if [hit_key(h) for h in hits] != [hit_key(h) for h in ohits]:
-        assert unresolved > 0, "hits differ from the Float64 oracle although no dip is flagged ambiguous"
-        assert len(hits) == len(ohits)
-        for a, b in zip(hits, ohits):
-            if hit_key(a) != hit_key(b):
-                assert a["flags"] & (_lib.HIT_TIE | _lib.HIT_AT_THRESHOLD)
+        # an isolated window whose exact distance EQUALS thr (inside the 2^-30 guard band) counts as not below in
+        # this mode, while the reference's chain may see it below and emit a hit of its own there: such windows are
+        # reported in n_at_threshold, and only the chain replay of (3) reproduces the reference around them
+        assert unresolved > 0 or stats["n_at_threshold"] > 0, "hits differ from the Float64 oracle although nothing is flagged ambiguous"
+        if stats["n_at_threshold"] == 0:
+            assert len(hits) == len(ohits)
+            for a, b in zip(hits, ohits):
+                if hit_key(a) != hit_key(b):
+                    assert a["flags"] & (_lib.HIT_TIE | _lib.HIT_AT_THRESHOLD)
     for a, b in zip(hits, ohits):
         if hit_key(a) == hit_key(b):
             assert abs(a["dist"] - b["dist"]) <= REL_TOL * max(b["dist"], 1e-300)
