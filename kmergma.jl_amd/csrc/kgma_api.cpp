@@ -30,7 +30,8 @@
 
 namespace kgma {
 hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc *cd, int n_contigs,
-                       int64_t total_words, unsigned long long *first_bad, hipStream_t st);
+                       int64_t total_words, const int32_t *block_contig, unsigned long long *first_bad, hipStream_t st);
+int pack_block_words();
 hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int64_t total_words,
                         uint64_t seed, hipStream_t st);
 hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
@@ -100,6 +101,7 @@ struct kgma_genome {
     uint32_t *d_planes = nullptr;
     ContigDesc *d_cd = nullptr;
     unsigned long long *d_first_bad = nullptr;
+    int32_t *d_block_contig = nullptr;       // record of the first word of every pack block (pack_kernel)
     int64_t device_bytes = 0;
 };
 
@@ -805,7 +807,23 @@ static int genome_layout(kgma_ctx *ctx, kgma_genome *g, const int64_t *contig_le
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_first_bad), std::max<size_t>(1, (size_t)n_contigs) * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&g->first_bad), std::max<size_t>(1, (size_t)n_contigs) * sizeof(unsigned long long), hipHostMallocDefault));
     g->uid = ctx->next_uid++;
-    g->device_bytes = g->ascii_bytes + g->total_words * 8 + n_contigs * (int64_t)(sizeof(ContigDesc) + 8);
+    {
+        // pack_kernel: record of the first plane word of every block (words before a record's first one -- lead /
+        // inter-record padding -- belong to the record before; the kernel walks forward from there)
+        const int64_t bw = pack_block_words();
+        const int64_t nblk = (g->total_words + bw - 1) / bw;
+        std::vector<int32_t> bc((size_t)std::max<int64_t>(nblk, 1), 0);
+        int32_t c = 0;
+        for (int64_t b = 0; b < nblk; b++) {
+            const int64_t w = b * bw;
+            while (c + 1 < n_contigs && g->cd[(size_t)c + 1].word_off <= w) c++;
+            bc[(size_t)b] = c;
+        }
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_block_contig), bc.size() * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMemcpy(g->d_block_contig, bc.data(), bc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        g->device_bytes += (int64_t)bc.size() * 4;
+    }
+    g->device_bytes += g->ascii_bytes + g->total_words * 8 + n_contigs * (int64_t)(sizeof(ContigDesc) + 8);
     if (n_contigs > 0)
         HIP_TRY(ctx, hipMemcpy(g->d_cd, g->cd.data(), (size_t)n_contigs * sizeof(ContigDesc), hipMemcpyHostToDevice));
     return KGMA_OK;
@@ -834,7 +852,7 @@ int kgma_genome_repack(kgma_ctx *ctx, kgma_genome *g)
     if (dirty) HIP_TRY(ctx, hipMemsetAsync(g->d_first_bad, 0xFF, std::max<size_t>(1, (size_t)g->n_contigs) * 8, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->evp0, ctx->stream));
     if (g->n_contigs > 0)
-        HIP_TRY(ctx, launch_pack(g->d_ascii, g->d_planes, g->d_cd, (int)g->n_contigs, g->total_words, g->d_first_bad, ctx->stream));
+        HIP_TRY(ctx, launch_pack(g->d_ascii, g->d_planes, g->d_cd, (int)g->n_contigs, g->total_words, g->d_block_contig, g->d_first_bad, ctx->stream));
     else
         HIP_TRY(ctx, hipMemsetAsync(g->d_planes, 0, (size_t)g->total_words * 8, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->evp1, ctx->stream));
@@ -1129,6 +1147,7 @@ void kgma_genome_free(kgma_ctx *ctx, kgma_genome *g)
     if (g->d_planes) (void)hipFree(g->d_planes);
     if (g->d_cd) (void)hipFree(g->d_cd);
     if (g->d_first_bad) (void)hipFree(g->d_first_bad);
+    if (g->d_block_contig) (void)hipFree(g->d_block_contig);
     if (g->first_bad) (void)hipHostFree(g->first_bad);
     if (ctx && ctx->tk_uid == g->uid) ctx->tk_uid = 0;
     delete g;

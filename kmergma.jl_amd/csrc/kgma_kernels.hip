@@ -37,8 +37,7 @@ namespace kgma {
 
 // ------------------------------------------------------------------------------------------
 // ASCII -> bit-planes (src/Consts.jl:22-28: A0 C1 G2 T3, N -> 3; either case).
-// One lane packs 32 residues (two 16-byte loads) into one {hi,lo} word pair.  Words past a
-// record's end (padding) are written as zero.  first_bad[c] receives the smallest 1-based
+// Words past a record's end (padding) are written as zero.  first_bad[c] receives the smallest 1-based
 // position of a residue outside A/C/G/T/N (atomicMin), or stays at its initial huge value.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int find_contig(const ContigDesc *cd, int n_contigs, int64_t g)
@@ -51,74 +50,123 @@ __device__ __forceinline__ int find_contig(const ContigDesc *cd, int n_contigs, 
     return lo;
 }
 
+// One lane packs 32 residues (two 16-byte loads) into one {hi,lo} word pair.
+__device__ __forceinline__ uint2 pack_word(const uint4 a, const uint4 b, const int nvalid, uint32_t *bad_out)
+{
+    uint32_t h = 0, l = 0, bad = 0;
+    const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    // Four residues per 32-bit word at a time.  After folding case, (ch >> 1) & 7 is distinct for the five
+    // accepted letters (A 0, C 1, T 2, G 3, N 7): v_perm_b32 uses it as an index into two 8-byte tables,
+    // one giving the letter back (any difference = a residue outside A/C/G/T/N) and one giving the code
+    // as 0x00 / 0x0F / 0xF0 / 0xFF (low nibble = code bit 0, high nibble = code bit 1; N -> T's code 3).
+    // ANDing with one bit per byte and summing the bytes (v_sad_u8) collects four residues' plane bits.
+    uint32_t diff = 0, hw[8], lw[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t v = x[j] & 0xDFDFDFDFu;                       // fold case
+        const uint32_t sel = (v >> 1) & 0x07070707u;
+        const uint32_t letter = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, sel);   // idx 7 'N' | 3 'G' 2 'T' 1 'C' 0 'A'
+        const uint32_t code = __builtin_amdgcn_perm(0xFF000000u, 0xF0FF0F00u, sel);     // idx 7 -> 3 | G 2, T 3, C 1, A 0
+        diff |= v ^ letter;
+        // residue t of word j goes to bit 4*(j&1)+t of the plane byte: pick that bit out of the nibble that
+        // carries the plane's indicator
+        if (j & 1) {
+            lw[j] = (code << 4) & 0x80402010u;
+            hw[j] = code & 0x80402010u;
+        } else {
+            lw[j] = code & 0x08040201u;
+            hw[j] = (code >> 4) & 0x08040201u;
+        }
+    }
+    if (diff == 0 && nvalid == 32) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {                                // 8 residues -> one byte of each plane
+            const uint32_t lb = __builtin_amdgcn_sad_u8(lw[2 * q + 1], 0u, __builtin_amdgcn_sad_u8(lw[2 * q], 0u, 0u));
+            const uint32_t hb = __builtin_amdgcn_sad_u8(hw[2 * q + 1], 0u, __builtin_amdgcn_sad_u8(hw[2 * q], 0u, 0u));
+            l |= lb << (8 * q);
+            h |= hb << (8 * q);
+        }
+    } else {
+        // a record's last (partial) word, or a residue to report: one residue at a time
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const uint32_t ch = ((x[i >> 2] >> (8 * (i & 3))) & 0xFFu) & 0xDFu;  // fold case
+            const uint32_t isA = ch == 'A', isC = ch == 'C', isG = ch == 'G';
+            const uint32_t isT = (ch == 'T') | (ch == 'N');
+            const uint32_t in = i < nvalid;
+            h |= ((isG | isT) & in) << i;
+            l |= ((isC | isT) & in) << i;
+            bad |= ((1u ^ (isA | isC | isG | isT)) & in) << i;
+        }
+    }
+    *bad_out = bad;
+    return make_uint2(h, l);
+}
+
+// A workgroup packs PACK_U x 256 consecutive plane words (32 KiB of residues at PACK_U = 4).  The record of
+// the block's first word comes from a host-built table (one entry per block: no per-word binary search in
+// front of the loads); when the whole block lies inside that record -- all but a few blocks per record -- the
+// addresses are a wave-uniform base plus the lane's offset and all 2 x PACK_U 16-byte loads of a lane are
+// issued before the first is used (128 B in flight per lane).  Loads and stores are non-temporal: the residue
+// text is read once and the planes are next read by another kernel, neither should displace L2 lines.
+constexpr int PACK_U = 4;
+constexpr int PACK_BLOCK_WORDS = 256 * PACK_U;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii,
                                                    uint32_t *__restrict__ planes,
                                                    const ContigDesc *__restrict__ cd, int n_contigs,
-                                                   int64_t total_words,
+                                                   int64_t total_words, const int32_t *__restrict__ block_contig,
                                                    unsigned long long *__restrict__ first_bad)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total_words; g += stride) {
-        const int c = find_contig(cd, n_contigs, g);
+    const int64_t g0 = (int64_t)blockIdx.x * PACK_BLOCK_WORDS;
+    const int c0 = block_contig[blockIdx.x];                          // record of word g0 (or the one before its lead padding)
+    const ContigDesc d0 = cd[c0];
+    const int64_t g_end = g0 + PACK_BLOCK_WORDS <= total_words ? g0 + PACK_BLOCK_WORDS : total_words;
+    const int64_t next_off = c0 + 1 < n_contigs ? cd[c0 + 1].word_off : INT64_MAX;
+    const int64_t w0 = g0 - d0.word_off;
+    uint2 *out = reinterpret_cast<uint2 *>(planes);
+    if (w0 >= 0 && g_end <= next_off && (w0 + PACK_BLOCK_WORDS) * 32 <= d0.len && g_end == g0 + PACK_BLOCK_WORDS) {
+        // fast path: every word of the block is a full word of record c0
+        const u32x4_t *p = reinterpret_cast<const u32x4_t *>(ascii + d0.ascii_off + w0 * 32) + 2 * threadIdx.x;
+        uint4 va[PACK_U], vb[PACK_U];
+#pragma unroll
+        for (int u = 0; u < PACK_U; u++) {
+            const u32x4_t x = __builtin_nontemporal_load(p + u * 512);
+            const u32x4_t y = __builtin_nontemporal_load(p + u * 512 + 1);
+            va[u] = make_uint4(x.x, x.y, x.z, x.w);
+            vb[u] = make_uint4(y.x, y.y, y.z, y.w);
+        }
+#pragma unroll
+        for (int u = 0; u < PACK_U; u++) {
+            uint32_t bad;
+            const uint2 r = pack_word(va[u], vb[u], 32, &bad);
+            const int64_t g = g0 + u * 256 + threadIdx.x;
+            if (bad) atomicMin(&first_bad[c0], (unsigned long long)((w0 + u * 256 + threadIdx.x) * 32 + __builtin_ctz(bad) + 1));
+            u32x2_t rv; rv.x = r.x; rv.y = r.y;
+            __builtin_nontemporal_store(rv, reinterpret_cast<u32x2_t *>(out + g));
+        }
+        return;
+    }
+    // slow path: record boundaries / padding / partial words inside the block
+    for (int u = 0; u < PACK_U; u++) {
+        const int64_t g = g0 + u * 256 + threadIdx.x;
+        if (g >= total_words) break;
+        int c = c0;
+        while (c + 1 < n_contigs && cd[c + 1].word_off <= g) c++;
         const int64_t w = g - cd[c].word_off;
         const int64_t L = cd[c].len;
         const int64_t base0 = w * 32;
-        uint32_t h = 0, l = 0, bad = 0;
+        uint2 r = make_uint2(0u, 0u);
         if (w >= 0 && base0 < L) {
             const uint4 *p = reinterpret_cast<const uint4 *>(ascii + cd[c].ascii_off + base0);
-            const uint4 a = p[0], b = p[1];
-            const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
             const int nvalid = (L - base0) < 32 ? (int)(L - base0) : 32;
-            // Four residues per 32-bit word at a time.  After folding case, (ch >> 1) & 7 is distinct for the five
-            // accepted letters (A 0, C 1, T 2, G 3, N 7): v_perm_b32 uses it as an index into two 8-byte tables,
-            // one giving the letter back (any difference = a residue outside A/C/G/T/N) and one giving the code
-            // as 0x00 / 0x0F / 0xF0 / 0xFF (low nibble = code bit 0, high nibble = code bit 1; N -> T's code 3).
-            // ANDing with one bit per byte and summing the bytes (v_sad_u8) collects four residues' plane bits.
-            uint32_t diff = 0, hw[8], lw[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t v = x[j] & 0xDFDFDFDFu;                       // fold case
-                const uint32_t sel = (v >> 1) & 0x07070707u;
-                const uint32_t letter = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, sel);   // idx 7 'N' | 3 'G' 2 'T' 1 'C' 0 'A'
-                const uint32_t code = __builtin_amdgcn_perm(0xFF000000u, 0xF0FF0F00u, sel);     // idx 7 -> 3 | G 2, T 3, C 1, A 0
-                diff |= v ^ letter;
-                // residue t of word j goes to bit 4*(j&1)+t of the plane byte: pick that bit out of the nibble that
-                // carries the plane's indicator
-                if (j & 1) {
-                    lw[j] = (code << 4) & 0x80402010u;
-                    hw[j] = code & 0x80402010u;
-                } else {
-                    lw[j] = code & 0x08040201u;
-                    hw[j] = (code >> 4) & 0x08040201u;
-                }
-            }
-            if (diff == 0 && nvalid == 32) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {                                // 8 residues -> one byte of each plane
-                    const uint32_t lb = __builtin_amdgcn_sad_u8(lw[2 * q + 1], 0u, __builtin_amdgcn_sad_u8(lw[2 * q], 0u, 0u));
-                    const uint32_t hb = __builtin_amdgcn_sad_u8(hw[2 * q + 1], 0u, __builtin_amdgcn_sad_u8(hw[2 * q], 0u, 0u));
-                    l |= lb << (8 * q);
-                    h |= hb << (8 * q);
-                }
-            } else {
-                // a record's last (partial) word, or a residue to report: one residue at a time
-#pragma unroll
-                for (int i = 0; i < 32; i++) {
-                    const uint32_t ch = ((x[i >> 2] >> (8 * (i & 3))) & 0xFFu) & 0xDFu;  // fold case
-                    const uint32_t isA = ch == 'A', isC = ch == 'C', isG = ch == 'G';
-                    const uint32_t isT = (ch == 'T') | (ch == 'N');
-                    const uint32_t in = i < nvalid;
-                    h |= ((isG | isT) & in) << i;
-                    l |= ((isC | isT) & in) << i;
-                    bad |= ((1u ^ (isA | isC | isG | isT)) & in) << i;
-                }
-            }
+            uint32_t bad;
+            r = pack_word(p[0], p[1], nvalid, &bad);
+            if (bad) atomicMin(&first_bad[c], (unsigned long long)(base0 + __builtin_ctz(bad) + 1));
         }
-        if (bad) {
-            const unsigned long long pos = (unsigned long long)(base0 + __builtin_ctz(bad) + 1);
-            atomicMin(&first_bad[c], pos);
-        }
-        reinterpret_cast<uint2 *>(planes)[g] = make_uint2(h, l);
+        out[g] = r;
     }
 }
 
@@ -1162,14 +1210,15 @@ hipError_t launch_export(uint8_t *res, uint8_t *host, int64_t d0_slots, int64_t 
     return hipGetLastError();
 }
 
+int pack_block_words() { return PACK_BLOCK_WORDS; }
+
 hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc *cd, int n_contigs,
-                       int64_t total_words, unsigned long long *first_bad, hipStream_t st)
+                       int64_t total_words, const int32_t *block_contig, unsigned long long *first_bad, hipStream_t st)
 {
     if (total_words <= 0) return hipSuccess;
-    int64_t blocks = (total_words + 255) / 256;
-    if (blocks > 256 * 64) blocks = 256 * 64;
+    const int64_t blocks = (total_words + PACK_BLOCK_WORDS - 1) / PACK_BLOCK_WORDS;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ascii, planes, cd,
-                       n_contigs, total_words, first_bad);
+                       n_contigs, total_words, block_contig, first_bad);
     return hipGetLastError();
 }
 
