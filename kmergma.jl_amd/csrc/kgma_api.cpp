@@ -29,7 +29,7 @@
 #include "kgma_chain.h"
 
 namespace kgma {
-hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc *cd, int n_contigs,
+hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, uint32_t *inter, const ContigDesc *cd, int n_contigs,
                        int64_t total_words, const int32_t *block_contig, unsigned long long *first_bad, hipStream_t st);
 int pack_block_words();
 hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int64_t total_words,
@@ -99,6 +99,7 @@ struct kgma_genome {
     uint64_t uid = 0;
     uint8_t *d_ascii = nullptr;
     uint32_t *d_planes = nullptr;
+    uint32_t *d_inter = nullptr;             // 2-bit interleaved copy (16 bases per dword), written by the pack kernel beside the planes
     ContigDesc *d_cd = nullptr;
     unsigned long long *d_first_bad = nullptr;
     int32_t *d_block_contig = nullptr;       // record of the first word of every pack block (pack_kernel)
@@ -803,6 +804,7 @@ static int genome_layout(kgma_ctx *ctx, kgma_genome *g, const int64_t *contig_le
     (void)hipSetDevice(ctx->device);
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_ascii), (size_t)g->ascii_bytes));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_planes), (size_t)g->total_words * 8));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_inter), (size_t)g->total_words * 8));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_cd), std::max<size_t>(1, (size_t)n_contigs) * sizeof(ContigDesc)));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_first_bad), std::max<size_t>(1, (size_t)n_contigs) * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&g->first_bad), std::max<size_t>(1, (size_t)n_contigs) * sizeof(unsigned long long), hipHostMallocDefault));
@@ -823,7 +825,7 @@ static int genome_layout(kgma_ctx *ctx, kgma_genome *g, const int64_t *contig_le
         HIP_TRY(ctx, hipMemcpy(g->d_block_contig, bc.data(), bc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         g->device_bytes += (int64_t)bc.size() * 4;
     }
-    g->device_bytes += g->ascii_bytes + g->total_words * 8 + n_contigs * (int64_t)(sizeof(ContigDesc) + 8);
+    g->device_bytes += g->ascii_bytes + g->total_words * 16 + n_contigs * (int64_t)(sizeof(ContigDesc) + 8);
     if (n_contigs > 0)
         HIP_TRY(ctx, hipMemcpy(g->d_cd, g->cd.data(), (size_t)n_contigs * sizeof(ContigDesc), hipMemcpyHostToDevice));
     return KGMA_OK;
@@ -852,9 +854,12 @@ int kgma_genome_repack(kgma_ctx *ctx, kgma_genome *g)
     if (dirty) HIP_TRY(ctx, hipMemsetAsync(g->d_first_bad, 0xFF, std::max<size_t>(1, (size_t)g->n_contigs) * 8, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->evp0, ctx->stream));
     if (g->n_contigs > 0)
-        HIP_TRY(ctx, launch_pack(g->d_ascii, g->d_planes, g->d_cd, (int)g->n_contigs, g->total_words, g->d_block_contig, g->d_first_bad, ctx->stream));
+        HIP_TRY(ctx, launch_pack(g->d_ascii, g->d_planes, g->d_inter, g->d_cd, (int)g->n_contigs, g->total_words, g->d_block_contig, g->d_first_bad, ctx->stream));
     else
+    {
         HIP_TRY(ctx, hipMemsetAsync(g->d_planes, 0, (size_t)g->total_words * 8, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(g->d_inter, 0, (size_t)g->total_words * 8, ctx->stream));
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->evp1, ctx->stream));
     if (dirty) HIP_TRY(ctx, hipMemcpyAsync(g->first_bad, g->d_first_bad, std::max<size_t>(1, (size_t)g->n_contigs) * 8, hipMemcpyDeviceToHost, ctx->stream));
     g->text_dirty = false;
@@ -1145,6 +1150,7 @@ void kgma_genome_free(kgma_ctx *ctx, kgma_genome *g)
     if (ctx) (void)hipSetDevice(ctx->device);
     if (g->d_ascii) (void)hipFree(g->d_ascii);
     if (g->d_planes) (void)hipFree(g->d_planes);
+    if (g->d_inter) (void)hipFree(g->d_inter);
     if (g->d_cd) (void)hipFree(g->d_cd);
     if (g->d_first_bad) (void)hipFree(g->d_first_bad);
     if (g->d_block_contig) (void)hipFree(g->d_block_contig);
@@ -1546,8 +1552,11 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
                 a.dist[u] = want_dists ? ctx->d_dist[(size_t)j] : nullptr;
             }
             a.planes = g->d_planes;
+            a.inter = g->d_inter;
             a.tiles = ctx->d_tiles;
-            a.Stab = use_stream ? ctx->d_StabC : ctx->d_Stab;   // all tables; the kernel indexes by KFV id
+            // all tables; the kernel indexes by KFV id.  The 16-bit stream kernel indexes k-mers as (hi bits << k) | lo bits,
+            // the bit-sliced kernel and the 8-bit stream kernel by the 2-bit interleaved code (first base least significant)
+            a.Stab = (use_stream && !stream8_applies(k, gp.nk, gp.n_kfv, ctx->kfv[(size_t)gr.kfvs.front()].N)) ? ctx->d_StabC : ctx->d_Stab;
             a.D0out = d_D0;                        // [KFV id - 1][tile]
             a.recs = d_recs;
             a.rec_count = reinterpret_cast<unsigned int *>(d_cnt);

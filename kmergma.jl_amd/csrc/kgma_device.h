@@ -74,6 +74,7 @@ struct DevRecord {
 // Arguments of one scan launch (either kernel).
 struct ScanArgs {
     const uint32_t *planes;
+    const uint32_t *inter;      // the same genome as 2-bit codes, 16 bases per dword (first base = bits 0-1): two dwords per plane word
     const TileDesc *tiles;
     const int32_t *Stab;        // all KFVs' tables, 4^k int32 each, in the launching kernel's index order
     int64_t *D0out;             // [KFV id - 1][n_tiles]

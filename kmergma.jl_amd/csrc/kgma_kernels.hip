@@ -103,6 +103,24 @@ __device__ __forceinline__ uint2 pack_word(const uint4 a, const uint4 b, const i
     return make_uint2(h, l);
 }
 
+// 2-bit interleaved copy of a plane word pair (stream8_kernel cuts a k-mer out of it with ONE funnel shift):
+// base t of the word -> bits 2t (code bit 0 = lo plane) and 2t+1 (code bit 1 = hi plane) of a 64-bit value.
+__device__ __forceinline__ uint32_t spread16(uint32_t x)             // bit j of the low half -> bit 2j
+{
+    x &= 0xFFFFu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+__device__ __forceinline__ uint2 interleave_word(const uint2 hl)     // hl = {hi plane, lo plane}
+{
+    const uint32_t i0 = spread16(hl.y & 0xFFFFu) | (spread16(hl.x & 0xFFFFu) << 1);
+    const uint32_t i1 = spread16(hl.y >> 16) | (spread16(hl.x >> 16) << 1);
+    return make_uint2(i0, i1);
+}
+
 // A workgroup packs PACK_U x 256 consecutive plane words (32 KiB of residues at PACK_U = 4).  The record of
 // the block's first word comes from a host-built table (one entry per block: no per-word binary search in
 // front of the loads); when the whole block lies inside that record -- all but a few blocks per record -- the
@@ -115,7 +133,7 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii,
-                                                   uint32_t *__restrict__ planes,
+                                                   uint32_t *__restrict__ planes, uint32_t *__restrict__ inter,
                                                    const ContigDesc *__restrict__ cd, int n_contigs,
                                                    int64_t total_words, const int32_t *__restrict__ block_contig,
                                                    unsigned long long *__restrict__ first_bad)
@@ -127,6 +145,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
     const int64_t next_off = c0 + 1 < n_contigs ? cd[c0 + 1].word_off : INT64_MAX;
     const int64_t w0 = g0 - d0.word_off;
     uint2 *out = reinterpret_cast<uint2 *>(planes);
+    uint2 *out2 = reinterpret_cast<uint2 *>(inter);
     if (w0 >= 0 && g_end <= next_off && (w0 + PACK_BLOCK_WORDS) * 32 <= d0.len && g_end == g0 + PACK_BLOCK_WORDS) {
         // fast path: every word of the block is a full word of record c0
         const u32x4_t *p = reinterpret_cast<const u32x4_t *>(ascii + d0.ascii_off + w0 * 32) + 2 * threadIdx.x;
@@ -146,6 +165,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
             if (bad) atomicMin(&first_bad[c0], (unsigned long long)((w0 + u * 256 + threadIdx.x) * 32 + __builtin_ctz(bad) + 1));
             u32x2_t rv; rv.x = r.x; rv.y = r.y;
             __builtin_nontemporal_store(rv, reinterpret_cast<u32x2_t *>(out + g));
+            const uint2 iw = interleave_word(r);
+            u32x2_t iv; iv.x = iw.x; iv.y = iw.y;
+            __builtin_nontemporal_store(iv, reinterpret_cast<u32x2_t *>(out2 + g));
         }
         return;
     }
@@ -167,6 +189,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
             if (bad) atomicMin(&first_bad[c], (unsigned long long)(base0 + __builtin_ctz(bad) + 1));
         }
         out[g] = r;
+        out2[g] = interleave_word(r);
     }
 }
 
@@ -454,17 +477,6 @@ __device__ __forceinline__ void counter6_add(Counter6 &s, uint32_t m)
     const uint32_t t = s.c[4] & c4;
     s.c[4] ^= c4;
     s.c[5] ^= t;      // a group holds at most 32 masks: no carry out of plane 5
-}
-
-// spread the 16 low bits of x to the even bit positions
-__device__ __forceinline__ uint32_t spread16(uint32_t x)
-{
-    x &= 0xFFFFu;
-    x = (x | (x << 8)) & 0x00FF00FFu;
-    x = (x | (x << 4)) & 0x0F0F0F0Fu;
-    x = (x | (x << 2)) & 0x33333333u;
-    x = (x | (x << 1)) & 0x55555555u;
-    return x;
 }
 
 // 2-bit interleave of one {hi,lo} word pair: stream bit 2i = lo bit i, bit 2i+1 = hi bit i, so the
@@ -1212,12 +1224,12 @@ hipError_t launch_export(uint8_t *res, uint8_t *host, int64_t d0_slots, int64_t 
 
 int pack_block_words() { return PACK_BLOCK_WORDS; }
 
-hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, const ContigDesc *cd, int n_contigs,
+hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, uint32_t *inter, const ContigDesc *cd, int n_contigs,
                        int64_t total_words, const int32_t *block_contig, unsigned long long *first_bad, hipStream_t st)
 {
     if (total_words <= 0) return hipSuccess;
     const int64_t blocks = (total_words + PACK_BLOCK_WORDS - 1) / PACK_BLOCK_WORDS;
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ascii, planes, cd,
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ascii, planes, inter, cd,
                        n_contigs, total_words, block_contig, first_bad);
     return hipGetLastError();
 }

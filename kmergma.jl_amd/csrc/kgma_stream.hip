@@ -517,11 +517,12 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
 // step's loads are issued into the same registers (no register rotation), the S table is kept as int16 when
 // every entry fits (8 KiB instead of 16 KiB at k = 6), 24-bit multiply for N * diff.
 // ------------------------------------------------------------------------------------------
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
 template <int K, bool S16>
 __global__ __launch_bounds__(1024, 8) void stream8_kernel(ScanArgs a, GroupParams gp)
 {
     constexpr int NB = 1 << (2 * K);
-    constexpr uint32_t KM = (1u << K) - 1u;
     extern __shared__ uint32_t smem[];
 
     const int lane = threadIdx.x & 63;
@@ -557,60 +558,52 @@ __global__ __launch_bounds__(1024, 8) void stream8_kernel(ScanArgs a, GroupParam
     const TileDesc td = a.tiles[tile];
     const int n_valid = td.n_valid, first_test = td.first_test;
     const int nk = gp.nk;
-    const uint2 *g2 = reinterpret_cast<const uint2 *>(a.planes) + td.word_base;
+    // the stream reads the 2-bit interleaved genome (16 bases per dword): its first base is bit 0 of gi[0]
+    const uint32_t *gi = a.inter + 2 * td.word_base;
     const int n_pos = n_valid + nk - 1;
     const int n_blocks = (n_pos + 63) >> 6;
     const int32_t Nj = gp.N[0];
     const int64_t twoN = 2 * (int64_t)Nj;
     const int kid = gp.kfv_id[0];
 
-    const int e_word = lane >> 5;
-    const uint32_t e_sh = (uint32_t)(lane & 31);
-    const int l_word = (lane - nk) >> 5;                              // floor: may be negative
-    const uint32_t l_sh = (uint32_t)((lane - nk) & 31);
-
-    // plane words of the NEXT step, loaded one step ahead.  Steady steps address them as a wave-uniform base
-    // (scalar registers, advanced by 16 bytes per step) plus a per-lane constant 32-bit offset, so that the
-    // loads need no address arithmetic on the vector unit; warm-up steps clamp the leaving words at the
-    // stream's first word.
-    uint2 pe0, pe1, pl0, pl1;
-    const int lw_min = (0 - nk) >> 5;                                 // l_word of lane 0 (the smallest)
-    const uint32_t e_off = (uint32_t)e_word * 8u, l_off = (uint32_t)(l_word - lw_min) * 8u;
-    const char *gbytes = reinterpret_cast<const char *>(g2);
-    auto prefetch_steady = [&](const int b) {                         // needs 2 b + lw_min >= 0
-        const char *be = gbytes + (size_t)b * 16;
-        const char *bl = gbytes + ((int64_t)b * 16 + (int64_t)lw_min * 8);
-        const uint4 ve = *reinterpret_cast<const uint4 *>(be + e_off);
-        const uint4 vl = *reinterpret_cast<const uint4 *>(bl + l_off);
-        pe0 = make_uint2(ve.x, ve.y); pe1 = make_uint2(ve.z, ve.w);
-        pl0 = make_uint2(vl.x, vl.y); pl1 = make_uint2(vl.z, vl.w);
+    // k-mer at position p = 64 b + lane: bits 2 (p & 15) ... of the dword pair starting at dword p >> 4.
+    // The pair of the NEXT step is loaded one step ahead.  Steady steps use buffer loads: a wave-uniform
+    // descriptor of the stream, a scalar byte offset advanced by 16 per step and a per-lane constant offset --
+    // no address arithmetic on the vector unit, and reads past the stream return 0.  Warm-up steps (some lane
+    // has no leaving k-mer yet: its dword index would be negative) use plain loads with the index clamped.
+    const uint32_t e_sh = 2u * (uint32_t)(lane & 15), l_sh = 2u * (uint32_t)((lane - nk) & 15);
+    const int e_idx = lane >> 4, l_idx = (lane - nk) >> 4;            // floor: l_idx is negative
+    const int lw_min = (0 - nk) >> 4;                                 // l_idx of lane 0 (the smallest)
+    const int e_voff = 4 * e_idx, l_voff = 4 * (l_idx - lw_min);
+    const uint64_t gaddr = reinterpret_cast<uint64_t>(gi);
+    const uint32_t g_lo = (uint32_t)uni((int)(uint32_t)gaddr), g_hi = (uint32_t)uni((int)(uint32_t)(gaddr >> 32));
+    const int g_bytes = uni(16 * (n_blocks + 2));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)g_hi << 32) | g_lo), 0, g_bytes, 0x00020000);
+    u32x2_t pe, pl;
+    auto prefetch_steady = [&](const int b) {                         // needs 16 b + 4 lw_min >= 0 (b >= b_warm)
+        pe = __builtin_amdgcn_raw_buffer_load_b64(rsrc, e_voff, 16 * b, 0);
+        pl = __builtin_amdgcn_raw_buffer_load_b64(rsrc, l_voff, 16 * b + 4 * lw_min, 0);
     };
     auto prefetch = [&](const int b) {
-        pe0 = g2[2 * b + e_word];
-        pe1 = g2[2 * b + e_word + 1];
-        int wi = 2 * b + l_word;
-        wi = wi < 0 ? 0 : wi;                                         // warm-up lanes have no leaving k-mer yet
-        pl0 = g2[wi];
-        pl1 = g2[wi + 1];
+        const int ie = 4 * b + e_idx;
+        int il = 4 * b + l_idx;
+        il = il < 0 ? 0 : il;                                         // warm-up lanes have no leaving k-mer yet
+        pe.x = gi[ie]; pe.y = gi[ie + 1];
+        pl.x = gi[il]; pl.y = gi[il + 1];
     };
     prefetch(0);
     const int neg_lane = -lane;
+    uint32_t one = 1u;
+    asm volatile("" : "+v"(one));
 
     auto step = [&](const int b, auto generic_tag) {
         constexpr bool GENERIC = decltype(generic_tag)::value;
         const int p = (b << 6) + lane;
-        uint32_t kp, ks;
-        {
-            const uint32_t hh = __builtin_amdgcn_alignbit(pe1.x, pe0.x, e_sh) & KM;
-            const uint32_t ll = __builtin_amdgcn_alignbit(pe1.y, pe0.y, e_sh) & KM;
-            kp = (hh << K) | ll;
-            const uint32_t h2 = __builtin_amdgcn_alignbit(pl1.x, pl0.x, l_sh) & KM;
-            const uint32_t l2 = __builtin_amdgcn_alignbit(pl1.y, pl0.y, l_sh) & KM;
-            ks = (h2 << K) | l2;
-        }
+        uint32_t kp = __builtin_amdgcn_alignbit(pe.y, pe.x, e_sh) & (uint32_t)(NB - 1);
+        uint32_t ks = __builtin_amdgcn_alignbit(pl.y, pl.x, l_sh) & (uint32_t)(NB - 1);
         asm volatile("" : "+v"(kp), "+v"(ks));                        // the k-mers are cut before the loads below overwrite their words
         // (the plane array is padded past the last record; b + 1 >= b_warm makes every leaving word index >= 0)
-        if constexpr (GENERIC) { if (2 * (b + 1) + lw_min >= 0) prefetch_steady(b + 1); else prefetch(b + 1); }
+        if constexpr (GENERIC) { if (4 * (b + 1) + lw_min >= 0) prefetch_steady(b + 1); else prefetch(b + 1); }
         else prefetch_steady(b + 1);
         bool haveL = true;
         if constexpr (GENERIC) { haveL = p >= nk; ks = haveL ? ks : kp; }
@@ -628,8 +621,8 @@ __global__ __launch_bounds__(1024, 8) void stream8_kernel(ScanArgs a, GroupParam
         // transition (left == right: homopolymer / N runs) issue nothing: 64 lanes adding 0 to one address would
         // serialise in the LDS for nothing
         uint32_t wop = 0, wos = 0;
-        if (actE) wop = atomicAdd(&C[kp >> 2], 1u << shp);
-        if (actL) wos = atomicSub(&C[ks >> 2], 1u << shs);
+        if (actE) wop = atomicAdd(&C[kp >> 2], one << shp);           // (`one` lives in a vector register: v_lshlrev in its short form)
+        if (actL) wos = atomicSub(&C[ks >> 2], one << shs);
         int32_t Sr, Sl;
         if constexpr (S16) { Sr = sTab16[kp]; Sl = sTab16[ks]; }
         else { Sr = sTab32[kp]; Sl = sTab32[ks]; }
@@ -669,8 +662,9 @@ __global__ __launch_bounds__(1024, 8) void stream8_kernel(ScanArgs a, GroupParam
                 Hkey = best_key; hcnt = best_end;
             }
             int32_t corrP = 0, corrS = 0;
-            if (pendE | pendL) {
-                for (int it = 0; it < 128 && (pendE | pendL) != 0; it++) {
+            // (every round clears the pending bit of the lane it was started from: at most 128 rounds)
+            while ((pendE | pendL) != 0) {
+                {
                     uint32_t x0;
                     if (pendE) x0 = (uint32_t)__builtin_amdgcn_readlane((int)kp, __builtin_ctzll(pendE));
                     else x0 = (uint32_t)__builtin_amdgcn_readlane((int)ks, __builtin_ctzll(pendL));
