@@ -613,7 +613,11 @@ __global__ __launch_bounds__(1024, 8) void stream8_kernel(ScanArgs a, GroupParam
         uint64_t AE = __builtin_amdgcn_uicmp(kp, ks, 33 /* ne */), AL = AE;
         if constexpr (GENERIC) { AE = __ballot(actE); AL = __ballot(actL); }
 
-        // ---- every LDS operation of the step back to back ------------------------------------------
+        // ---- every LDS operation of the step back to back (the S lookups first: LDS operations of a wave
+        //      complete in order, so the wait for the count operations below covers them) -----------------
+        int32_t Sr, Sl;
+        if constexpr (S16) { Sr = sTab16[kp]; Sl = sTab16[ks]; }
+        else { Sr = sTab32[kp]; Sl = sTab32[ks]; }
         const uint8_t *Cb = reinterpret_cast<const uint8_t *>(C);
         uint32_t cp = Cb[kp], cs = Cb[ks];                            // counts at the start of the step (raw bytes)
         const uint32_t shp = 8u * (kp & 3u), shs = 8u * (ks & 3u);
@@ -623,9 +627,6 @@ __global__ __launch_bounds__(1024, 8) void stream8_kernel(ScanArgs a, GroupParam
         uint32_t wop = 0, wos = 0;
         if (actE) wop = atomicAdd(&C[kp >> 2], one << shp);           // (`one` lives in a vector register: v_lshlrev in its short form)
         if (actL) wos = atomicSub(&C[ks >> 2], one << shs);
-        int32_t Sr, Sl;
-        if constexpr (S16) { Sr = sTab16[kp]; Sl = sTab16[ks]; }
-        else { Sr = sTab32[kp]; Sl = sTab32[ks]; }
 
         // ---- exact counts of the entering / leaving k-mer in THIS lane's window ---------------------
         int32_t cP, cS;
@@ -661,27 +662,25 @@ __global__ __launch_bounds__(1024, 8) void stream8_kernel(ScanArgs a, GroupParam
                 heavy = best_end >= 128u;
                 Hkey = best_key; hcnt = best_end;
             }
+            // Rounds over the distinct k-mers with a pending lane (every round clears the pending bits of all lanes
+            // with that k-mer).  For a lane whose entering (leaving) k-mer is x: transitions of LOWER lanes happen
+            // before its window, so its count of x is off by #entries - #exits of x among them; #exits below =
+            // lane - #non-exits below, so one chain of four v_mbcnt started at -lane gives the difference.
             int32_t corrP = 0, corrS = 0;
-            // (every round clears the pending bit of the lane it was started from: at most 128 rounds)
-            while ((pendE | pendL) != 0) {
-                {
-                    uint32_t x0;
-                    if (pendE) x0 = (uint32_t)__builtin_amdgcn_readlane((int)kp, __builtin_ctzll(pendE));
-                    else x0 = (uint32_t)__builtin_amdgcn_readlane((int)ks, __builtin_ctzll(pendL));
-                    const uint64_t eqP = __builtin_amdgcn_uicmp(kp, x0, 32 /* eq */), eqS = __builtin_amdgcn_uicmp(ks, x0, 32 /* eq */);
-                    // transitions of lower lanes happen before this lane's window: #entries - #exits among them.
-                    // #exits below = lane - #non-exits below, so one chain of four v_mbcnt started at -lane gives the difference
-                    const uint64_t ME = eqP & AE, MLn = ~(eqS & AL);
-                    uint32_t v = __builtin_amdgcn_mbcnt_lo((uint32_t)ME, (uint32_t)neg_lane);
-                    v = __builtin_amdgcn_mbcnt_hi((uint32_t)(ME >> 32), v);
-                    v = __builtin_amdgcn_mbcnt_lo((uint32_t)MLn, v);
-                    v = __builtin_amdgcn_mbcnt_hi((uint32_t)(MLn >> 32), v);
-                    corrP = kp == x0 ? (int32_t)v : corrP;
-                    corrS = ks == x0 ? (int32_t)v : corrS;
-                    pendE &= ~eqP;
-                    pendL &= ~eqS;
-                }
-            }
+            auto round = [&](const uint32_t x0) {
+                const uint64_t eqP = __builtin_amdgcn_uicmp(kp, x0, 32 /* eq */), eqS = __builtin_amdgcn_uicmp(ks, x0, 32 /* eq */);
+                const uint64_t ME = eqP & AE, MLn = ~(eqS & AL);
+                uint32_t v = __builtin_amdgcn_mbcnt_lo((uint32_t)ME, (uint32_t)neg_lane);
+                v = __builtin_amdgcn_mbcnt_hi((uint32_t)(ME >> 32), v);
+                v = __builtin_amdgcn_mbcnt_lo((uint32_t)MLn, v);
+                v = __builtin_amdgcn_mbcnt_hi((uint32_t)(MLn >> 32), v);
+                corrP = kp == x0 ? (int32_t)v : corrP;
+                corrS = ks == x0 ? (int32_t)v : corrS;
+                pendE &= ~eqP;
+                pendL &= ~eqS;
+            };
+            while (pendE != 0) round((uint32_t)__builtin_amdgcn_readlane((int)kp, __builtin_ctzll(pendE)));
+            while (pendL != 0) round((uint32_t)__builtin_amdgcn_readlane((int)ks, __builtin_ctzll(pendL)));
             cP = (int32_t)cp + corrP;
             cS = (int32_t)cs + corrS;
         }
