@@ -307,7 +307,7 @@ void threshold_band(double thr, int k, int64_t N, int64_t *T_lo, int64_t *T_hi)
 // Launch groups: KFVs sorted by window size; a launch takes up to KGMA_MAX_GROUP KFVs whose sizes
 // span at most KGMA_MAX_DW with at most KGMA_MAX_SIZES distinct values (the match loop runs once, for
 // the largest).
-std::vector<Group> make_groups(const kgma_ctx *ctx, int mode)
+std::vector<Group> make_groups(const kgma_ctx *ctx, int mode, bool same_size_only = false)
 {
     std::vector<Group> gs;
     if (mode == KGMA_MODE_SINGLE) {
@@ -326,7 +326,7 @@ std::vector<Group> make_groups(const kgma_ctx *ctx, int mode)
             int64_t last = -1;
             for (int u : g.kfvs) { if (ctx->kfv[(size_t)u].W != last) { distinct++; last = ctx->kfv[(size_t)u].W; } }
             const int64_t wmin = ctx->kfv[(size_t)g.kfvs.front()].W;
-            if ((int)g.kfvs.size() < KGMA_MAX_GROUP && W - wmin <= KGMA_MAX_DW && (W == last || distinct < KGMA_MAX_SIZES)) {
+            if ((int)g.kfvs.size() < KGMA_MAX_GROUP && W - wmin <= KGMA_MAX_DW && (W == last || (distinct < KGMA_MAX_SIZES && !same_size_only))) {
                 g.kfvs.push_back(j);
                 g.W = W;        // largest so far (sorted)
                 placed = true;
@@ -1300,11 +1300,24 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     for (int j = 0; j < m_used; j++) maxws = std::max(maxws, ctx->kfv[(size_t)j].W);
     // ---- which kernel: the count-table stream kernel for k <= 7 (one wave per stream), the bit-sliced
     //      kernel for longer k-mers (their 4^k counters do not fit a wave's share of the LDS)
-    const std::vector<Group> groups = make_groups(ctx, mode);
     // (measured, 400 Mb random sequence: k=6 one KFV 294 vs 172 Gbp/s; below k=5 the 64 transitions of
-    // a step collide too often, and with several KFVs / k=7 the per-wave LDS share leaves too few waves)
+    // a step collide too often, and at k=7 the per-wave LDS share leaves too few waves)
+    // Several KFVs: the 8-bit stream kernel takes the KFVs of ONE window size per launch (they share the k-mers, the
+    // count table and the corrections), so the cluster engine's KFVs are grouped by window size for it; the bit-sliced
+    // kernel groups up to 8 KFVs of up to 4 sizes.
+    const char *kenv = getenv("KGMA_KERNEL");                    // testing only: run the other kernel where both apply
+    bool s8_all = k >= 5 && k <= 6 && !(kenv && !strcmp(kenv, "bitslice"));
+    for (int j = 0; j < m_used && s8_all; j++)
+        s8_all = stream8_applies(k, (int)(ctx->kfv[(size_t)j].W - k + 1), 1, ctx->kfv[(size_t)j].N);
+    const std::vector<Group> groups = make_groups(ctx, mode, s8_all);
+    auto group_nmax = [&](const Group &gr) { int64_t n = 0; for (int j : gr.kfvs) n = std::max(n, ctx->kfv[(size_t)j].N); return n; };
+    auto group_one_size = [&](const Group &gr) { return ctx->kfv[(size_t)gr.kfvs.front()].W == ctx->kfv[(size_t)gr.kfvs.back()].W; };
+    auto group_s8 = [&](const Group &gr) {
+        return group_one_size(gr) && stream8_applies(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr));
+    };
     bool use_stream = k >= 5 && k <= 6;
-    for (const Group &gr : groups) if (gr.kfvs.size() != 1) use_stream = false;   // several KFVs: 99 vs 112 Gbp/s (3 KFVs)
+    for (const Group &gr : groups)
+        if (gr.kfvs.size() != 1 && !group_s8(gr)) use_stream = false;   // (the 16-bit multi-KFV stream kernel lost to the bit-sliced one: 99 vs 112 Gbp/s)
     if (const char *kv = getenv("KGMA_KERNEL")) {      // testing only: run the other kernel where both apply
         if (!strcmp(kv, "bitslice")) use_stream = false;
         if (!strcmp(kv, "stream")) use_stream = k <= KGMA_STREAM_MAX_K;
@@ -1317,7 +1330,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             for (int j : gr.kfvs) { if (ctx->kfv[(size_t)j].W != prev) n_sizes++; prev = ctx->kfv[(size_t)j].W; }
             bool s16 = true;
             for (int j : gr.kfvs) s16 = s16 && ctx->kfv[(size_t)j].Smax <= 32767;
-            const int nw = stream_slots_per_cu(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), n_sizes, s16, ctx->kfv[(size_t)gr.kfvs.front()].N);
+            const int nw = stream_slots_per_cu(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), n_sizes, s16, group_nmax(gr));
             if (nw < 1) use_stream = false;
             stream_nw = std::min(stream_nw, nw);
         }
@@ -1327,8 +1340,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     {
         bool s8 = use_stream;
         if (use_stream)
-            for (const Group &gr : groups)
-                s8 = s8 && stream8_applies(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), ctx->kfv[(size_t)gr.kfvs.front()].N);
+            for (const Group &gr : groups) s8 = s8 && group_s8(gr);
         snprintf(ctx->kernel_name, sizeof ctx->kernel_name, s8 ? "stream8_kernel<%d>" : use_stream ? "stream_kernel<%d>" : "scan_kernel<%d>", k);   // (+ pos_kernel for multi-KFV groups)
     }
 
@@ -1534,6 +1546,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             gp.nk = (int32_t)(gr.W - k + 1);                                  // largest window of the launch
             gp.nk_min = (int32_t)(ctx->kfv[(size_t)gr.kfvs.front()].W - k + 1);
             gp.nblocks = scan_nblocks(gp.nk);
+            gp.stream_slots = use_stream ? stream_nw : 0;
             if (const char *ds = getenv("KGMA_DEBUG_SKIP")) gp.debug_skip = atoi(ds);   // timing experiments only
             for (size_t u = 0; u < gr.kfvs.size(); u++) {
                 const int j = gr.kfvs[u];
@@ -1556,7 +1569,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             a.tiles = ctx->d_tiles;
             // all tables; the kernel indexes by KFV id.  The 16-bit stream kernel indexes k-mers as (hi bits << k) | lo bits,
             // the bit-sliced kernel and the 8-bit stream kernel by the 2-bit interleaved code (first base least significant)
-            a.Stab = (use_stream && !stream8_applies(k, gp.nk, gp.n_kfv, ctx->kfv[(size_t)gr.kfvs.front()].N)) ? ctx->d_StabC : ctx->d_Stab;
+            a.Stab = (use_stream && !group_s8(gr)) ? ctx->d_StabC : ctx->d_Stab;
             a.D0out = d_D0;                        // [KFV id - 1][tile]
             a.recs = d_recs;
             a.rec_count = reinterpret_cast<unsigned int *>(d_cnt);

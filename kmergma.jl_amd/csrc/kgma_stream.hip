@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdlib>
+#include <cstring>
 
 #include <type_traits>
 
@@ -519,38 +520,58 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
 // ------------------------------------------------------------------------------------------
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
-template <int K, bool S16>
-__global__ __launch_bounds__(1024, 8) void stream8_kernel(ScanArgs a, GroupParams gp)
+template <int K, bool S16, int NKFV>
+__global__ __launch_bounds__(1024, NKFV == 1 ? 8 : (NKFV <= 4 ? 6 : 4)) void stream8_kernel(ScanArgs a, GroupParams gp)
 {
+    // The launch parameters that only rare paths need (first-window D, thresholds, record emission, distances) are
+    // read from the kernel-argument segment where they are used, through a pointer the optimiser cannot see through:
+    // held in scalar registers for the whole kernel they push the per-KFV hot state out (hundreds of spills).
+    const GroupParams *gpp;
+    {
+        const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(ScanArgs) + 7) & ~(size_t)7);
+        asm volatile("" : "+s"(ka));
+        gpp = reinterpret_cast<const GroupParams *>(ka);
+    }
+    const int n_kfv = NKFV == 1 ? 1 : gp.n_kfv;                        // KFVs of this launch (<= NKFV), all of ONE window size
     constexpr int NB = 1 << (2 * K);
     extern __shared__ uint32_t smem[];
 
     const int lane = threadIdx.x & 63;
     const int wave = uni((int)(threadIdx.x >> 6));
 
-    // ---- LDS: [S table: int16 or int32 per k-mer] then per wave [NB byte counters]
-    constexpr size_t tab_words = S16 ? NB / 2 : NB;
+    // ---- LDS: [S tables: NKFV x (int16 or int32 per k-mer)] then per wave [NB byte counters | cold per-KFV dip state (NKFV > 1)]
+    constexpr size_t tab_words_1 = S16 ? NB / 2 : NB;
+    constexpr size_t per_wave_words = NB / 4 + (NKFV > 1 ? NKFV * ST_WORDS : 0);
     int32_t *sTab32 = reinterpret_cast<int32_t *>(smem);
     int16_t *sTab16 = reinterpret_cast<int16_t *>(smem);
-    uint32_t *C = smem + tab_words + (size_t)wave * (NB / 4);
-    {
-        const int32_t *Sg = a.Stab + (size_t)(gp.kfv_id[0] - 1) * NB;
+    uint32_t *C = smem + tab_words_1 * NKFV + (size_t)wave * per_wave_words;
+    int32_t *sState = reinterpret_cast<int32_t *>(C + NB / 4);
+#pragma unroll
+    for (int j = 0; j < NKFV; j++) {
+        if (j >= n_kfv) continue;
+        const int32_t *Sg = a.Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
         for (int i = threadIdx.x; i < NB; i += blockDim.x) {
-            if constexpr (S16) sTab16[i] = (int16_t)Sg[i];
-            else sTab32[i] = Sg[i];
+            if constexpr (S16) sTab16[(size_t)j * NB + i] = (int16_t)Sg[i];
+            else sTab32[(size_t)j * NB + i] = Sg[i];
         }
-        __syncthreads();
     }
+    __syncthreads();
     const int tile = wave * (int)gridDim.x + (int)blockIdx.x;         // streams are dealt to workgroups round-robin
     if (tile >= a.n_tiles) return;                                    // (after the only workgroup barrier)
 
     for (int i = lane; i < NB / 4; i += 64) C[i] = 0;
-    int32_t st[ST_WORDS];
+    if constexpr (NKFV > 1) { for (int i = lane; i < NKFV * ST_WORDS; i += 64) sState[i] = 0; }
+    int32_t st_reg[ST_WORDS];                                         // NKFV == 1: the dip state stays in registers
 #pragma unroll
-    for (int i = 0; i < ST_WORDS; i++) st[i] = 0;
-    int32_t h_carry = 0, h_TE = 0;
-    bool in_run_flag = false, has_att = false;
-    const bool want_dist = a.dist[0] != nullptr;
+    for (int i = 0; i < ST_WORDS; i++) st_reg[i] = 0;
+    // hot per-KFV state (wave-uniform): prefix carry, threshold; one bit per KFV for "inside a dip", "has a guard band", "distances"
+    int32_t h_carry[NKFV], h_TE[NKFV];
+#pragma unroll
+    for (int j = 0; j < NKFV; j++) { h_carry[j] = 0; h_TE[j] = 0; }
+    uint32_t inrun_mask = 0, att_mask = 0, dist_mask = 0;
+#pragma unroll
+    for (int j = 0; j < NKFV; j++)
+        if (j < n_kfv && a.dist[j] != nullptr) dist_mask |= 1u << j;
     // heavy k-mer (wave-uniform)
     bool heavy = false;
     uint32_t Hkey = 0, hcnt = 0;
@@ -562,9 +583,6 @@ __global__ __launch_bounds__(1024, 8) void stream8_kernel(ScanArgs a, GroupParam
     const uint32_t *gi = a.inter + 2 * td.word_base;
     const int n_pos = n_valid + nk - 1;
     const int n_blocks = (n_pos + 63) >> 6;
-    const int32_t Nj = gp.N[0];
-    const int64_t twoN = 2 * (int64_t)Nj;
-    const int kid = gp.kfv_id[0];
 
     // k-mer at position p = 64 b + lane: bits 2 (p & 15) ... of the dword pair starting at dword p >> 4.
     // The pair of the NEXT step is loaded one step ahead.  Steady steps use buffer loads: a wave-uniform
@@ -615,9 +633,14 @@ __global__ __launch_bounds__(1024, 8) void stream8_kernel(ScanArgs a, GroupParam
 
         // ---- every LDS operation of the step back to back (the S lookups first: LDS operations of a wave
         //      complete in order, so the wait for the count operations below covers them) -----------------
-        int32_t Sr, Sl;
-        if constexpr (S16) { Sr = sTab16[kp]; Sl = sTab16[ks]; }
-        else { Sr = sTab32[kp]; Sl = sTab32[ks]; }
+        int32_t Sr[NKFV], Sl[NKFV];
+#pragma unroll
+        for (int j = 0; j < NKFV; j++) {
+            Sr[j] = Sl[j] = 0;
+            if (j >= n_kfv) continue;
+            if constexpr (S16) { Sr[j] = sTab16[(size_t)j * NB + kp]; Sl[j] = sTab16[(size_t)j * NB + ks]; }
+            else { Sr[j] = sTab32[(size_t)j * NB + kp]; Sl[j] = sTab32[(size_t)j * NB + ks]; }
+        }
         const uint8_t *Cb = reinterpret_cast<const uint8_t *>(C);
         uint32_t cp = Cb[kp], cs = Cb[ks];                            // counts at the start of the step (raw bytes)
         const uint32_t shp = 8u * (kp & 3u), shs = 8u * (ks & 3u);
@@ -686,116 +709,127 @@ __global__ __launch_bounds__(1024, 8) void stream8_kernel(ScanArgs a, GroupParam
         }
         // left == right: same k-mer, same count, difference 0; otherwise c[l] - 1 - c[r]
         const int32_t dd = cS - cP - (differ ? 1 : 0);
-        // GenomeMiner.jl:67-68 times 2kN^2 / 2N.  Without a transition the two k-mers are equal (Sl == Sr,
-        // dd == 0) except in the warm-up, where there is no leaving k-mer at all.
-        int32_t e = Sl - Sr - __mul24(Nj, dd);
-        if constexpr (GENERIC) e = actL ? e : 0;
+        // ---- per KFV (all of this launch's KFVs have the same window: same k-mers, same counts) ----------------
+#pragma unroll
+        for (int j = 0; j < NKFV; j++) {
+            if (j >= n_kfv) continue;
+            int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
+            const int32_t Nj = gp.N[j];
+            const int64_t twoN = 2 * (int64_t)Nj;
+            // GenomeMiner.jl:67-68 times 2kN^2 / 2N.  Without a transition the two k-mers are equal (Sl == Sr,
+            // dd == 0) except in the warm-up, where there is no leaving k-mer at all.
+            int32_t e = Sl[j] - Sr[j] - __mul24(Nj, dd);
+            if constexpr (GENERIC) e = actL ? e : 0;
 
-        if constexpr (GENERIC) {
-            if ((b << 6) < nk) {                                      // warm-up steps: first-window D
-                const bool wu = p < nk;
-                const int64_t ssum = wave_sum_i64(wu ? (int64_t)Sr : 0);
-                const int64_t psum = wave_sum_i64(wu ? (int64_t)cP : 0);
-                int64_t sumS = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_SUMHI]) << 32) | (uint32_t)uni(st[ST_SUMLO])) + ssum;
-                const int32_t pairs = uni(st[ST_PAIRS]) + (int32_t)psum;
-                st[ST_SUMLO] = (int32_t)(uint32_t)sumS;
-                st[ST_SUMHI] = (int32_t)(uint32_t)((uint64_t)sumS >> 32);
-                st[ST_PAIRS] = pairs;
-                if (nk - 1 < (b << 6) + 64) {                         // last warm-up position is in this step
-                    const int64_t D0 = gp.sumS2[0] - twoN * sumS + (int64_t)Nj * Nj * ((int64_t)nk + 2 * (int64_t)pairs);
-                    if (lane == 0) a.D0out[(size_t)(kid - 1) * a.n_tiles + tile] = D0;
-                    st[ST_D0LO] = (int32_t)(uint32_t)D0;
-                    st[ST_D0HI] = (int32_t)(uint32_t)((uint64_t)D0 >> 32);
-                    const int64_t num = gp.T[0] - D0;
-                    int64_t TE64 = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
-                    const int64_t numh = gp.T_hi[0] - D0;
-                    const int64_t TH64 = numh >= 0 ? numh / twoN : -((-numh + twoN - 1) / twoN);
-                    int64_t na = gp.T_hi[0] >= gp.T[0] ? TH64 - TE64 + 1 : 0;
-                    if (na < 0) na = 0;
-                    if (na > 0x3FFFFFFF) na = 0x3FFFFFFF;
-                    if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; na = 0; }
-                    if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; na = 0; }
-                    h_TE = uni((int32_t)TE64);
-                    st[ST_NATT] = (int32_t)na;
-                    has_att = uni((int32_t)na) != 0;
-                }
-            }
-        }
-
-        const int32_t E = wave_incl_scan(e) + h_carry;
-        h_carry = __builtin_amdgcn_readlane(E, 63);
-        const int32_t TE = h_TE;
-        const int q = p - nk + 1;                                     // window start (local) this transition leads to
-        bool tested = true;
-        if constexpr (GENERIC) tested = q >= first_test && q < n_valid;
-        const bool under = tested && E < TE;
-        if (want_dist) {
-            if (tested) {
-                const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
-                a.dist[0][td.dist_base + q] = (double)(D0 + twoN * (int64_t)E) / gp.inv_scale[0];
-            }
-        }
-        bool att = false;
-        uint64_t A = 0;
-        if (has_att) {                                                // (only when the threshold sits on the distance lattice)
-            att = tested && !under && E - TE < uni(st[ST_NATT]);
-            A = __ballot(att);
-        }
-        const uint64_t U = __ballot(under);
-        int in_run = in_run_flag ? 1 : 0;
-        if ((U | A) == 0 && !in_run) return;                          // fast path: nothing near the threshold
-
-        // ---- a dip touches this step: walk its runs (wave-uniform) ----------------------------
-        const int q0 = (b << 6) - nk + 1;                             // window of lane 0
-        if (att) {
-            DevRecord rec;
-            rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8);
-            rec.start = q; rec.end = q; rec.minE = E;
-            rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
-            emit_global(a, rec);
-            atomicAdd(a.n_att, 1ull);
-        }
-        int run_start = uni(st[ST_START]), minE = uni(st[ST_MINE]), argf = uni(st[ST_ARGF]), argl = uni(st[ST_ARGL]),
-            nmin = uni(st[ST_NMIN]);
-        int cursor = 0;
-        while (cursor < 64) {
-            const uint64_t rem = ~(uint64_t)0 << cursor;
-            if (in_run) {
-                const uint64_t nz = ~U & rem;
-                const int end_lane = nz ? __builtin_ctzll(nz) : 64;
-                if (end_lane > cursor) {
-                    const bool inseg = lane >= cursor && lane < end_lane;
-                    const int32_t segmin = wave_min_i32(inseg ? E : 0x7FFFFFFF);
-                    const uint64_t eq = __ballot(inseg && E == segmin);
-                    const int fl = __builtin_ctzll(eq), ll2 = 63 - __builtin_clzll(eq), pc = __builtin_popcountll(eq);
-                    if (nmin == 0 || segmin < minE) { minE = segmin; argf = q0 + fl; argl = q0 + ll2; nmin = pc; }
-                    else if (segmin == minE) { argl = q0 + ll2; nmin += pc; }
-                }
-                if (end_lane < 64) {
-                    const int qe = q0 + end_lane;
-                    const int32_t exitE = __builtin_amdgcn_readlane(E, end_lane);
-                    if (lane == 0) {
-                        DevRecord rec;
-                        rec.tile = tile; rec.kind_kfv = REC_RUN | (kid << 8);
-                        rec.start = run_start; rec.end = qe - 1; rec.minE = minE;
-                        rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
-                        rec.exitE = exitE; rec.has_exit = qe < n_valid ? 1 : 0;
-                        emit_global(a, rec);
+            if constexpr (GENERIC) {
+                if ((b << 6) < nk) {                                  // warm-up steps: first-window D
+                    const bool wu = p < nk;
+                    const int64_t ssum = wave_sum_i64(wu ? (int64_t)Sr[j] : 0);
+                    const int64_t psum = wave_sum_i64(wu ? (int64_t)cP : 0);
+                    int64_t sumS = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_SUMHI]) << 32) | (uint32_t)uni(st[ST_SUMLO])) + ssum;
+                    const int32_t pairs = uni(st[ST_PAIRS]) + (int32_t)psum;
+                    st[ST_SUMLO] = (int32_t)(uint32_t)sumS;
+                    st[ST_SUMHI] = (int32_t)(uint32_t)((uint64_t)sumS >> 32);
+                    st[ST_PAIRS] = pairs;
+                    if (nk - 1 < (b << 6) + 64) {                     // last warm-up position is in this step
+                        const int64_t D0 = gpp->sumS2[j] - twoN * sumS + (int64_t)Nj * Nj * ((int64_t)nk + 2 * (int64_t)pairs);
+                        if (lane == 0) a.D0out[(size_t)(gpp->kfv_id[j] - 1) * a.n_tiles + tile] = D0;
+                        st[ST_D0LO] = (int32_t)(uint32_t)D0;
+                        st[ST_D0HI] = (int32_t)(uint32_t)((uint64_t)D0 >> 32);
+                        // E_q < TE  <=>  D0 + 2N E_q < T; windows with TE <= E_q < TE + natt are at threshold
+                        const int64_t Tj = gpp->T[j], Thj = gpp->T_hi[j];
+                        const int64_t num = Tj - D0;
+                        int64_t TE64 = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
+                        const int64_t numh = Thj - D0;
+                        const int64_t TH64 = numh >= 0 ? numh / twoN : -((-numh + twoN - 1) / twoN);
+                        int64_t na = Thj >= Tj ? TH64 - TE64 + 1 : 0;
+                        if (na < 0) na = 0;
+                        if (na > 0x3FFFFFFF) na = 0x3FFFFFFF;
+                        if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; na = 0; }
+                        if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; na = 0; }
+                        h_TE[j] = uni((int32_t)TE64);
+                        st[ST_NATT] = (int32_t)na;
+                        if (uni((int32_t)na) != 0) att_mask |= 1u << j;
                     }
-                    in_run = 0;
-                    cursor = end_lane;
-                } else {
-                    cursor = 64;
                 }
-            } else {
-                const uint64_t nu = U & rem;
-                if (!nu) break;
-                cursor = __builtin_ctzll(nu);
-                in_run = 1; run_start = q0 + cursor; nmin = 0; minE = 0; argf = argl = run_start;
             }
+
+            const int32_t E = wave_incl_scan(e) + h_carry[j];
+            h_carry[j] = __builtin_amdgcn_readlane(E, 63);
+            const int32_t TE = h_TE[j];
+            const int q = p - nk + 1;                                 // window start (local) this transition leads to
+            bool tested = true;
+            if constexpr (GENERIC) tested = q >= first_test && q < n_valid;
+            const bool under = tested && E < TE;
+            if ((dist_mask >> j) & 1u) {
+                if (tested) {
+                    const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
+                    a.dist[j][td.dist_base + q] = (double)(D0 + twoN * (int64_t)E) / gpp->inv_scale[j];
+                }
+            }
+            bool att = false;
+            uint64_t A = 0;
+            if ((att_mask >> j) & 1u) {                                // (only when the threshold sits on the distance lattice)
+                att = tested && !under && E - TE < uni(st[ST_NATT]);
+                A = __ballot(att);
+            }
+            const uint64_t U = __ballot(under);
+            int in_run = (int)((inrun_mask >> j) & 1u);
+            if ((U | A) == 0 && !in_run) continue;                    // fast path: nothing near the threshold
+
+            // ---- a dip touches this step: walk its runs (wave-uniform) ----------------------------
+            const int kid = gpp->kfv_id[j];
+            const int q0 = (b << 6) - nk + 1;                         // window of lane 0
+            if (att) {
+                DevRecord rec;
+                rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8);
+                rec.start = q; rec.end = q; rec.minE = E;
+                rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
+                emit_global(a, rec);
+                atomicAdd(a.n_att, 1ull);
+            }
+            int run_start = uni(st[ST_START]), minE = uni(st[ST_MINE]), argf = uni(st[ST_ARGF]), argl = uni(st[ST_ARGL]),
+                nmin = uni(st[ST_NMIN]);
+            int cursor = 0;
+            while (cursor < 64) {
+                const uint64_t rem = ~(uint64_t)0 << cursor;
+                if (in_run) {
+                    const uint64_t nz = ~U & rem;
+                    const int end_lane = nz ? __builtin_ctzll(nz) : 64;
+                    if (end_lane > cursor) {
+                        const bool inseg = lane >= cursor && lane < end_lane;
+                        const int32_t segmin = wave_min_i32(inseg ? E : 0x7FFFFFFF);
+                        const uint64_t eq = __ballot(inseg && E == segmin);
+                        const int fl = __builtin_ctzll(eq), ll2 = 63 - __builtin_clzll(eq), pc = __builtin_popcountll(eq);
+                        if (nmin == 0 || segmin < minE) { minE = segmin; argf = q0 + fl; argl = q0 + ll2; nmin = pc; }
+                        else if (segmin == minE) { argl = q0 + ll2; nmin += pc; }
+                    }
+                    if (end_lane < 64) {
+                        const int qe = q0 + end_lane;
+                        const int32_t exitE = __builtin_amdgcn_readlane(E, end_lane);
+                        if (lane == 0) {
+                            DevRecord rec;
+                            rec.tile = tile; rec.kind_kfv = REC_RUN | (kid << 8);
+                            rec.start = run_start; rec.end = qe - 1; rec.minE = minE;
+                            rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
+                            rec.exitE = exitE; rec.has_exit = qe < n_valid ? 1 : 0;
+                            emit_global(a, rec);
+                        }
+                        in_run = 0;
+                        cursor = end_lane;
+                    } else {
+                        cursor = 64;
+                    }
+                } else {
+                    const uint64_t nu = U & rem;
+                    if (!nu) break;
+                    cursor = __builtin_ctzll(nu);
+                    in_run = 1; run_start = q0 + cursor; nmin = 0; minE = 0; argf = argl = run_start;
+                }
+            }
+            inrun_mask = (inrun_mask & ~(1u << j)) | ((uint32_t)in_run << j);
+            st[ST_START] = run_start; st[ST_MINE] = minE; st[ST_ARGF] = argf; st[ST_ARGL] = argl; st[ST_NMIN] = nmin;
         }
-        in_run_flag = in_run != 0;
-        st[ST_START] = run_start; st[ST_MINE] = minE; st[ST_ARGF] = argf; st[ST_ARGL] = argl; st[ST_NMIN] = nmin;
     };
 
     int b_warm = (nk + 63) >> 6;
@@ -809,13 +843,19 @@ __global__ __launch_bounds__(1024, 8) void stream8_kernel(ScanArgs a, GroupParam
     for (; b < b_tail; b++) step(b, std::false_type{});
     for (; b < n_blocks; b++) step(b, std::true_type{});
 
-    if (in_run_flag && lane == 0) {                                   // run still open at the end of the stream
-        DevRecord rec;
-        rec.tile = tile; rec.kind_kfv = REC_RUN | (kid << 8);
-        rec.start = st[ST_START]; rec.end = n_valid - 1; rec.minE = st[ST_MINE];
-        rec.argf = st[ST_ARGF]; rec.argl = st[ST_ARGL]; rec.nmin = st[ST_NMIN];
-        rec.exitE = 0; rec.has_exit = 0;
-        emit_global(a, rec);
+    // ---- runs still open at the end of the stream (the host joins them with the next stream's) ----
+#pragma unroll
+    for (int j = 0; j < NKFV; j++) {
+        if (j >= n_kfv) continue;
+        const int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
+        if (((inrun_mask >> j) & 1u) && lane == 0) {
+            DevRecord rec;
+            rec.tile = tile; rec.kind_kfv = REC_RUN | (gpp->kfv_id[j] << 8);
+            rec.start = st[ST_START]; rec.end = n_valid - 1; rec.minE = st[ST_MINE];
+            rec.argf = st[ST_ARGF]; rec.argl = st[ST_ARGL]; rec.nmin = st[ST_NMIN];
+            rec.exitE = 0; rec.has_exit = 0;
+            emit_global(a, rec);
+        }
     }
 }
 
@@ -870,7 +910,7 @@ static hipError_t launch_stream_k(const ScanArgs &a, const GroupParams &gp, hipS
     return hipGetLastError();
 }
 
-// ---- 8-bit counter kernel: one KFV, k = 5 or 6, at most 383 k-mers per window --------------------
+// ---- 8-bit counter kernel: 1 ... 8 KFVs of ONE window size, k = 5 or 6, at most 383 k-mers per window
 constexpr int KGMA_STREAM8_MAX_NK = 383;
 
 static bool stream8_env_on()                         // KGMA_STREAM8=0 (testing): keep the 16-bit counter kernel; read at every scan
@@ -879,71 +919,102 @@ static bool stream8_env_on()                         // KGMA_STREAM8=0 (testing)
     return !(e && atoi(e) == 0);
 }
 
-// (N < 2^22: the kernel multiplies N by a count difference with the 24-bit multiplier)
+// (N < 2^22: the kernel multiplies N by a count difference with the 24-bit multiplier; n_ref = largest N of the launch)
 bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref)
 {
-    return stream8_env_on() && n_kfv == 1 && (k == 5 || k == 6) && nk <= KGMA_STREAM8_MAX_NK && n_ref < ((int64_t)1 << 22);
+    return stream8_env_on() && n_kfv >= 1 && n_kfv <= KGMA_MAX_GROUP && (k == 5 || k == 6) && nk <= KGMA_STREAM8_MAX_NK &&
+           n_ref < ((int64_t)1 << 22);
 }
 
-static size_t stream8_lds(int k, bool s16, int nw)
+static int stream8_variant(int n_kfv) { return n_kfv <= 1 ? 1 : n_kfv <= 2 ? 2 : n_kfv <= 4 ? 4 : 8; }   // instantiated NKFV
+
+static size_t stream8_lds(int k, bool s16, int nkfv, int nw)
 {
     const size_t NB = (size_t)1 << (2 * k);
-    return NB * (s16 ? 2 : 4) + (size_t)nw * NB;
+    return NB * (s16 ? 2 : 4) * (size_t)nkfv + (size_t)nw * (NB + (nkfv > 1 ? (size_t)nkfv * ST_WORDS * 4 : 0));
 }
 
 template <int K, bool S16>
-static const void *stream8_fn() { return reinterpret_cast<const void *>(&stream8_kernel<K, S16>); }
-
-static const void *stream8_fn_of(int k, bool s16)
+static const void *stream8_fn_k(int nkfv)
 {
-    if (k == 5) return s16 ? stream8_fn<5, true>() : stream8_fn<5, false>();
-    return s16 ? stream8_fn<6, true>() : stream8_fn<6, false>();
+    switch (nkfv) {
+    case 1: return reinterpret_cast<const void *>(&stream8_kernel<K, S16, 1>);
+    case 2: return reinterpret_cast<const void *>(&stream8_kernel<K, S16, 2>);
+    case 4: return reinterpret_cast<const void *>(&stream8_kernel<K, S16, 4>);
+    default: return reinterpret_cast<const void *>(&stream8_kernel<K, S16, 8>);
+    }
 }
 
-// waves per workgroup and workgroups per CU: two 16-wave workgroups when the LDS holds them (asked of the
-// runtime, which knows the allocation granule), else the largest workgroup that still runs two per CU
-void stream8_geometry(int k, bool s16, int *nw_out, int *blocks_out)
+static const void *stream8_fn_of(int k, bool s16, int nkfv)
 {
-    static int cache[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};     // [k-5][s16] -> {nw, blocks}
-    int *c = cache[k - 5][s16 ? 1 : 0];
+    if (k == 5) return s16 ? stream8_fn_k<5, true>(nkfv) : stream8_fn_k<5, false>(nkfv);
+    return s16 ? stream8_fn_k<6, true>(nkfv) : stream8_fn_k<6, false>(nkfv);
+}
+
+// waves per workgroup and workgroups per CU that keep the most streams resident (asked of the runtime, which knows
+// the LDS allocation granule and the kernel's registers); one KFV: two 16-wave workgroups = 32 waves per CU
+void stream8_geometry(int k, bool s16, int nkfv, int *nw_out, int *blocks_out)
+{
+    static int cache[2][2][9][2];
+    static bool init = false;
+    if (!init) { memset(cache, 0, sizeof cache); init = true; }
+    int *c = cache[k - 5][s16 ? 1 : 0][nkfv];
     if (c[0] == 0) {
-        int best_nw = 16, best_blocks = 1;
-        for (int nw = 16; nw >= 12; nw--) {
-            const size_t lds = stream8_lds(k, s16, nw);
+        int best_nw = 0, best_blocks = 0;
+        for (int nw = 16; nw >= 4; nw--) {
+            const size_t lds = stream8_lds(k, s16, nkfv, nw);
+            if (lds > ((size_t)160 << 10)) continue;
             int blocks = 0;
-            if (hipFuncSetAttribute(stream8_fn_of(k, s16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, stream8_fn_of(k, s16), 64 * nw, lds) != hipSuccess) continue;
-            if (blocks > 2) blocks = 2;                                   // 32 waves per CU
+            if (hipFuncSetAttribute(stream8_fn_of(k, s16, nkfv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, stream8_fn_of(k, s16, nkfv), 64 * nw, lds) != hipSuccess) continue;
+            if (blocks * nw > 32) blocks = 32 / nw;
             if (blocks * nw > best_blocks * best_nw) { best_blocks = blocks; best_nw = nw; }
-            if (blocks >= 2) break;
         }
         (void)hipGetLastError();
-        c[0] = best_nw; c[1] = best_blocks;
+        c[0] = best_nw > 0 ? best_nw : 4; c[1] = best_blocks > 0 ? best_blocks : 1;
     }
     *nw_out = c[0]; *blocks_out = c[1];
 }
 
-template <int K>
-static hipError_t launch_stream8_k(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+template <int K, bool S16>
+static void stream8_launch_ks(int nkfv, unsigned grid, unsigned threads, size_t lds, hipStream_t st, const ScanArgs &a, const GroupParams &gp)
+{
+    switch (nkfv) {
+    case 1: hipLaunchKernelGGL((stream8_kernel<K, S16, 1>), dim3(grid), dim3(threads), lds, st, a, gp); break;
+    case 2: hipLaunchKernelGGL((stream8_kernel<K, S16, 2>), dim3(grid), dim3(threads), lds, st, a, gp); break;
+    case 4: hipLaunchKernelGGL((stream8_kernel<K, S16, 4>), dim3(grid), dim3(threads), lds, st, a, gp); break;
+    default: hipLaunchKernelGGL((stream8_kernel<K, S16, 8>), dim3(grid), dim3(threads), lds, st, a, gp); break;
+    }
+}
+
+static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
 {
     const bool s16 = gp.s_fits_i16 != 0;
+    const int nkfv = stream8_variant(gp.n_kfv);
     int nw = 16, blocks = 1;
-    stream8_geometry(K, s16, &nw, &blocks);
-    const size_t lds = stream8_lds(K, s16, nw);
+    stream8_geometry(gp.k, s16, nkfv, &nw, &blocks);
+    // all launches of a scan share one stream table, sized for the launch that keeps the fewest streams resident:
+    // use workgroups that fill exactly that many wave slots per CU, so that every CU gets the same number of streams
+    if (gp.stream_slots > 0 && gp.stream_slots < nw * blocks) {
+        const int slots = gp.stream_slots;
+        if (slots % 2 == 0 && slots / 2 <= 16 && blocks >= 2) { nw = slots / 2; blocks = 2; }
+        else if (slots <= 16) { nw = slots; blocks = 1; }
+    }
+    const size_t lds = stream8_lds(gp.k, s16, nkfv, nw);
     const unsigned grid = (unsigned)((a.n_tiles + nw - 1) / nw);
-    hipError_t e = hipFuncSetAttribute(stream8_fn_of(K, s16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(stream8_fn_of(gp.k, s16, nkfv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (s16) hipLaunchKernelGGL((stream8_kernel<K, true>), dim3(grid), dim3((unsigned)(64 * nw)), lds, st, a, gp);
-    else hipLaunchKernelGGL((stream8_kernel<K, false>), dim3(grid), dim3((unsigned)(64 * nw)), lds, st, a, gp);
+    if (gp.k == 5) { if (s16) stream8_launch_ks<5, true>(nkfv, grid, 64u * nw, lds, st, a, gp); else stream8_launch_ks<5, false>(nkfv, grid, 64u * nw, lds, st, a, gp); }
+    else           { if (s16) stream8_launch_ks<6, true>(nkfv, grid, 64u * nw, lds, st, a, gp); else stream8_launch_ks<6, false>(nkfv, grid, 64u * nw, lds, st, a, gp); }
     return hipGetLastError();
 }
 
-// streams resident per CU (what the host sizes the streams for)
+// streams resident per CU (what the host sizes the streams for); n_ref = largest reference count of the launch's KFVs
 int stream_slots_per_cu(int k, int nk, int n_kfv, int n_sizes, bool s16, int64_t n_ref)
 {
-    if (stream8_applies(k, nk, n_kfv, n_ref)) {
+    if (n_sizes == 1 && stream8_applies(k, nk, n_kfv, n_ref)) {
         int nw = 16, blocks = 1;
-        stream8_geometry(k, s16, &nw, &blocks);
+        stream8_geometry(k, s16, stream8_variant(n_kfv), &nw, &blocks);
         return nw * blocks;
     }
     return stream_waves(k, nk, n_kfv, n_sizes);
@@ -951,7 +1022,11 @@ int stream_slots_per_cu(int k, int nk, int n_kfv, int n_sizes, bool s16, int64_t
 
 hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
 {
-    if (stream8_applies(gp.k, gp.nk, gp.n_kfv, gp.N[0])) return gp.k == 5 ? launch_stream8_k<5>(a, gp, st) : launch_stream8_k<6>(a, gp, st);
+    {
+        int64_t nmax = 0;
+        for (int j = 0; j < gp.n_kfv; j++) nmax = gp.N[j] > nmax ? gp.N[j] : nmax;
+        if (gp.n_sizes == 1 && stream8_applies(gp.k, gp.nk, gp.n_kfv, nmax)) return launch_stream8(a, gp, st);
+    }
     switch (gp.k) {
     case 2: return launch_stream_k<2>(a, gp, st);
     case 3: return launch_stream_k<3>(a, gp, st);
