@@ -271,6 +271,28 @@ int kgma_align_hits_device(kgma_ctx *ctx, const kgma_genome *genome, const uint8
                            int32_t gap_open_score, int32_t gap_extend_score, int64_t n_hits, const int32_t *contig,
                            const int64_t *lo, const int64_t *hi, int64_t *first_out, int64_t *last_out, int64_t *score_out);
 
+/* The scan with the hits' re-alignment done ON THE DEVICE in batches, for hosts that do not bring their
+ * own aligner: replaces, per hit, pairalign(SemiGlobalAlignment(), consensus, view(seq, range),
+ * AffineGapScoreModel(EDNAFULL, gap_open, gap_extend)) + cigar_to_UnitRange (src/Alignment.jl:13-30,41-46 for the single
+ * engine, against consensus[1:windowsize]; src/OmnGenomeMiner.jl:130-136 for the cluster engine, against the whole
+ * consensus_seqs[ind]).  consensus[j] / consensus_len[j]: one sequence per KFV (the single engine uses entry 0).
+ * Single engine: the hits of the scan are aligned in one batch.  Cluster engine: the aligned range feeds back into the
+ * overlap checks (OmnGenomeMiner.jl:126,139,152), but WHICH range is aligned depends only on a dip's best window and KFV,
+ * so every dip's candidate range is aligned speculatively in one batch per KFV right after the scan and the hit state
+ * machine looks the results up where the reference calls pairalign; a range that was not speculated is aligned by the
+ * host restatement (kgma_host_semiglobal_cigar) and counted in n_host.  Hits then come from kgma_get_hits (lo:hi =
+ * aligned range); kgma_get_alignments lists the alignments the state machine consumed, in order (first, last =
+ * cigar_to_UnitRange's result relative to lo). */
+typedef struct {
+    int32_t contig;
+    int32_t kfv;          /* 1-based; 0 for the single engine */
+    int64_t lo, hi;       /* the range that was aligned */
+    int64_t first, last;  /* cigar_to_UnitRange of the alignment (1-based, relative to lo; last < first: empty) */
+} kgma_alignment;
+int kgma_scan_aligned(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, int64_t genome_pos0, uint32_t flags,
+                      const uint8_t *const *consensus, const int64_t *consensus_len, int32_t gap_open_score, int32_t gap_extend_score);
+int kgma_get_alignments(kgma_ctx *ctx, kgma_alignment *out, int64_t cap, int64_t *n, int64_t *n_device, int64_t *n_host);
+
 /* kgma_genome_repack + kgma_scan (no align callback) + kgma_get_hits in one call, for callers that run the
  * whole step in a loop (bench.py): out must hold `cap` hits; if more were found KGMA_E_ARG is returned and
  * *n holds the number needed (the scan results stay valid: call kgma_get_hits with a larger buffer). */

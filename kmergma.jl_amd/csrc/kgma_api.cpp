@@ -173,6 +173,8 @@ struct kgma_ctx {
     const uint8_t *aux_host = nullptr;       // aux region of the last scan (pinned staging)
     unsigned int aux_used = 0;
     std::vector<kgma_hit> hits;
+    std::vector<kgma_alignment> aligns;      // alignments the hit state machine consumed (kgma_scan_aligned), in order
+    int64_t n_align_device = 0, n_align_host = 0;
     std::vector<int64_t> contig_len;
     int64_t n_dists_per_kfv = 0;
     int64_t tile_windows = KGMA_TILE_WINDOWS;
@@ -2325,6 +2327,175 @@ int kgma_resolve_ties_local(kgma_ctx *ctx, const kgma_genome *g)
             d.flags = (d.flags & ~(uint32_t)KGMA_HIT_TIE) | KGMA_HIT_TIE_RESOLVED;
         }
     }
+    return KGMA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// kgma_scan_aligned: the scan with the re-alignment of hits done ON THE DEVICE, in batches.
+//   single engine (GenomeMiner.jl:96-99): the alignment does not feed back, so the hits of the scan are
+//     re-aligned in one batch afterwards;
+//   cluster engine (OmnGenomeMiner.jl:126-153): the aligned range feeds the overlap checks, but the range that
+//     gets aligned depends only on a dip's best window (CMI) and its KFV -- so EVERY dip's candidate range
+//     max(CMI - buff, 1) : min(CMI + ws - 1 + buff, L) is aligned speculatively in one batch per KFV right after
+//     the scan, and the hit state machine looks the results up where the reference calls pairalign.  A range that
+//     was not speculated (a tie decided differently during the replay) is aligned by the host restatement.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct AlignKey {
+    int32_t contig, kfv; int64_t lo, hi;
+    bool operator<(const AlignKey &o) const
+    {
+        if (contig != o.contig) return contig < o.contig;
+        if (kfv != o.kfv) return kfv < o.kfv;
+        if (lo != o.lo) return lo < o.lo;
+        return hi < o.hi;
+    }
+};
+
+// cigar_to_UnitRange (src/Alignment.jl:13-30), quirks included: the LAST operation is dropped from the sum, `lower` is the
+// length of the FIRST operation whatever its type
+void cigar_range(const char *cigar, int64_t *first, int64_t *last)
+{
+    int64_t curr = 0, count = 0, sum = 0, lower = 0;
+    const size_t n = strlen(cigar);
+    for (size_t i = 1; i <= n; i++) {
+        if (i == n) break;
+        const char ch = cigar[i - 1];
+        if (ch >= '0' && ch <= '9') curr = curr * 10 + (ch - '0');
+        else { count++; if (count == 1) lower = curr; sum += curr; curr = 0; }
+    }
+    *first = lower + 1; *last = sum;
+}
+
+struct AlignedScan {
+    kgma_ctx *ctx; const kgma_genome *g;
+    const uint8_t *const *cons; const int64_t *cons_len; int32_t go, ge;
+    std::map<AlignKey, std::pair<int64_t, int64_t>> table;
+    bool failed = false;
+};
+
+void aligned_cb(void *user, int32_t contig, int32_t kfv, int64_t lo, int64_t hi, int64_t L, int64_t *out_lo, int64_t *out_hi)
+{
+    AlignedScan *A = static_cast<AlignedScan *>(user);
+    kgma_ctx *ctx = A->ctx;
+    int64_t first = 1, last = hi - lo + 1;
+    auto it = A->table.find(AlignKey{contig, kfv, lo, hi});
+    if (it != A->table.end()) {
+        first = it->second.first; last = it->second.second;
+        ctx->n_align_device++;
+    } else {
+        // not speculated: align on the host (the library's restatement of BioAlignments' semi-global affine alignment)
+        const int j = kfv > 0 ? kfv - 1 : 0;
+        const int64_t n = hi - lo + 1;
+        std::vector<uint8_t> seg((size_t)std::max<int64_t>(n, 1));
+        std::vector<char> cig((size_t)(2 * (A->cons_len[j] + n) + 16));
+        int64_t score = 0;
+        if (n < 1 || hipMemcpy(seg.data(), A->g->d_ascii + A->g->cd[(size_t)contig].ascii_off + (lo - 1), (size_t)n, hipMemcpyDeviceToHost) != hipSuccess ||
+            kgma_host_semiglobal_cigar(A->cons[j], A->cons_len[j], seg.data(), n, A->go, A->ge, cig.data(), (int64_t)cig.size(), &score) != KGMA_OK) {
+            A->failed = true;
+        } else {
+            cigar_range(cig.data(), &first, &last);
+        }
+        ctx->n_align_host++;
+    }
+    ctx->aligns.push_back(kgma_alignment{contig, kfv, lo, hi, first, last});
+    *out_lo = std::max<int64_t>(1, lo + first - 1);                   // Alignment.jl:46 / OmnGenomeMiner.jl:133-136
+    *out_hi = std::min<int64_t>(lo + last - 1, L);
+}
+
+}  // namespace
+
+int kgma_scan_aligned(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, int64_t genome_pos0, uint32_t flags,
+                      const uint8_t *const *consensus, const int64_t *consensus_len, int32_t gap_open_score, int32_t gap_extend_score)
+{
+    if (!ctx || !g) return KGMA_E_ARG;
+    if (!consensus || !consensus_len) return fail(ctx, KGMA_E_ARG, "null consensus");
+    if (buff < 0) return fail(ctx, KGMA_E_ARG, "buff < 0");
+    const int m_used = mode == KGMA_MODE_SINGLE ? 1 : ctx->m;
+    for (int j = 0; j < m_used; j++)
+        if (!consensus[j] || consensus_len[j] < 1 || consensus_len[j] > KGMA_ALIGN_MAX_CONSENSUS)
+            return fail(ctx, KGMA_E_UNSUPPORTED, "consensus %d: %lld residues", j + 1, (long long)consensus_len[j]);
+    ctx->aligns.clear();
+    ctx->n_align_device = ctx->n_align_host = 0;
+    int rc = kgma_scan_device(ctx, g, mode, flags);
+    if (rc) return rc;
+    ctx->stats.chain_ms = 0; ctx->stats.n_chain_pairs = 0; ctx->stats.chain_windows = 0;
+    if ((flags & KGMA_F_CHAIN_REPLAY) && !(flags & KGMA_F_NO_TIE_RESOLVE)) {
+        rc = chain_decide(ctx, g, mode);
+        if (rc) return rc;
+    } else if (!(flags & KGMA_F_NO_TIE_RESOLVE)) {
+        rc = kgma_resolve_ties_local(ctx, g);                          // the dips' best windows are final before they are aligned
+        if (rc) return rc;
+    }
+    if (mode == KGMA_MODE_SINGLE) {
+        // GenomeMiner.jl:96-99: align the hits' ranges (consensus[1:windowsize], Alignment.jl:42) in one batch
+        rc = replay_hits(ctx, g, mode, buff, genome_pos0, flags, nullptr, nullptr);
+        if (rc) return rc;
+        const int64_t nh = (int64_t)ctx->hits.size();
+        if (nh == 0) return KGMA_OK;
+        const int64_t W = ctx->kfv[0].W;
+        const int64_t cl = std::min<int64_t>(consensus_len[0], W);
+        std::vector<int32_t> hc((size_t)nh);
+        std::vector<int64_t> lo((size_t)nh), hi((size_t)nh), first((size_t)nh), last((size_t)nh);
+        for (int64_t i = 0; i < nh; i++) { hc[(size_t)i] = ctx->hits[(size_t)i].contig; lo[(size_t)i] = ctx->hits[(size_t)i].lo; hi[(size_t)i] = ctx->hits[(size_t)i].hi; }
+        rc = kgma_align_hits_device(ctx, g, consensus[0], cl, gap_open_score, gap_extend_score, nh, hc.data(), lo.data(), hi.data(),
+                                    first.data(), last.data(), nullptr);
+        if (rc) return rc;
+        for (int64_t i = 0; i < nh; i++) {
+            kgma_hit &h = ctx->hits[(size_t)i];
+            const int64_t L = ctx->contig_len[(size_t)h.contig];
+            ctx->aligns.push_back(kgma_alignment{h.contig, 0, h.lo, h.hi, first[(size_t)i], last[(size_t)i]});
+            const int64_t l0 = h.lo;
+            h.lo = std::max<int64_t>(1, l0 + first[(size_t)i] - 1);
+            h.hi = std::min<int64_t>(l0 + last[(size_t)i] - 1, L);
+        }
+        ctx->n_align_device = nh;
+        return KGMA_OK;
+    }
+    // cluster engine: speculate every dip's candidate range, one device batch per KFV
+    AlignedScan A{ctx, g, consensus, consensus_len, gap_open_score, gap_extend_score, {}, false};
+    {
+        std::vector<std::vector<AlignKey>> jobs((size_t)ctx->m);
+        for (const kgma_dip &d : ctx->dips) {
+            if (d.exit_pos == 0) continue;                            // open at the record end: never a hit
+            const int j = d.kfv - 1;
+            const int64_t L = ctx->contig_len[(size_t)d.contig];
+            const int64_t CMI = d.argmin - 1;                         // OmnGenomeMiner.jl:117
+            const int64_t lo = std::max<int64_t>(CMI - buff, 1), hi = std::min<int64_t>(CMI + ctx->kfv[(size_t)j].W - 1 + buff, L);
+            if (hi < lo || hi - lo + 1 > KGMA_ALIGN_MAX_SEGMENT) continue;   // (the replay falls back to the host for it)
+            jobs[(size_t)j].push_back(AlignKey{d.contig, d.kfv, lo, hi});
+        }
+        for (int j = 0; j < ctx->m; j++) {
+            std::vector<AlignKey> &v = jobs[(size_t)j];
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end(), [](const AlignKey &a, const AlignKey &b) { return !(a < b) && !(b < a); }), v.end());
+            const int64_t n = (int64_t)v.size();
+            if (n == 0) continue;
+            std::vector<int32_t> hc((size_t)n);
+            std::vector<int64_t> lo((size_t)n), hi((size_t)n), first((size_t)n), last((size_t)n);
+            for (int64_t i = 0; i < n; i++) { hc[(size_t)i] = v[(size_t)i].contig; lo[(size_t)i] = v[(size_t)i].lo; hi[(size_t)i] = v[(size_t)i].hi; }
+            rc = kgma_align_hits_device(ctx, g, consensus[j], consensus_len[j], gap_open_score, gap_extend_score, n, hc.data(), lo.data(),
+                                        hi.data(), first.data(), last.data(), nullptr);
+            if (rc) return rc;
+            for (int64_t i = 0; i < n; i++) A.table[v[(size_t)i]] = std::make_pair(first[(size_t)i], last[(size_t)i]);
+        }
+    }
+    rc = replay_hits(ctx, g, mode, buff, genome_pos0, flags, aligned_cb, &A);
+    if (rc) return rc;
+    if (A.failed) return fail(ctx, KGMA_E_HIP, "host fallback alignment failed");
+    return KGMA_OK;
+}
+
+int kgma_get_alignments(kgma_ctx *ctx, kgma_alignment *out, int64_t cap, int64_t *n, int64_t *n_device, int64_t *n_host)
+{
+    if (!ctx || !n) return KGMA_E_ARG;
+    *n = (int64_t)ctx->aligns.size();
+    if (n_device) *n_device = ctx->n_align_device;
+    if (n_host) *n_host = ctx->n_align_host;
+    if (!out) return KGMA_OK;
+    if (cap < *n) return fail(ctx, KGMA_E_ARG, "kgma_get_alignments: capacity %lld < %lld", (long long)cap, (long long)*n);
+    if (*n) memcpy(out, ctx->aligns.data(), (size_t)*n * sizeof(kgma_alignment));
     return KGMA_OK;
 }
 

@@ -31,6 +31,7 @@ EXPORTS = [
     "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_header", "kgma_scan_kernel_name",
     "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips", "kgma_align_hits_device", "kgma_repack_scan_hits",
     "kgma_kmer_count_batch", "kgma_kmer_dist_batch", "kgma_step_begin", "kgma_step_end", "kgma_set_reserved_cus",
+    "kgma_scan_aligned", "kgma_get_alignments",
 ]
 
 
@@ -44,6 +45,11 @@ class KgmaDip(C.Structure):
     _fields_ = [("contig", C.c_int32), ("kfv", C.c_int32), ("start", C.c_int64), ("end", C.c_int64),
                 ("argmin", C.c_int64), ("D_min", C.c_int64), ("exit_pos", C.c_int64), ("D_exit", C.c_int64),
                 ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class KgmaAlignment(C.Structure):
+    _fields_ = [("contig", C.c_int32), ("kfv", C.c_int32), ("lo", C.c_int64), ("hi", C.c_int64),
+                ("first", C.c_int64), ("last", C.c_int64)]
 
 
 class KgmaStats(C.Structure):
@@ -136,6 +142,8 @@ def load():
     L.kgma_step_end.argtypes = [vp, P(KgmaHit), i64, P(i64)]
     L.kgma_kmer_count_batch.argtypes = [vp, i32, C.c_char_p, P(i64), i64, P(dbl)]
     L.kgma_kmer_dist_batch.argtypes = [vp, i32, P(dbl), C.c_char_p, P(i64), i64, P(dbl)]
+    L.kgma_scan_aligned.argtypes = [vp, vp, i32, i64, i64, C.c_uint32, P(C.c_char_p), P(i64), i32, i32]
+    L.kgma_get_alignments.argtypes = [vp, P(KgmaAlignment), i64, P(i64), P(i64), P(i64)]
     L.kgma_stream.argtypes = [vp]
     L.kgma_stream.restype = vp
     L.kgma_scan_kernel_name.argtypes = [vp]
@@ -293,6 +301,25 @@ class Context:
                 plo[0], phi[0] = int(nlo), int(nhi)
             cb = ALIGN_FN(tramp)
         self._check(load().kgma_scan(self._h, genome._h, mode, buff, genome_pos, flags, cb, None))
+
+    def scan_aligned(self, genome: Genome, mode: int, buff: int, genome_pos: int, flags: int, consensus: Sequence[bytes],
+                     gap_open: int, gap_extend: int) -> None:
+        """kgma_scan_aligned: the scan with the hits re-aligned on the device in batches (cluster engine: every dip's
+        candidate range is aligned speculatively and looked up by the hit state machine)."""
+        cons = [bytes(c) for c in consensus]
+        arr = (C.c_char_p * max(len(cons), 1))(*cons)
+        lens = np.asarray([len(c) for c in cons], dtype=np.int64)
+        self._check(load().kgma_scan_aligned(self._h, genome._h, mode, buff, genome_pos, flags, arr, _np_ptr(lens, C.c_int64),
+                                             int(gap_open), int(gap_extend)))
+
+    def alignments(self):
+        """(list of dict(contig, kfv, lo, hi, first, last) consumed by the last scan_aligned, n on the device, n on the host)."""
+        n, nd, nh = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._check(load().kgma_get_alignments(self._h, None, 0, C.byref(n), C.byref(nd), C.byref(nh)))
+        arr = (KgmaAlignment * max(n.value, 1))()
+        self._check(load().kgma_get_alignments(self._h, arr, n.value, C.byref(n), C.byref(nd), C.byref(nh)))
+        return ([dict(contig=x.contig, kfv=x.kfv, lo=x.lo, hi=x.hi, first=x.first, last=x.last) for x in arr[:n.value]],
+                int(nd.value), int(nh.value))
 
     def scan_device(self, genome: Genome, mode: int, flags: int = 0) -> None:
         self._check(load().kgma_scan_device(self._h, genome._h, mode, flags))

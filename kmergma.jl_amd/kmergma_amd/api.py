@@ -105,8 +105,10 @@ def ac_gma_testing(*, genome_path, refVec, consensus_refseq: bytes = b"", k: int
                    do_return_align: bool = False, get_hit_loci: bool = False,
                    hit_loci_vec: Optional[list] = None, resultVec: Optional[list] = None,
                    n_refs: Optional[int] = None, aligner: Optional[Callable] = None,
-                   with_genome_pos: bool = True, ctx: Optional["_lib.Context"] = None) -> None:
-    """`ac_gma_testing!` (src/GenomeMiner.jl:4-109): mutates resultVec / hit_loci_vec / dist_vec."""
+                   with_genome_pos: bool = True, ctx: Optional["_lib.Context"] = None, float_chain: bool = True) -> None:
+    """`ac_gma_testing!` (src/GenomeMiner.jl:4-109): mutates resultVec / hit_loci_vec / dist_vec.
+    float_chain (default on): KGMA_F_CHAIN_REPLAY -- every decision that hangs on the rounding of the reference's
+    running Float64 distance is taken from a host replay of that value (kgma.h)."""
     _check_derived(k, mask, ScaleFactor)
     resultVec = resultVec if resultVec is not None else []
     ctx = ctx or default_context()
@@ -122,18 +124,16 @@ def ac_gma_testing(*, genome_path, refVec, consensus_refseq: bytes = b"", k: int
                 from .align import align_range as aligner  # noqa: N813
             cb = _make_align_cb(aligner, view, lambda kfv: consensus_refseq, lambda kfv: int(windowsize),
                                 gap_open_score, gap_extend_score, result_align_vec if do_return_align else None)
-        ctx.scan(genome, _lib.MODE_SINGLE, int(buff), 0, _lib.F_RETURN_DISTS if do_return_dists else 0, cb)
-        hits = ctx.hits()
-        if device_align and hits:
+        flags = (_lib.F_RETURN_DISTS if do_return_dists else 0) | (_lib.F_CHAIN_REPLAY if float_chain else 0)
+        if device_align:
             # the single engine's alignment does not feed back into the hit state machine
             # (GenomeMiner.jl:96-99): all hits of the scan are re-aligned in one device batch
-            first, last, _ = ctx.align_hits_device(genome, consensus_refseq[:int(windowsize)], gap_open_score, gap_extend_score,
-                                                   [h["contig"] for h in hits], [h["lo"] for h in hits], [h["hi"] for h in hits])
-            for h, a_first, a_last in zip(hits, first, last):
-                lo, hi, L = h["lo"], h["hi"], genome.contig_len(h["contig"])
-                if do_return_align and result_align_vec is not None:
-                    result_align_vec.append((h["contig"], 0, lo, hi, int(a_first), int(a_last)))
-                h["lo"], h["hi"] = max(1, lo + int(a_first) - 1), min(lo + int(a_last) - 1, L)
+            ctx.scan_aligned(genome, _lib.MODE_SINGLE, int(buff), 0, flags, [consensus_refseq], gap_open_score, gap_extend_score)
+            if do_return_align and result_align_vec is not None:
+                result_align_vec.extend((a["contig"], 0, a["lo"], a["hi"], a["first"], a["last"]) for a in ctx.alignments()[0])
+        else:
+            ctx.scan(genome, _lib.MODE_SINGLE, int(buff), 0, flags, cb)
+        hits = ctx.hits()
         for h in hits:
             c = h["contig"]
             hdr = headers.single_header(view.identifier(c), h["dist"], h["lo"], h["hi"], h["genome_pos"], with_genome_pos)
@@ -164,8 +164,9 @@ def Omn_KmerGMA(*, genome_path, refVecs: Sequence, windowsizes: Sequence[int], c
                 gap_extend_score: int = -1, genome_pos: int = 0, get_hit_loci: bool = False,
                 hit_loci_vec: Optional[list] = None, get_aligns: bool = False, do_return_dists: bool = False,
                 dist_vec_vec: Optional[List[list]] = None, n_refs: Optional[Sequence[int]] = None,
-                aligner: Optional[Callable] = None, ctx=None) -> None:
-    """`Omn_KmerGMA!` (src/OmnGenomeMiner.jl:7-162)."""
+                aligner: Optional[Callable] = None, ctx=None, float_chain: bool = True) -> None:
+    """`Omn_KmerGMA!` (src/OmnGenomeMiner.jl:7-162).  Without a caller-supplied `aligner` the hits are re-aligned on the
+    device: every dip's candidate range in one batch per KFV, looked up by the hit state machine (kgma_scan_aligned)."""
     _check_derived(k, mask, ScaleFactor)
     m = len(windowsizes)
     ctx = ctx or default_context()
@@ -175,13 +176,22 @@ def Omn_KmerGMA(*, genome_path, refVecs: Sequence, windowsizes: Sequence[int], c
     genome = view.genome
     try:
         cb = None
-        if align_hits:
-            if aligner is None:
-                from .align import align_range as aligner  # noqa: N813
+        flags = (_lib.F_RETURN_DISTS if do_return_dists else 0) | (_lib.F_CHAIN_REPLAY if float_chain else 0)
+        device_align = (align_hits and aligner is None and len(consensus_seqs) >= m
+                        and max(int(w) for w in windowsizes) + 2 * int(buff) <= 8191)
+        if device_align:
             # the cluster engine aligns against the whole consensus_seqs[ind] (OmnGenomeMiner.jl:131)
-            cb = _make_align_cb(aligner, view, lambda kfv: consensus_seqs[kfv - 1], lambda kfv: None,
-                                gap_open_score, gap_extend_score, align_vec if get_aligns else None)
-        ctx.scan(genome, _lib.MODE_OMN, int(buff), int(genome_pos), _lib.F_RETURN_DISTS if do_return_dists else 0, cb)
+            ctx.scan_aligned(genome, _lib.MODE_OMN, int(buff), int(genome_pos), flags, list(consensus_seqs)[:m],
+                             gap_open_score, gap_extend_score)
+            if get_aligns and align_vec is not None:
+                align_vec.extend((a["contig"], a["kfv"], a["lo"], a["hi"], a["first"], a["last"]) for a in ctx.alignments()[0])
+        else:
+            if align_hits:
+                if aligner is None:
+                    from .align import align_range as aligner  # noqa: N813
+                cb = _make_align_cb(aligner, view, lambda kfv: consensus_seqs[kfv - 1], lambda kfv: None,
+                                    gap_open_score, gap_extend_score, align_vec if get_aligns else None)
+            ctx.scan(genome, _lib.MODE_OMN, int(buff), int(genome_pos), flags, cb)
         for h in ctx.hits():
             c = h["contig"]
             hdr = headers.omn_header(view.identifier(c), h["dist"], h["kfv"], h["lo"], h["hi"], h["genome_pos"])

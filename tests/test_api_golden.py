@@ -132,3 +132,34 @@ def test_write_results_appends(tmp_path, paths, alp_ref):
     api.write_results(res, p)
     back = fasta.read_fasta(p)
     assert len(back) == 2 * len(res) and back[0] == res[0]
+
+
+def test_cluster_mode_alignment_on_device_zero_host_calls(golden, paths):
+    """findGenes_cluster_mode's goldens (test-KmerGMA.jl:265-271) with every alignment done on the device: all dips'
+    candidate ranges are aligned speculatively in one batch per KFV and looked up by the hit state machine; no
+    per-hit host alignment happens.  The host-callback path (same restated aligner, -200/-1) must give the same records."""
+    from kmergma_amd import align
+    g = golden["scan"]["findGenes_cluster_mode"]
+    ctx = api.default_context()
+    out = api.findGenes_cluster_mode(genome_path=paths["mini"], ref_path=paths["tf"], KmerDistThrs=g["KmerDistThrs"],
+                                     buffer=g["buffer"], verbose=False, do_return_align=True)
+    assert [r.description for r in out[0]] == g["headers"]
+    al, n_dev, n_host = ctx.alignments()
+    assert n_host == 0 and n_dev == len(al) >= len(out[0])
+    assert [tuple(x) for x in out[1]] == [(a["contig"], a["kfv"], a["lo"], a["hi"], a["first"], a["last"]) for a in al]
+    host = api.findGenes_cluster_mode(genome_path=paths["mini"], ref_path=paths["tf"], KmerDistThrs=g["KmerDistThrs"],
+                                      buffer=g["buffer"], verbose=False, do_return_align=True, aligner=align.align_range)
+    assert [r.description for r in host[0]] == [r.description for r in out[0]]
+    assert [r.sequence for r in host[0]] == [r.sequence for r in out[0]]
+    assert [tuple(x) for x in host[1]] == [tuple(x) for x in out[1]]
+    # a bigger case: the 4-record fixture, cluster engine with the -200/-1 gap model, device vs host callback
+    for buffer in (50, 100, 200):
+        a = api.findGenes_cluster_mode(genome_path=paths["genome"], ref_path=paths["tf"], KmerDistThrs=[37, 33, 38, 34, 28, 30],
+                                       buffer=buffer, verbose=False, do_return_align=True, do_return_hit_loci=True)
+        _, nd, nh = ctx.alignments()
+        b = api.findGenes_cluster_mode(genome_path=paths["genome"], ref_path=paths["tf"], KmerDistThrs=[37, 33, 38, 34, 28, 30],
+                                       buffer=buffer, verbose=False, do_return_align=True, do_return_hit_loci=True,
+                                       aligner=align.align_range)
+        assert nh == 0 and nd > 0
+        assert [r.description for r in a[0]] == [r.description for r in b[0]] and len(a[0]) > 5
+        assert a[1] == b[1] and [tuple(x) for x in a[2]] == [tuple(x) for x in b[2]]
