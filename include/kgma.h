@@ -256,6 +256,13 @@ int kgma_host_semiglobal_cigar(const uint8_t *a, int64_t m, const uint8_t *b, in
  * [m][n_records] (D of each record's first window, -1 for skipped records); dips must be sorted by
  * (record, KFV, start).  Hits then come from kgma_get_hits as usual. */
 int kgma_resolve_ties_local(kgma_ctx *ctx, const kgma_genome *genome);
+/* Residue source for kgma_replay_dips: rank 0 has no genome for the dips other GPUs found, so a dip whose minimum
+ * EQUALS the stale running minimum left by an earlier dip (GenomeMiner.jl:93-103) -- a tie only the hit state machine
+ * can see -- is decided by asking the caller for the residues of the stretch in between: fn must write `len` residue
+ * characters of record `contig` starting at 1-based `pos` and return 0 (anything else: the tie stays KGMA_HIT_TIE).
+ * NULL (default): such ties stay flagged.  The chain replay (KGMA_F_CHAIN_REPLAY) is not run by kgma_replay_dips. */
+typedef int (*kgma_fetch_fn)(void *user, int32_t contig, int64_t pos, int64_t len, uint8_t *out);
+int kgma_set_residue_source(kgma_ctx *ctx, kgma_fetch_fn fn, void *user);
 int kgma_get_dip_last_min(kgma_ctx *ctx, int64_t *out, int64_t cap, int64_t *n);   /* last window attaining each dip's minimum */
 int kgma_replay_dips(kgma_ctx *ctx, int32_t mode, int64_t buff, int64_t genome_pos0, uint32_t flags, int64_t n_records,
                      const int64_t *record_len, const int64_t *first_D, const kgma_dip *dips, const int64_t *dip_last_min,

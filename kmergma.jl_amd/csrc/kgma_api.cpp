@@ -173,6 +173,7 @@ struct kgma_ctx {
     const uint8_t *aux_host = nullptr;       // aux region of the last scan (pinned staging)
     unsigned int aux_used = 0;
     std::vector<kgma_hit> hits;
+    kgma_fetch_fn fetch = nullptr; void *fetch_user = nullptr;   // residue source for kgma_replay_dips (dips found on other GPUs)
     std::vector<kgma_alignment> aligns;      // alignments the hit state machine consumed (kgma_scan_aligned), in order
     int64_t n_align_device = 0, n_align_host = 0;
     std::vector<int64_t> contig_len;
@@ -1778,7 +1779,7 @@ struct TieResolver {
                   int64_t Dmin, bool include_start, const uint8_t *residues = nullptr)
     {
         Result r{false, true, false, cand_lo};
-        if (!g) return r;                                   // no residues at hand (dips came from another GPU)
+        if (!g && !ctx->fetch) return r;                    // no residues at hand (dips came from another GPU, no residue source set)
         const KfvInfo &f = ctx->kfv[(size_t)kfv];
         const int k = ctx->k;
         const int64_t NB = (int64_t)1 << (2 * k);
@@ -1786,13 +1787,17 @@ struct TieResolver {
         const int64_t W = f.W, N = f.N;
         if (p_from < 1 || cand_hi < p_from || cand_hi - p_from > MAX_SPAN) return r;
         const int64_t nbases = (cand_hi - p_from) + W;
-        if (p_from - 1 + nbases > g->cd[(size_t)contig].len) return r;
+        if (p_from - 1 + nbases > (g ? g->cd[(size_t)contig].len : ctx->contig_len[(size_t)contig])) return r;
         const uint8_t *seq = residues;
         if (!seq) {
             seqbuf.resize((size_t)nbases);
-            (void)hipSetDevice(ctx->device);
-            if (hipMemcpy(seqbuf.data(), g->d_ascii + g->cd[(size_t)contig].ascii_off + (p_from - 1), (size_t)nbases,
-                          hipMemcpyDeviceToHost) != hipSuccess) return r;
+            if (g) {
+                (void)hipSetDevice(ctx->device);
+                if (hipMemcpy(seqbuf.data(), g->d_ascii + g->cd[(size_t)contig].ascii_off + (p_from - 1), (size_t)nbases,
+                              hipMemcpyDeviceToHost) != hipSuccess) return r;
+            } else if (ctx->fetch(ctx->fetch_user, (int32_t)contig, p_from, nbases, seqbuf.data()) != 0) {
+                return r;                                   // the caller's residue source could not deliver
+            }
             seq = seqbuf.data();
         }
         if (cnt.empty()) cnt.assign((size_t)NB, 0);
@@ -2496,6 +2501,13 @@ int kgma_get_alignments(kgma_ctx *ctx, kgma_alignment *out, int64_t cap, int64_t
     if (!out) return KGMA_OK;
     if (cap < *n) return fail(ctx, KGMA_E_ARG, "kgma_get_alignments: capacity %lld < %lld", (long long)cap, (long long)*n);
     if (*n) memcpy(out, ctx->aligns.data(), (size_t)*n * sizeof(kgma_alignment));
+    return KGMA_OK;
+}
+
+int kgma_set_residue_source(kgma_ctx *ctx, kgma_fetch_fn fn, void *user)
+{
+    if (!ctx) return KGMA_E_ARG;
+    ctx->fetch = fn; ctx->fetch_user = user;
     return KGMA_OK;
 }
 

@@ -31,7 +31,7 @@ EXPORTS = [
     "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_header", "kgma_scan_kernel_name",
     "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips", "kgma_align_hits_device", "kgma_repack_scan_hits",
     "kgma_kmer_count_batch", "kgma_kmer_dist_batch", "kgma_step_begin", "kgma_step_end", "kgma_set_reserved_cus",
-    "kgma_scan_aligned", "kgma_get_alignments",
+    "kgma_scan_aligned", "kgma_get_alignments", "kgma_set_residue_source",
 ]
 
 
@@ -68,6 +68,7 @@ DIP_DTYPE = np.dtype([("contig", "<i4"), ("kfv", "<i4"), ("start", "<i8"), ("end
 
 ALIGN_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                        C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+FETCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_uint8))
 
 
 class KgmaError(RuntimeError):
@@ -144,6 +145,7 @@ def load():
     L.kgma_kmer_dist_batch.argtypes = [vp, i32, P(dbl), C.c_char_p, P(i64), i64, P(dbl)]
     L.kgma_scan_aligned.argtypes = [vp, vp, i32, i64, i64, C.c_uint32, P(C.c_char_p), P(i64), i32, i32]
     L.kgma_get_alignments.argtypes = [vp, P(KgmaAlignment), i64, P(i64), P(i64), P(i64)]
+    L.kgma_set_residue_source.argtypes = [vp, FETCH_FN, vp]
     L.kgma_stream.argtypes = [vp]
     L.kgma_stream.restype = vp
     L.kgma_scan_kernel_name.argtypes = [vp]
@@ -377,6 +379,26 @@ class Context:
         out = np.zeros(max(n.value, 1), dtype=np.int64)
         self._check(load().kgma_get_dip_last_min(self._h, _np_ptr(out, C.c_int64), out.size, C.byref(n)))
         return out[:n.value]
+
+    def set_residue_source(self, fetch: Optional[Callable]) -> None:
+        """kgma_set_residue_source: `fetch(record, pos, length) -> bytes` serves residues to kgma_replay_dips (ties between a
+        dip found on another GPU and the stale running minimum); None removes it."""
+        if fetch is None:
+            self._fetch_cb = None
+            self._check(load().kgma_set_residue_source(self._h, C.cast(None, FETCH_FN), None))
+            return
+
+        def tramp(_u, contig, pos, length, out):
+            try:
+                data = fetch(int(contig), int(pos), int(length))
+                if len(data) != length:
+                    return 1
+                C.memmove(out, bytes(data), length)
+                return 0
+            except Exception:
+                return 1
+        self._fetch_cb = FETCH_FN(tramp)                 # kept alive with the context
+        self._check(load().kgma_set_residue_source(self._h, self._fetch_cb, None))
 
     def resolve_ties_local(self, genome: "Genome") -> None:
         self._check(load().kgma_resolve_ties_local(self._h, genome._h))

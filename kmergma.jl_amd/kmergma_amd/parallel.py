@@ -278,16 +278,33 @@ def slice_bases(u: int, v: int, L: int, mode_single: bool, windowsizes: Sequence
     return u - 1, min(u - 1 + n, L)
 
 
-def local_scan(ctx, records: Sequence[bytes], my_slices: Sequence[Tuple[int, int, int]], mode: int, flags: int = 0) -> dict:
+class RecordSource:
+    """The records of a sharded scan as a rank sees them: every rank knows all record LENGTHS, but only reads the residues
+    of its own slices through `fetch(record, begin, end)` (0-based half-open).  A plain list of bytes is wrapped as is."""
+
+    def __init__(self, lengths: Sequence[int], fetch):
+        self.lengths = [int(x) for x in lengths]
+        self.fetch = fetch
+
+    @staticmethod
+    def of(records) -> "RecordSource":
+        if isinstance(records, RecordSource):
+            return records
+        recs = list(records)
+        return RecordSource([len(r) for r in recs], lambda c, b, e: recs[c][b:e])
+
+
+def local_scan(ctx, records, my_slices: Sequence[Tuple[int, int, int]], mode: int, flags: int = 0) -> dict:
     """One rank's part: scan the slices, decide local ties, return dips in whole-record coordinates."""
     from . import _lib
+    src = RecordSource.of(records)
     mode_single = mode == _lib.MODE_SINGLE
     ws = [ctx.ws[0]] if mode_single else list(ctx.ws)
     m = 1 if mode_single else len(ctx.ws)
     pieces = []
     for (c, u, v) in my_slices:
-        b, e = slice_bases(u, v, len(records[c]), mode_single, ws, ctx.k)
-        pieces.append(records[c][b:e])
+        b, e = slice_bases(u, v, src.lengths[c], mode_single, ws, ctx.k)
+        pieces.append(src.fetch(c, b, e))
     payload = dict(slices=list(my_slices), dips=np.zeros(0, dtype=_lib.DIP_DTYPE), last_min=np.zeros(0, dtype=np.int64), first_D={})
     if not pieces:
         return payload
@@ -317,6 +334,69 @@ def local_scan(ctx, records: Sequence[bytes], my_slices: Sequence[Tuple[int, int
         if u == 1:
             payload["first_D"][int(c)] = [int(fw[j][i]) for j in range(m)]
     return payload
+
+
+# ---- the ranks' dips travel as ONE fixed-layout int64 tensor per rank (RCCL / gloo all_gather), like the hit records ----
+_PAYLOAD_HEADER = 8       # n_dips, n_first, status, error class, error record, error position, rank, reserved
+
+
+def encode_payload(payload: dict, m: int) -> np.ndarray:
+    """[header | n_dips x 9 (the 64-byte kgma_dip as 8 words + the last window attaining the minimum) | n_first x (1 + m)]."""
+    from . import _lib
+    dips = np.ascontiguousarray(payload["dips"], dtype=_lib.DIP_DTYPE)
+    nd = int(dips.shape[0])
+    first = sorted(payload["first_D"].items())
+    out = np.zeros(_PAYLOAD_HEADER + nd * 9 + len(first) * (1 + m), dtype=np.int64)
+    out[0], out[1] = nd, len(first)
+    err = payload.get("error")
+    if err:
+        out[2:7] = [int(err["status"]), int(err["kind"]), int(err["record"]), int(err["position"]), int(err["rank"])]
+    if nd:
+        body = out[_PAYLOAD_HEADER:_PAYLOAD_HEADER + nd * 9].reshape(nd, 9)
+        body[:, :8] = dips.view(np.int64).reshape(nd, 8)
+        body[:, 8] = np.asarray(payload["last_min"], dtype=np.int64)
+    p = _PAYLOAD_HEADER + nd * 9
+    for c, vals in first:
+        out[p] = c
+        out[p + 1:p + 1 + m] = vals
+        p += 1 + m
+    return out
+
+
+def decode_payload(buf: np.ndarray, m: int) -> dict:
+    from . import _lib
+    nd, nf = int(buf[0]), int(buf[1])
+    body = buf[_PAYLOAD_HEADER:_PAYLOAD_HEADER + nd * 9].reshape(nd, 9)
+    dips = np.ascontiguousarray(body[:, :8]).reshape(-1).view(_lib.DIP_DTYPE).copy() if nd else np.zeros(0, dtype=_lib.DIP_DTYPE)
+    last_min = body[:, 8].copy() if nd else np.zeros(0, dtype=np.int64)
+    first_D = {}
+    p = _PAYLOAD_HEADER + nd * 9
+    for _ in range(nf):
+        first_D[int(buf[p])] = [int(x) for x in buf[p + 1:p + 1 + m]]
+        p += 1 + m
+    err = None
+    if int(buf[2]) != 0:
+        err = dict(status=int(buf[2]), kind=int(buf[3]), record=int(buf[4]), position=int(buf[5]), rank=int(buf[6]))
+    return dict(dips=dips, last_min=last_min, first_D=first_D, error=err)
+
+
+def gather_payloads(payload: dict, m: int, device=None, group=None) -> List[dict]:
+    """Every rank's payload on every rank: an all_gather of the sizes, then ONE padded all_gather of the int64 blocks
+    (device tensors with RCCL, host tensors with gloo)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = device if device is not None else torch.device("cpu")
+    enc = encode_payload(payload, m)
+    size = torch.tensor([enc.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size, group=group)
+    mx = max(int(x) for x in sizes)
+    buf = torch.zeros(mx, dtype=torch.int64, device=dev)
+    buf[:enc.size] = torch.from_numpy(enc).to(dev)
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    return [decode_payload(bufs[r][:int(sizes[r])].cpu().numpy(), m) for r in range(world)]
 
 
 def merge_payloads(payloads: Sequence[dict], n_records: int, m: int):
@@ -362,38 +442,67 @@ def merge_payloads(payloads: Sequence[dict], n_records: int, m: int):
     return merged, np.array(out_last, dtype=np.int64), first_D
 
 
-def scan_sharded(ctx, records: Sequence[bytes], mode: int, buff: int = 50, genome_pos: int = 0, flags: int = 0,
-                 align=None, group=None, min_windows: int = 4096):
-    """findGenes-style scan of `records` sharded over all ranks INSIDE records.  Every rank passes the
-    same records (or at least the residues of its slices); rank 0 returns the hits (list of dicts in
-    the reference's order), the others []."""
+_ERR_KINDS = {"KgmaError": 0, "BadBaseError": 1, "RecordBoundsError": 2}
+
+
+def _error_entry(e, plan_rank, src, mode_single, ws, k, rank) -> dict:
+    """A rank-local library error in genome coordinates: the slice-local record index / position of the message are
+    mapped back through the rank's slices."""
+    import re
+    kind = _ERR_KINDS.get(type(e).__name__, 0)
+    rec, pos = (plan_rank[0][0] if plan_rank else 0), 0
+    mt = re.search(r"record (\d+)(?: position (\d+))?", e.message or "")
+    if mt and int(mt.group(1)) < len(plan_rank):
+        c, u, v = plan_rank[int(mt.group(1))]
+        b, _ = slice_bases(u, v, src.lengths[c], mode_single, ws, k)
+        rec = c
+        pos = b + int(mt.group(2)) if mt.group(2) else 0
+    return dict(status=int(e.status), kind=kind, record=int(rec), position=int(pos), rank=int(rank))
+
+
+def scan_sharded(ctx, records, mode: int, buff: int = 50, genome_pos: int = 0, flags: int = 0,
+                 align=None, group=None, min_windows: int = 4096, device=None):
+    """findGenes-style scan of `records` sharded over all ranks INSIDE records.  `records`: a list of bytes (every rank
+    holds everything) or a RecordSource (every rank knows the lengths and reads only its slices).  The ranks' dips are
+    gathered as one int64 tensor per rank (`device` = the rank's GPU for RCCL, None for gloo); rank 0 joins them, runs the
+    hit state machine over whole records and returns the hits (list of dicts in the reference's order), the others [].
+    Rank 0 reads the few residues it needs to decide ties between a dip and the stale running minimum through the same
+    source (kgma_set_residue_source)."""
     import torch.distributed as dist
     from . import _lib
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    src = RecordSource.of(records)
     mode_single = mode == _lib.MODE_SINGLE
     ws = [ctx.ws[0]] if mode_single else list(ctx.ws)
-    lengths = [len(r) for r in records]
+    m = 1 if mode_single else len(ctx.ws)
+    lengths = src.lengths
     plan = plan_slices(lengths, world, mode_single, ws, ctx.k, min_windows)
     # a rank-local failure (a residue outside A/C/G/T/N in this rank's slices, a record shorter than k-1, a
-    # record-buffer overflow) must not leave the other ranks blocked in the collective: it travels with the
-    # payload, the collective completes, and EVERY rank raises the first error in record order
+    # record-buffer overflow) must not leave the other ranks blocked in the collective: it travels in the header of the
+    # rank's block, the collective completes, and EVERY rank raises the first error in record order
     try:
-        payload = local_scan(ctx, records, plan[rank], mode, flags)
+        payload = local_scan(ctx, src, plan[rank], mode, flags)
         payload["error"] = None
     except _lib.KgmaError as e:
-        first_rec = min((c for (c, _, _) in plan[rank]), default=0)
         payload = dict(slices=list(plan[rank]), dips=np.zeros(0, dtype=_lib.DIP_DTYPE), last_min=np.zeros(0, dtype=np.int64),
-                       first_D={}, error=(type(e).__name__, int(e.status), e.message, int(first_rec), int(rank)))
-    gathered = [None] * world
-    dist.all_gather_object(gathered, payload, group=group)
-    errors = sorted((p["error"] for p in gathered if p.get("error")), key=lambda t: (t[3], t[4]))
+                       first_D={}, error=_error_entry(e, plan[rank], src, mode_single, ws, ctx.k, rank))
+    gathered = gather_payloads(payload, m, device=device, group=group)
+    errors = sorted((p["error"] for p in gathered if p.get("error")), key=lambda t: (t["record"], t["position"], t["rank"]))
     if errors:
-        name, status, message, _rec, erank = errors[0]
-        cls = {"BadBaseError": _lib.BadBaseError, "RecordBoundsError": _lib.RecordBoundsError}.get(name, _lib.KgmaError)
-        raise cls(status, f"(rank {erank}, slice-local coordinates) {message}")
+        e = errors[0]
+        if e["kind"] == 1:
+            raise _lib.BadBaseError(e["status"], f"record {e['record']} position {e['position']}: residue is not one of A/C/G/T/N "
+                                                 f"(KeyError, Consts.jl:22-28) [found by rank {e['rank']}]")
+        if e["kind"] == 2:
+            raise _lib.RecordBoundsError(e["status"], f"record {e['record']} has fewer than k-1 residues (BoundsError, "
+                                                      f"OmnGenomeMiner.jl:84-86) [found by rank {e['rank']}]")
+        raise _lib.KgmaError(e["status"], f"rank {e['rank']} failed while scanning its slices of record {e['record']}")
     if rank != 0:
         return []
-    m = 1 if mode_single else len(ctx.ws)
-    dips, last_min, first_D = merge_payloads(gathered, len(records), m)
-    ctx.replay_dips(mode, buff, genome_pos, flags, lengths, first_D, dips, last_min, align)
+    dips, last_min, first_D = merge_payloads(gathered, len(lengths), m)
+    ctx.set_residue_source(lambda c, pos, n: src.fetch(c, pos - 1, pos - 1 + n))
+    try:
+        ctx.replay_dips(mode, buff, genome_pos, flags, lengths, first_D, dips, last_min, align)
+    finally:
+        ctx.set_residue_source(None)
     return ctx.hits()

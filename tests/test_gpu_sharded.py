@@ -1,6 +1,7 @@
-"""Two processes (gloo rendezvous, both on cuda:0 -- the GPU box has one card) run
-parallel.scan_sharded on the same records: slices of the records per rank, dips gathered with one
-all_gather_object, hit state machine on rank 0.  The result must equal the unsharded scan."""
+"""Two / three processes (gloo rendezvous, all on cuda:0 -- the GPU box has one card) run
+parallel.scan_sharded on the same records: slices of the records per rank (every rank reads ONLY the residues
+of its slices), dips gathered as one int64 tensor per rank, hit state machine on rank 0.  The result must equal
+the unsharded scan; a rank-local error must surface on every rank."""
 import os
 import socket
 import sys
@@ -26,32 +27,67 @@ def _worker(rank, world, port, q):
     refs = workloads.fixture_refs(data, 6)
     rng = np.random.default_rng(5)                      # same records on every rank
     contigs, _ = make_genome(rng, [400000, 100, 90000], refs["genes"], n_plants_per_mb=150)
+    # a gene copied twice, 150 bases apart: the second dip is suppressed (inside goal_ind) and has EXACTLY the minimum of
+    # the first, then a third copy further on ties with the stale running minimum -- across a slice boundary for 3 ranks
+    gene = refs["genes"][5]
+    a = bytearray(contigs[0])
+    for pos in (130000, 130150, 133700, 266000, 266150, 268000):
+        a[pos:pos + len(gene)] = gene
+    contigs[0] = bytes(a)
+    touched = []
+
+    def fetch(c, b, e):
+        touched.append((c, b, e))
+        return contigs[c][b:e]
+
+    src = parallel.RecordSource([len(c) for c in contigs], fetch)
     ctx = _lib.Context(0)
     ctx.set_refs(6, [refs["RV"]], [refs["ws"]], [30.0], [refs["N"]])
-    hits = parallel.scan_sharded(ctx, contigs, _lib.MODE_SINGLE, buff=50, genome_pos=0, flags=_lib.F_NO_TIE_RESOLVE,
-                                 min_windows=2048)
+    ok = True
+    for flags in (_lib.F_NO_TIE_RESOLVE, 0):
+        del touched[:]
+        hits = parallel.scan_sharded(ctx, src, _lib.MODE_SINGLE, buff=50, genome_pos=0, flags=flags, min_windows=2048)
+        plan = parallel.plan_slices(src.lengths, world, True, [refs["ws"]], 6, 2048)
+        mine = {(c,) + parallel.slice_bases(u, v, src.lengths[c], True, [refs["ws"]], 6) for (c, u, v) in plan[rank]}
+        if rank != 0:
+            assert hits == []
+            ok = ok and set(touched) == mine                      # only this rank's slices were read
+        else:
+            g = ctx.genome_from_host(contigs)
+            ctx.scan(g, _lib.MODE_SINGLE, 50, 0, flags, None)
+            ref, ref_dips = ctx.hits(), ctx.dips()
+            g.free()
+            ok = ok and [hit_key(h) for h in hits] == [hit_key(h) for h in ref] and [h["D"] for h in hits] == [h["D"] for h in ref]
+            if flags == 0:                                           # ties with the stale minimum decided like the unsharded scan
+                ok = ok and [h["flags"] & _lib.HIT_TIE for h in hits] == [h["flags"] & _lib.HIT_TIE for h in ref]
+                ok = ok and sum(1 for d in ref_dips if d["flags"] & _lib.HIT_TIE_RESOLVED) >= 2
+            n_hits = len(hits)
+    # a residue outside A/C/G/T/N in the LAST rank's part: every rank raises the reference's KeyError, in genome coordinates
+    bad = bytearray(contigs[2]); bad[80000] = ord("R")
+    src_bad = parallel.RecordSource(src.lengths, lambda c, b, e: (bytes(bad) if c == 2 else contigs[c])[b:e])
+    try:
+        parallel.scan_sharded(ctx, src_bad, _lib.MODE_SINGLE, buff=50, min_windows=2048)
+        ok = False
+    except _lib.BadBaseError as e:
+        ok = ok and "record 2 position 80001" in str(e)
+    hits = parallel.scan_sharded(ctx, src, _lib.MODE_SINGLE, buff=50, flags=_lib.F_NO_TIE_RESOLVE, min_windows=2048)   # still usable
     if rank == 0:
-        g = ctx.genome_from_host(contigs)
-        ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_NO_TIE_RESOLVE, None)
-        ref = ctx.hits()
-        g.free()
-        q.put(([hit_key(h) for h in hits] == [hit_key(h) for h in ref] and [h["D"] for h in hits] == [h["D"] for h in ref],
-               len(hits)))
-    else:
-        assert hits == []
+        ok = ok and len(hits) == n_hits
+        q.put((bool(ok), n_hits))
     dist.barrier()
     ctx.close()
     dist.destroy_process_group()
 
 
-def test_scan_sharded_two_ranks():
+@pytest.mark.parametrize("world", [2, 3])
+def test_scan_sharded_ranks(world):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     same, n = q.get(timeout=300)
@@ -102,6 +138,14 @@ def _rccl_body(torch, dist, _lib, parallel, workloads, port, q):
     for o in outs:
         ok = ok and o.shape == direct.shape and all(np.array_equal(o[f], direct[f]) for f in direct.dtype.names)
     ok = ok and np.array_equal(g.gather(direct, 0, 0)["cmi"], direct["cmi"])
+    # the dips of a sharded scan travel the same way: one int64 device tensor per rank over RCCL
+    gg = ctx.genome_from_host([genome.fetch(0, 1, 600_000)])
+    ctx.scan_device(gg, _lib.MODE_SINGLE, 0)
+    pay = dict(slices=[(0, 1, 10)], dips=ctx.dips_array().copy(), last_min=ctx.dip_last_min().copy(), first_D={0: [int(ctx.first_window(1)[0])]}, error=None)
+    gg.free()
+    got = parallel.gather_payloads(pay, 1, device=dev)
+    ok = ok and len(got) == 1 and np.array_equal(got[0]["dips"], pay["dips"]) and np.array_equal(got[0]["last_min"], pay["last_min"])
+    ok = ok and got[0]["first_D"] == pay["first_D"]
     try:                                                # one step in flight per context; end needs a begin
         ctx.step_end()
         ok = False

@@ -189,3 +189,75 @@ def test_plan_slices_covers_every_window_once_plus_shared():
             loads = [sum(v - u for (_, u, v) in sl) for sl in plan]
             total = sum(parallel.record_windows(L, mode_single, ws, 6) for L in lens)
             assert max(loads) <= total / world + 2 * 512 + max(1, total // world // 50) + 4096
+
+
+def _worker_dips(rank, world, port, q):
+    """Four ranks exchange their dips as int64 tensors (parallel.gather_payloads) and rank 0 joins the dips that
+    straddle slice boundaries (parallel.merge_payloads).  Synthetic dips: the scan itself needs a GPU."""
+    sys.path.insert(0, os.path.join(ROOT, "kmergma.jl_amd"))
+    import torch.distributed as dist
+    from kmergma_amd import _lib, parallel as par
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lengths = [100_000, 200, 60_000]
+    plan = par.plan_slices(lengths, world, True, [289], 6, min_windows=512)
+    mine = plan[rank]
+
+    def dip(c, start, end, argmin, dmin, exit_pos, dexit, flags=0):
+        d = np.zeros(1, dtype=_lib.DIP_DTYPE)
+        d["contig"], d["kfv"], d["start"], d["end"], d["argmin"] = c, 1, start, end, argmin
+        d["D_min"], d["exit_pos"], d["D_exit"], d["flags"] = dmin, exit_pos, dexit, flags
+        return d
+
+    dips, last = [], []
+    for (c, u, v) in mine:
+        if v - u > 50:
+            dips.append(dip(c, u + 10, u + 20, u + 15, 1000 + rank, u + 21, 5000)); last.append(u + 15)   # inside the slice
+        nwin = par.record_windows(lengths[c], True, [289], 6)
+        if v < nwin:                                    # a dip that reaches the end of the slice: continues on the next rank
+            dips.append(dip(c, v - 5, v, v - 2, 700, 0, 0)); last.append(v - 2)
+        if u > 1:                                       # ... and its continuation: starts at the shared window u + 1 = v_prev
+            dips.append(dip(c, u + 1, u + 4, u + 3, 650, u + 5, 6000)); last.append(u + 3)
+    payload = dict(slices=list(mine), first_D={int(c): [123 + c] for (c, u, v) in mine if u == 1},
+                   dips=np.concatenate(dips) if dips else np.zeros(0, dtype=_lib.DIP_DTYPE),
+                   last_min=np.asarray(last, dtype=np.int64), error=None)
+    order = np.argsort(payload["dips"]["start"], kind="stable") if len(dips) else []
+    payload["dips"], payload["last_min"] = payload["dips"][order], payload["last_min"][order]
+    got = par.gather_payloads(payload, 1)
+    assert len(got) == world and all(g["error"] is None for g in got)
+    assert np.array_equal(got[rank]["dips"], payload["dips"]) and np.array_equal(got[rank]["last_min"], payload["last_min"])
+    merged, last_min, first_D = par.merge_payloads(got, len(lengths), 1)
+    # an error on ONE rank reaches every rank through the same exchange
+    bad = dict(payload, error=dict(status=4, kind=1, record=2, position=4242, rank=rank) if rank == 2 else None)
+    errs = [g["error"] for g in par.gather_payloads(bad, 1) if g["error"]]
+    assert errs == [dict(status=4, kind=1, record=2, position=4242, rank=2)]
+    if rank == 0:
+        q.put((merged, last_min, first_D, plan))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dip_exchange_world4_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_dips, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    merged, last_min, first_D, plan = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert first_D[0, 0] == 123 and first_D[0, 2] == 125 and first_D[0, 1] == -1      # record 1 is shorter than the window
+    n_cuts = sum(len(sl) for sl in plan) - len({c for sl in plan for (c, _, _) in sl})
+    assert n_cuts >= 3
+    # every cut joined one open dip with its continuation: minimum 650 from the later part, exit from the later part
+    joined = [d for d in merged if d["D_min"] == 650]
+    assert len(joined) == n_cuts
+    for d in joined:
+        assert d["exit_pos"] == d["end"] + 1 and d["D_exit"] == 6000 and d["end"] - d["start"] == 8
+    assert not any(d["exit_pos"] == 0 for d in merged)
+    keys = [(int(d["contig"]), int(d["kfv"]), int(d["start"])) for d in merged]
+    assert keys == sorted(keys)
