@@ -50,12 +50,41 @@ def main():
             "n_at_threshold": int(st["n_at_threshold"]),
         }
 
+    def chain(name, mode, buff):
+        """One scan with KGMA_F_CHAIN_REPLAY (host-side Float64 tie decider): what it costs on this workload."""
+        import time
+        t = time.perf_counter()
+        ctx.scan(g, mode, buff, 0, _lib.F_CHAIN_REPLAY, None)
+        wall = (time.perf_counter() - t) * 1e3
+        st = ctx.stats()
+        out[name]["chain_replay"] = {"scan_call_wall_ms": round(wall, 1), "chain_ms": round(st["chain_ms"], 1),
+                                     "record_kfv_pairs": int(st["n_chain_pairs"]), "windows_walked": int(st["chain_windows"]),
+                                     "n_hits": int(st["n_hits"]), "n_tie_flagged": int(st["n_tie_flagged"])}
+
     ctx.set_refs(6, [refs["RV"]], [refs["ws"]], [30.0], [refs["N"]])
     ctx.scan(g, _lib.MODE_SINGLE, 50, 0, 0, None)              # warm-up (tile table, pack)
     run("config3_findGenes_k6_1kfv", _lib.MODE_SINGLE, 50)
+    chain("config3_findGenes_k6_1kfv", _lib.MODE_SINGLE, 50)
     ctx.set_refs(6, cl["KFVs"], cl["ws"], [37.0, 33.0, 38.0, 34.0, 28.0], cl["N"])
     ctx.scan(g, _lib.MODE_OMN, 100, 0, 0, None)
     run("config4_cluster_mode_k6_5kfv", _lib.MODE_OMN, 100)
+    chain("config4_cluster_mode_k6_5kfv", _lib.MODE_OMN, 100)
+    # the same scan with every dip's candidate range re-aligned on the device (kgma_scan_aligned, -200/-1)
+    import time
+    t = time.perf_counter()
+    ctx.scan_aligned(g, _lib.MODE_OMN, 100, 0, 0, cl["cons"], -200, -1)
+    wall = (time.perf_counter() - t) * 1e3
+    al, nd, nh = ctx.alignments()
+    out["config4_cluster_mode_k6_5kfv"]["aligned_scan"] = {"scan_call_wall_ms": round(wall, 1), "alignments_consumed": len(al),
+                                                         "looked_up_from_device_batch": nd, "host_fallbacks": nh,
+                                                         "n_hits": int(ctx.stats()["n_hits"])}
+    pk = []
+    for _ in range(3):
+        g.repack()
+        ctx.scan_device(g, _lib.MODE_OMN, 0)
+        pk.append(ctx.stats()["pack_ms"])
+    out["pack_kernel"] = {"ms": round(min(pk), 3), "GBps_read_plus_write": round(1.5 * bases / min(pk) / 1e6, 1),
+                          "bytes_per_base": "1 read + 0.25 planes + 0.25 interleaved written"}
     print(json.dumps(out, indent=1))
     if args.out:
         with open(args.out, "w") as fh:
