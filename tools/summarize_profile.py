@@ -85,8 +85,8 @@ def main():
             d["lds_bank_conflict_fraction_of_lds_cycles"] = means["SQ_LDS_BANK_CONFLICT"] / means["SQ_LDS_IDX_ACTIVE"]
     if "SQ_WAIT_ANY" in means and "SQ_WAVE_CYCLES" in means and means["SQ_WAVE_CYCLES"] > 0:
         d["wait_any_fraction_of_wave_cycles"] = means["SQ_WAIT_ANY"] / means["SQ_WAVE_CYCLES"]
-    if "SQ_ACTIVE_INST_VALU" in means and "gpu_cycles" in d:
-        d["valu_busy_fraction_of_kernel"] = means["SQ_ACTIVE_INST_VALU"] * 4.0 / (d["gpu_cycles"] * 1024.0)
+    # (SQ_ACTIVE_INST_VALU is kept raw in per_launch_mean: on gfx950 its unit relative to GRBM_GUI_ACTIVE is not documented
+    #  -- x4 / (cycles x 1024 SIMDs) comes out at 0.97-1.10 for this kernel, i.e. "the vector unit never idles")
     out = {
         "command": "tools/profile_bench.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-secondary --no-cpu-baseline "
                    "(defaults) and one rocprofv3 --pmc <set> --kernel-trace pass per counter set with --steps 2 --warmup 1; "
