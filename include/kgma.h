@@ -159,6 +159,8 @@ void kgma_destroy(kgma_ctx *ctx);
 
 /* Upload the reference KFV(s).  ref: m x 4^k row-major Float64 (refVec / refVecs, natural k-mer
  * index order: first base most significant, src/Kmers.jl:37-43).  windowsizes[m], thr[m].
+ * DELIBERATE LIMIT: refVec::Vector{Float64} (src/GenomeMiner.jl:6) may be any vector; here a KFV must be S/N with integer S
+ * (every KFV gen_ref_ws_cons / cluster_ref_API produce is); anything else is KGMA_E_UNSUPPORTED.
  * n_refs[m]: number of reference sequences averaged into each KFV (KFV = S/N, S integer); the
  * device computes in exact integers with S = round(ref*N).  n_refs == NULL: N is inferred
  * (smallest N <= 2^20 making ref*N integral to 1e-9); KGMA_E_UNSUPPORTED if none exists.
@@ -216,7 +218,14 @@ int kgma_genome_poke(kgma_ctx *ctx, kgma_genome *g, int64_t contig, int64_t pos,
  * benchmarks that time pack + scan). */
 int kgma_genome_repack(kgma_ctx *ctx, kgma_genome *g);
 
-/* Scan every record of `g`.  mode: KGMA_MODE_*.  buff: `buff`.  genome_pos0: the cluster
+/* Scan every record of `g`.  mode: KGMA_MODE_*.  buff: `buff`.
+ * (What "identical to the reference" means: every window's distance is the exact value; the hit list is the one
+ * the reference's Float64 arithmetic produces wherever that does not hang on rounding noise.  Where it does -- dips
+ * reported with KGMA_HIT_TIE / KGMA_HIT_AT_THRESHOLD, windows counted in kgma_stats.n_at_threshold -- exact arithmetic's
+ * choice is returned unless KGMA_F_CHAIN_REPLAY is passed, which takes those decisions from a replay of the reference's
+ * running value and leaves nothing flagged.  So: bit-identical with the flag; without it, bit-identical whenever
+ * n_tie_flagged == 0 && n_at_threshold == 0.)
+ * genome_pos0 is the cluster
  * engine's `genome_pos` keyword (OmnGenomeMiner.jl:25); ignored (0) by the single engine.
  * Results are kept in the context until the next scan. */
 int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, int64_t genome_pos0,
@@ -331,15 +340,17 @@ int kgma_step_end(kgma_ctx *ctx, kgma_hit *out, int64_t cap, int64_t *n);
 /* The count-table stream kernel sizes its streams so that one round of workgroups fills every CU of the chip
  * (one workgroup takes a CU's whole LDS).  A caller that runs other kernels beside the scan -- the RCCL
  * collective of a multi-rank step loop, whose workgroups wait on their peers while resident -- reserves `n`
- * CUs for them (0..128; default 0): the scan then uses 256 - n workgroups per round, so that neither kernel
+ * CUs for them (0 .. half of the device's CUs, queried at kgma_create; default 0): the scan then uses (CUs - n) x the
+ * resident waves per CU as its number of streams per round, so that neither kernel
  * waits for the other's workgroups to retire.  Takes effect at the next scan. */
 int kgma_set_reserved_cus(kgma_ctx *ctx, int32_t n);
 
 /* Host stream handle (hipStream_t) the context launches on, for callers that time with hipEvents. */
 void *kgma_stream(kgma_ctx *ctx);
 
-/* Name of the device kernel the last scan launched ("stream_kernel<6>" / "scan_kernel<8>"): the
- * count-table stream kernel serves k = 5, 6 with one KFV per launch, the bit-sliced kernel the rest. */
+/* Name of the device kernel the last scan launched ("stream8_kernel<6>" / "stream_kernel<6>" / "scan_kernel<8>"): the
+ * 8-bit count-table stream kernel serves k = 5, 6 (windows of <= 383 k-mers; the KFVs of one window size per launch), the
+ * 16-bit one longer windows, the bit-sliced kernel the rest. */
 const char *kgma_scan_kernel_name(const kgma_ctx *ctx);
 
 #ifdef __cplusplus
