@@ -38,7 +38,8 @@ hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
 hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 int stream_waves(int k, int nk, int n_kfv, int n_sizes);
 int stream_slots_per_cu(int k, int nk, int n_kfv, int n_sizes, bool s16, int64_t n_ref);
-bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref);
+bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16);
+int stream8_variant(int n_kfv);
 hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
 int pos_tables_per_pass(int k);
 int64_t align_trace_bytes(int m, int n);
@@ -142,6 +143,7 @@ struct kgma_ctx {
     int k = 0, m = 0;
     std::vector<KfvInfo> kfv;
     int32_t *d_Stab = nullptr;        // m x 4^k, device index order (first base least significant)
+    std::map<std::vector<int>, int16_t *> sinter;   // k = 7 stream kernel: interleaved int16 S tables per launch group (device)
     int32_t *d_StabC = nullptr;       // the same tables in the stream kernel's index order ((hi bits << k) | lo bits)
     int64_t *d_Wtab = nullptr;        // window size per KFV (export_kernel's tie gather)
     int16_t *d_diff = nullptr; int64_t diff_cap = 0;   // two-kernel cluster path: per-window self-match differences of a tile chunk
@@ -415,6 +417,7 @@ void kgma_destroy(kgma_ctx *ctx)
     for (double *p : ctx->d_dist) if (p) (void)hipFree(p);
     if (ctx->d_Stab) (void)hipFree(ctx->d_Stab);
     if (ctx->d_StabC) (void)hipFree(ctx->d_StabC);
+    for (auto &kv2 : ctx->sinter) (void)hipFree(kv2.second);
     if (ctx->d_Wtab) (void)hipFree(ctx->d_Wtab);
     if (ctx->d_diff) (void)hipFree(ctx->d_diff);
     if (ctx->d_tiles) (void)hipFree(ctx->d_tiles);
@@ -715,6 +718,8 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_Stab), tab.size() * sizeof(int32_t)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_Stab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (ctx->d_StabC) { (void)hipFree(ctx->d_StabC); ctx->d_StabC = nullptr; }
+    for (auto &kv2 : ctx->sinter) (void)hipFree(kv2.second);
+    ctx->sinter.clear();
     if (k <= KGMA_STREAM_MAX_K) {
         for (int j = 0; j < m; j++)
             for (int64_t v = 0; v < NB; v++)
@@ -1309,16 +1314,17 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     // count table and the corrections), so the cluster engine's KFVs are grouped by window size for it; the bit-sliced
     // kernel groups up to 8 KFVs of up to 4 sizes.
     const char *kenv = getenv("KGMA_KERNEL");                    // testing only: run the other kernel where both apply
-    bool s8_all = k >= 5 && k <= 6 && !(kenv && !strcmp(kenv, "bitslice"));
+    bool s8_all = k >= 5 && k <= 7 && !(kenv && !strcmp(kenv, "bitslice"));
     for (int j = 0; j < m_used && s8_all; j++)
-        s8_all = stream8_applies(k, (int)(ctx->kfv[(size_t)j].W - k + 1), 1, ctx->kfv[(size_t)j].N);
+        s8_all = stream8_applies(k, (int)(ctx->kfv[(size_t)j].W - k + 1), 1, ctx->kfv[(size_t)j].N, ctx->kfv[(size_t)j].Smax <= 32767);
     const std::vector<Group> groups = make_groups(ctx, mode, s8_all);
     auto group_nmax = [&](const Group &gr) { int64_t n = 0; for (int j : gr.kfvs) n = std::max(n, ctx->kfv[(size_t)j].N); return n; };
     auto group_one_size = [&](const Group &gr) { return ctx->kfv[(size_t)gr.kfvs.front()].W == ctx->kfv[(size_t)gr.kfvs.back()].W; };
+    auto group_s16 = [&](const Group &gr) { bool ok = true; for (int j : gr.kfvs) ok = ok && ctx->kfv[(size_t)j].Smax <= 32767; return ok; };
     auto group_s8 = [&](const Group &gr) {
-        return group_one_size(gr) && stream8_applies(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr));
+        return group_one_size(gr) && stream8_applies(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr));
     };
-    bool use_stream = k >= 5 && k <= 6;
+    bool use_stream = (k >= 5 && k <= 6) || (k == 7 && s8_all);   // k = 7: only the 8-bit kernel (S tables in global memory) beats the bit-sliced one
     for (const Group &gr : groups)
         if (gr.kfvs.size() != 1 && !group_s8(gr)) use_stream = false;   // (the 16-bit multi-KFV stream kernel lost to the bit-sliced one: 99 vs 112 Gbp/s)
     if (const char *kv = getenv("KGMA_KERNEL")) {      // testing only: run the other kernel where both apply
@@ -1573,6 +1579,24 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             // all tables; the kernel indexes by KFV id.  The 16-bit stream kernel indexes k-mers as (hi bits << k) | lo bits,
             // the bit-sliced kernel and the 8-bit stream kernel by the 2-bit interleaved code (first base least significant)
             a.Stab = (use_stream && !group_s8(gr)) ? ctx->d_StabC : ctx->d_Stab;
+            a.Sinter = nullptr;
+            if (use_stream && group_s8(gr) && k >= 7) {
+                // the launch's S tables interleaved per k-mer, int16, in the interleaved-code index order; built once per group
+                auto it = ctx->sinter.find(gr.kfvs);
+                if (it == ctx->sinter.end()) {
+                    const int nv = stream8_variant((int)gr.kfvs.size());
+                    const int64_t NBk = (int64_t)1 << (2 * k);
+                    std::vector<int16_t> tab((size_t)NBk * (size_t)nv, 0);
+                    for (size_t u = 0; u < gr.kfvs.size(); u++)
+                        for (int64_t v = 0; v < NBk; v++)
+                            tab[(size_t)device_index_of((uint32_t)v, k) * (size_t)nv + u] = (int16_t)ctx->kfv[(size_t)gr.kfvs[u]].S[(size_t)v];
+                    int16_t *d = nullptr;
+                    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d), tab.size() * sizeof(int16_t)));
+                    HIP_TRY(ctx, hipMemcpy(d, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+                    it = ctx->sinter.emplace(gr.kfvs, d).first;
+                }
+                a.Sinter = it->second;
+            }
             a.D0out = d_D0;                        // [KFV id - 1][tile]
             a.recs = d_recs;
             a.rec_count = reinterpret_cast<unsigned int *>(d_cnt);

@@ -79,6 +79,7 @@ struct ScanArgs {
     const uint32_t *inter;      // the same genome as 2-bit codes, 16 bases per dword (first base = bits 0-1): two dwords per plane word
     const TileDesc *tiles;
     const int32_t *Stab;        // all KFVs' tables, 4^k int32 each, in the launching kernel's index order
+    const int16_t *Sinter;      // stream8_kernel at k = 7: the launch's S tables interleaved per k-mer ([k-mer][NKFV] int16), in global memory
     int64_t *D0out;             // [KFV id - 1][n_tiles]
     DevRecord *recs;
     unsigned int *rec_count;

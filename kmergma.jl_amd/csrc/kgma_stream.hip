@@ -521,8 +521,12 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 template <int K, bool S16, int NKFV>
-__global__ __launch_bounds__(1024, NKFV == 1 ? 8 : (NKFV <= 4 ? 6 : 4)) void stream8_kernel(ScanArgs a, GroupParams gp)
+__global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 : 4))) void stream8_kernel(ScanArgs a, GroupParams gp)
 {
+    // k = 7: a wave's table is 16 KiB, so the LDS holds 10 of them and nothing else; the S tables stay in global memory,
+    // interleaved per k-mer ([k-mer][NKFV] int16: ONE gather per k-mer serves every KFV of the launch; 32-256 KiB, L2-resident)
+    constexpr bool SGLOBAL = K >= 7;
+    static_assert(!SGLOBAL || S16, "the k = 7 path keeps the S tables as int16");
     // The launch parameters that only rare paths need (first-window D, thresholds, record emission, distances) are
     // read from the kernel-argument segment where they are used, through a pointer the optimiser cannot see through:
     // held in scalar registers for the whole kernel they push the per-KFV hot state out (hundreds of spills).
@@ -544,15 +548,17 @@ __global__ __launch_bounds__(1024, NKFV == 1 ? 8 : (NKFV <= 4 ? 6 : 4)) void str
     constexpr size_t per_wave_words = NB / 4 + (NKFV > 1 ? NKFV * ST_WORDS : 0);
     int32_t *sTab32 = reinterpret_cast<int32_t *>(smem);
     int16_t *sTab16 = reinterpret_cast<int16_t *>(smem);
-    uint32_t *C = smem + tab_words_1 * NKFV + (size_t)wave * per_wave_words;
+    uint32_t *C = smem + (SGLOBAL ? 0 : tab_words_1 * NKFV) + (size_t)wave * per_wave_words;
     int32_t *sState = reinterpret_cast<int32_t *>(C + NB / 4);
+    if constexpr (!SGLOBAL) {
 #pragma unroll
-    for (int j = 0; j < NKFV; j++) {
-        if (j >= n_kfv) continue;
-        const int32_t *Sg = a.Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
-        for (int i = threadIdx.x; i < NB; i += blockDim.x) {
-            if constexpr (S16) sTab16[(size_t)j * NB + i] = (int16_t)Sg[i];
-            else sTab32[(size_t)j * NB + i] = Sg[i];
+        for (int j = 0; j < NKFV; j++) {
+            if (j >= n_kfv) continue;
+            const int32_t *Sg = a.Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
+            for (int i = threadIdx.x; i < NB; i += blockDim.x) {
+                if constexpr (S16) sTab16[(size_t)j * NB + i] = (int16_t)Sg[i];
+                else sTab32[(size_t)j * NB + i] = Sg[i];
+            }
         }
     }
     __syncthreads();
@@ -634,12 +640,35 @@ __global__ __launch_bounds__(1024, NKFV == 1 ? 8 : (NKFV <= 4 ? 6 : 4)) void str
         // ---- every LDS operation of the step back to back (the S lookups first: LDS operations of a wave
         //      complete in order, so the wait for the count operations below covers them) -----------------
         int32_t Sr[NKFV], Sl[NKFV];
+        if constexpr (SGLOBAL) {
+            // one gather per k-mer for all KFVs of the launch (issued first: the longest latency of the step)
+            constexpr int NW = NKFV >= 2 ? NKFV / 2 : 1;             // dwords per table row
+            uint32_t vr[NW], vl[NW];
+            if constexpr (NKFV == 1) {
+                vr[0] = (uint32_t)(uint16_t)a.Sinter[kp]; vl[0] = (uint32_t)(uint16_t)a.Sinter[ks];
+            } else {
+                typedef uint32_t rowv __attribute__((ext_vector_type(NW)));
+                const rowv *rows = reinterpret_cast<const rowv *>(a.Sinter);
+                if constexpr (NW == 1) { vr[0] = reinterpret_cast<const uint32_t *>(a.Sinter)[kp]; vl[0] = reinterpret_cast<const uint32_t *>(a.Sinter)[ks]; }
+                else {
+                    const rowv r = rows[kp], l = rows[ks];
 #pragma unroll
-        for (int j = 0; j < NKFV; j++) {
-            Sr[j] = Sl[j] = 0;
-            if (j >= n_kfv) continue;
-            if constexpr (S16) { Sr[j] = sTab16[(size_t)j * NB + kp]; Sl[j] = sTab16[(size_t)j * NB + ks]; }
-            else { Sr[j] = sTab32[(size_t)j * NB + kp]; Sl[j] = sTab32[(size_t)j * NB + ks]; }
+                    for (int w = 0; w < NW; w++) { vr[w] = r[w]; vl[w] = l[w]; }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NKFV; j++) {
+                Sr[j] = (int32_t)(int16_t)(uint16_t)(vr[j / 2] >> (16 * (j & 1)));
+                Sl[j] = (int32_t)(int16_t)(uint16_t)(vl[j / 2] >> (16 * (j & 1)));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NKFV; j++) {
+                Sr[j] = Sl[j] = 0;
+                if (j >= n_kfv) continue;
+                if constexpr (S16) { Sr[j] = sTab16[(size_t)j * NB + kp]; Sl[j] = sTab16[(size_t)j * NB + ks]; }
+                else { Sr[j] = sTab32[(size_t)j * NB + kp]; Sl[j] = sTab32[(size_t)j * NB + ks]; }
+            }
         }
         const uint8_t *Cb = reinterpret_cast<const uint8_t *>(C);
         uint32_t cp = Cb[kp], cs = Cb[ks];                            // counts at the start of the step (raw bytes)
@@ -920,18 +949,19 @@ static bool stream8_env_on()                         // KGMA_STREAM8=0 (testing)
 }
 
 // (N < 2^22: the kernel multiplies N by a count difference with the 24-bit multiplier; n_ref = largest N of the launch)
-bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref)
+bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16)
 {
-    return stream8_env_on() && n_kfv >= 1 && n_kfv <= KGMA_MAX_GROUP && (k == 5 || k == 6) && nk <= KGMA_STREAM8_MAX_NK &&
+    return stream8_env_on() && n_kfv >= 1 && n_kfv <= KGMA_MAX_GROUP && (k == 5 || k == 6 || (k == 7 && s16)) && nk <= KGMA_STREAM8_MAX_NK &&
            n_ref < ((int64_t)1 << 22);
 }
 
-static int stream8_variant(int n_kfv) { return n_kfv <= 1 ? 1 : n_kfv <= 2 ? 2 : n_kfv <= 4 ? 4 : 8; }   // instantiated NKFV
+int stream8_variant(int n_kfv) { return n_kfv <= 1 ? 1 : n_kfv <= 2 ? 2 : n_kfv <= 4 ? 4 : 8; }   // instantiated NKFV
 
 static size_t stream8_lds(int k, bool s16, int nkfv, int nw)
 {
     const size_t NB = (size_t)1 << (2 * k);
-    return NB * (s16 ? 2 : 4) * (size_t)nkfv + (size_t)nw * (NB + (nkfv > 1 ? (size_t)nkfv * ST_WORDS * 4 : 0));
+    const size_t tabs = k >= 7 ? 0 : NB * (s16 ? 2 : 4) * (size_t)nkfv;            // k = 7: the S tables stay in global memory
+    return tabs + (size_t)nw * (NB + (nkfv > 1 ? (size_t)nkfv * ST_WORDS * 4 : 0));
 }
 
 template <int K, bool S16>
@@ -948,6 +978,7 @@ static const void *stream8_fn_k(int nkfv)
 static const void *stream8_fn_of(int k, bool s16, int nkfv)
 {
     if (k == 5) return s16 ? stream8_fn_k<5, true>(nkfv) : stream8_fn_k<5, false>(nkfv);
+    if (k == 7) return stream8_fn_k<7, true>(nkfv);
     return s16 ? stream8_fn_k<6, true>(nkfv) : stream8_fn_k<6, false>(nkfv);
 }
 
@@ -955,7 +986,7 @@ static const void *stream8_fn_of(int k, bool s16, int nkfv)
 // the LDS allocation granule and the kernel's registers); one KFV: two 16-wave workgroups = 32 waves per CU
 void stream8_geometry(int k, bool s16, int nkfv, int *nw_out, int *blocks_out)
 {
-    static int cache[2][2][9][2];
+    static int cache[3][2][9][2];
     static bool init = false;
     if (!init) { memset(cache, 0, sizeof cache); init = true; }
     int *c = cache[k - 5][s16 ? 1 : 0][nkfv];
@@ -1005,6 +1036,7 @@ static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp, hipSt
     hipError_t e = hipFuncSetAttribute(stream8_fn_of(gp.k, s16, nkfv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (gp.k == 5) { if (s16) stream8_launch_ks<5, true>(nkfv, grid, 64u * nw, lds, st, a, gp); else stream8_launch_ks<5, false>(nkfv, grid, 64u * nw, lds, st, a, gp); }
+    else if (gp.k == 7) stream8_launch_ks<7, true>(nkfv, grid, 64u * nw, lds, st, a, gp);
     else           { if (s16) stream8_launch_ks<6, true>(nkfv, grid, 64u * nw, lds, st, a, gp); else stream8_launch_ks<6, false>(nkfv, grid, 64u * nw, lds, st, a, gp); }
     return hipGetLastError();
 }
@@ -1012,7 +1044,7 @@ static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp, hipSt
 // streams resident per CU (what the host sizes the streams for); n_ref = largest reference count of the launch's KFVs
 int stream_slots_per_cu(int k, int nk, int n_kfv, int n_sizes, bool s16, int64_t n_ref)
 {
-    if (n_sizes == 1 && stream8_applies(k, nk, n_kfv, n_ref)) {
+    if (n_sizes == 1 && stream8_applies(k, nk, n_kfv, n_ref, s16)) {
         int nw = 16, blocks = 1;
         stream8_geometry(k, s16, stream8_variant(n_kfv), &nw, &blocks);
         return nw * blocks;
@@ -1025,7 +1057,7 @@ hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t s
     {
         int64_t nmax = 0;
         for (int j = 0; j < gp.n_kfv; j++) nmax = gp.N[j] > nmax ? gp.N[j] : nmax;
-        if (gp.n_sizes == 1 && stream8_applies(gp.k, gp.nk, gp.n_kfv, nmax)) return launch_stream8(a, gp, st);
+        if (gp.n_sizes == 1 && stream8_applies(gp.k, gp.nk, gp.n_kfv, nmax, gp.s_fits_i16 != 0)) return launch_stream8(a, gp, st);
     }
     switch (gp.k) {
     case 2: return launch_stream_k<2>(a, gp, st);

@@ -213,11 +213,19 @@ def test_config5_k7_eight_kfvs_50mb(ctx):
     ohits, _ = orc.omn_scan(seqs, KFVs, k, ws, thr, 100, 77, hit_cap=1 << 16)
     assert len(ohi) >= 40
     ctx.set_refs(k, KFVs, ws, thr, N)
-    old = os.environ.get("KGMA_TWOKERNEL")
+    old, oldk = os.environ.get("KGMA_TWOKERNEL"), os.environ.get("KGMA_KERNEL")
     try:
-        for two in ("0", "1"):
-            os.environ["KGMA_TWOKERNEL"] = two
+        # default: the 8-bit stream kernel (KFVs grouped by window size, S tables interleaved in global memory);
+        # KGMA_KERNEL=bitslice: the bit-sliced kernel in one launch (two = "0") and the two-kernel path (two = "1")
+        for two in ("stream8", "0", "1"):
+            if two == "stream8":
+                os.environ.pop("KGMA_KERNEL", None)
+                os.environ.pop("KGMA_TWOKERNEL", None)
+            else:
+                os.environ["KGMA_KERNEL"] = "bitslice"
+                os.environ["KGMA_TWOKERNEL"] = two
             ctx.scan(g, _lib.MODE_OMN, 100, 77, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
+            assert ctx.kernel_name().startswith("stream8_kernel<7>" if two == "stream8" else "scan_kernel<7>")
             hits = ctx.hits()
             assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi], f"two-kernel={two}"
             assert [h["D"] for h in hits] == [h["D"] for h in ohi]
@@ -230,10 +238,11 @@ def test_config5_k7_eight_kfvs_50mb(ctx):
             assert [hit_key(h) for h in hits_c] == [hit_key(h) for h in ohits], f"two-kernel={two}"
             assert st_c["n_tie_flagged"] == 0
     finally:
-        if old is None:
-            os.environ.pop("KGMA_TWOKERNEL", None)
-        else:
-            os.environ["KGMA_TWOKERNEL"] = old
+        for name, val in (("KGMA_TWOKERNEL", old), ("KGMA_KERNEL", oldk)):
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val
     g.free()
 
 

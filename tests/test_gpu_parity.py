@@ -560,7 +560,7 @@ def test_stream_kernel_cluster_mode(ctx, data_dir, genes, k, force_kernel):
     ctx.set_refs(k, c["KFVs"], ws, thr, c["N"])
     gen = ctx.genome_from_host(contigs)
     ctx.scan(gen, _lib.MODE_OMN, 100, 77, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
-    assert ctx.kernel_name().startswith("stream8_kernel" if k <= 6 else "stream_kernel")
+    assert ctx.kernel_name().startswith("stream8_kernel")      # 8-bit kernel at k = 5, 6 and (S tables in global memory) 7
     hits = ctx.hits()
     dists = [ctx.dists(j + 1) for j in range(m)]
     gen.free()
