@@ -1584,7 +1584,8 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
                 // the launch's S tables interleaved per k-mer, int16, in the interleaved-code index order; built once per group
                 auto it = ctx->sinter.find(gr.kfvs);
                 if (it == ctx->sinter.end()) {
-                    const int nv = stream8_variant((int)gr.kfvs.size());
+                    const int nv0 = stream8_variant((int)gr.kfvs.size());
+                    const int nv = nv0 == 3 ? 4 : nv0;                 // row width in int16 slots
                     const int64_t NBk = (int64_t)1 << (2 * k);
                     std::vector<int16_t> tab((size_t)NBk * (size_t)nv, 0);
                     for (size_t u = 0; u < gr.kfvs.size(); u++)

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
         asm volatile("" : "+s"(ka));
         gpp = reinterpret_cast<const GroupParams *>(ka);
     }
-    const int n_kfv = NKFV == 1 ? 1 : gp.n_kfv;                        // KFVs of this launch (<= NKFV), all of ONE window size
+    const int n_kfv = NKFV < 8 ? NKFV : gp.n_kfv;                      // KFVs of this launch, all of ONE window size (variants 1-4 are launched full)
     constexpr int NB = 1 << (2 * K);
     extern __shared__ uint32_t smem[];
 
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
         int32_t Sr[NKFV], Sl[NKFV];
         if constexpr (SGLOBAL) {
             // one gather per k-mer for all KFVs of the launch (issued first: the longest latency of the step)
-            constexpr int NW = NKFV >= 2 ? NKFV / 2 : 1;             // dwords per table row
+            constexpr int NW = NKFV >= 2 ? (NKFV + 1) / 2 : 1;       // dwords per table row (NKFV = 3: a 4-slot row)
             uint32_t vr[NW], vl[NW];
             if constexpr (NKFV == 1) {
                 vr[0] = (uint32_t)(uint16_t)a.Sinter[kp]; vl[0] = (uint32_t)(uint16_t)a.Sinter[ks];
@@ -739,19 +739,23 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
         // left == right: same k-mer, same count, difference 0; otherwise c[l] - 1 - c[r]
         const int32_t dd = cS - cP - (differ ? 1 : 0);
         // ---- per KFV (all of this launch's KFVs have the same window: same k-mers, same counts) ----------------
+        // Phase 1: e of every KFV (and, in warm-up steps, the first-window D)
+        int32_t sc[NKFV];
 #pragma unroll
         for (int j = 0; j < NKFV; j++) {
-            if (j >= n_kfv) continue;
+            sc[j] = 0;
+            if (NKFV == 8 && j >= n_kfv) continue;                    // (smaller variants are launched full)
             int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
             const int32_t Nj = gp.N[j];
-            const int64_t twoN = 2 * (int64_t)Nj;
             // GenomeMiner.jl:67-68 times 2kN^2 / 2N.  Without a transition the two k-mers are equal (Sl == Sr,
             // dd == 0) except in the warm-up, where there is no leaving k-mer at all.
             int32_t e = Sl[j] - Sr[j] - __mul24(Nj, dd);
             if constexpr (GENERIC) e = actL ? e : 0;
+            sc[j] = e;
 
             if constexpr (GENERIC) {
                 if ((b << 6) < nk) {                                  // warm-up steps: first-window D
+                    const int64_t twoN = 2 * (int64_t)Nj;
                     const bool wu = p < nk;
                     const int64_t ssum = wave_sum_i64(wu ? (int64_t)Sr[j] : 0);
                     const int64_t psum = wave_sum_i64(wu ? (int64_t)cP : 0);
@@ -782,29 +786,64 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
                     }
                 }
             }
-
-            const int32_t E = wave_incl_scan(e) + h_carry[j];
-            h_carry[j] = __builtin_amdgcn_readlane(E, 63);
-            const int32_t TE = h_TE[j];
-            const int q = p - nk + 1;                                 // window start (local) this transition leads to
-            bool tested = true;
-            if constexpr (GENERIC) tested = q >= first_test && q < n_valid;
-            const bool under = tested && E < TE;
-            if ((dist_mask >> j) & 1u) {
-                if (tested) {
-                    const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
-                    a.dist[j][td.dist_base + q] = (double)(D0 + twoN * (int64_t)E) / gpp->inv_scale[j];
-                }
+        }
+        // Phase 2: the prefix sums of all KFVs, stage by stage (independent DPP chains interleave: no wait states between
+        // the dependent steps of one chain)
+#define KGMA_SCAN_STAGE(ctrl, rmask)                                                                        \
+        _Pragma("unroll") for (int j = 0; j < NKFV; j++) sc[j] += __builtin_amdgcn_update_dpp(0, sc[j], ctrl, rmask, 0xF, false);
+        KGMA_SCAN_STAGE(0x111, 0xF)     // row_shr:1
+        KGMA_SCAN_STAGE(0x112, 0xF)     // row_shr:2
+        KGMA_SCAN_STAGE(0x114, 0xF)     // row_shr:4
+        KGMA_SCAN_STAGE(0x118, 0xF)     // row_shr:8
+        KGMA_SCAN_STAGE(0x142, 0xA)     // row_bcast:15 -> rows 1,3
+        KGMA_SCAN_STAGE(0x143, 0xC)     // row_bcast:31 -> rows 2,3
+#undef KGMA_SCAN_STAGE
+        // Phase 3: thresholds; one combined test decides whether any KFV has a dip in this step
+        const int q = p - nk + 1;                                     // window start (local) this transition leads to
+        bool tested = true;
+        uint64_t TESTED = ~(uint64_t)0;
+        if constexpr (GENERIC) { tested = q >= first_test && q < n_valid; TESTED = __ballot(tested); }
+        int32_t E[NKFV];
+        uint64_t Um[NKFV];
+        uint64_t anyU = 0;
+#pragma unroll
+        for (int j = 0; j < NKFV; j++) {
+            E[j] = 0; Um[j] = 0;
+            if (NKFV == 8 && j >= n_kfv) continue;
+            E[j] = sc[j] + h_carry[j];
+            h_carry[j] = __builtin_amdgcn_readlane(E[j], 63);
+            Um[j] = __builtin_amdgcn_sicmp(E[j], h_TE[j], 40 /* slt */) & TESTED;
+            anyU |= Um[j];
+        }
+        if (dist_mask != 0) {
+#pragma unroll
+            for (int j = 0; j < NKFV; j++) {
+                if (!((dist_mask >> j) & 1u) || !tested) continue;
+                const int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
+                const int64_t twoN = 2 * (int64_t)gp.N[j];
+                const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
+                a.dist[j][td.dist_base + q] = (double)(D0 + twoN * (int64_t)E[j]) / gpp->inv_scale[j];
             }
+        }
+        if (anyU == 0 && inrun_mask == 0 && att_mask == 0) return;    // fast path: nothing near any threshold
+
+#pragma unroll
+        for (int j = 0; j < NKFV; j++) {
+            if (NKFV == 8 && j >= n_kfv) continue;
+            int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
+            const int32_t Ej = E[j];
+            const int32_t TE = h_TE[j];
+            const uint64_t U = Um[j];
+            const bool under = (U >> lane) & 1u;
             bool att = false;
             uint64_t A = 0;
             if ((att_mask >> j) & 1u) {                                // (only when the threshold sits on the distance lattice)
-                att = tested && !under && E - TE < uni(st[ST_NATT]);
+                att = tested && !under && Ej - TE < uni(st[ST_NATT]);
                 A = __ballot(att);
             }
-            const uint64_t U = __ballot(under);
             int in_run = (int)((inrun_mask >> j) & 1u);
-            if ((U | A) == 0 && !in_run) continue;                    // fast path: nothing near the threshold
+            if ((U | A) == 0 && !in_run) continue;
+            const int32_t E = Ej;
 
             // ---- a dip touches this step: walk its runs (wave-uniform) ----------------------------
             const int kid = gpp->kfv_id[j];
@@ -955,7 +994,7 @@ bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16)
            n_ref < ((int64_t)1 << 22);
 }
 
-int stream8_variant(int n_kfv) { return n_kfv <= 1 ? 1 : n_kfv <= 2 ? 2 : n_kfv <= 4 ? 4 : 8; }   // instantiated NKFV
+int stream8_variant(int n_kfv) { return n_kfv <= 4 ? (n_kfv < 1 ? 1 : n_kfv) : 8; }   // instantiated NKFV: 1-4 are launched full, 8 takes 5-8 KFVs
 
 static size_t stream8_lds(int k, bool s16, int nkfv, int nw)
 {
@@ -970,6 +1009,7 @@ static const void *stream8_fn_k(int nkfv)
     switch (nkfv) {
     case 1: return reinterpret_cast<const void *>(&stream8_kernel<K, S16, 1>);
     case 2: return reinterpret_cast<const void *>(&stream8_kernel<K, S16, 2>);
+    case 3: return reinterpret_cast<const void *>(&stream8_kernel<K, S16, 3>);
     case 4: return reinterpret_cast<const void *>(&stream8_kernel<K, S16, 4>);
     default: return reinterpret_cast<const void *>(&stream8_kernel<K, S16, 8>);
     }
@@ -1013,6 +1053,7 @@ static void stream8_launch_ks(int nkfv, unsigned grid, unsigned threads, size_t 
     switch (nkfv) {
     case 1: hipLaunchKernelGGL((stream8_kernel<K, S16, 1>), dim3(grid), dim3(threads), lds, st, a, gp); break;
     case 2: hipLaunchKernelGGL((stream8_kernel<K, S16, 2>), dim3(grid), dim3(threads), lds, st, a, gp); break;
+    case 3: hipLaunchKernelGGL((stream8_kernel<K, S16, 3>), dim3(grid), dim3(threads), lds, st, a, gp); break;
     case 4: hipLaunchKernelGGL((stream8_kernel<K, S16, 4>), dim3(grid), dim3(threads), lds, st, a, gp); break;
     default: hipLaunchKernelGGL((stream8_kernel<K, S16, 8>), dim3(grid), dim3(threads), lds, st, a, gp); break;
     }
