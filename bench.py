@@ -253,8 +253,9 @@ def main():
                                          "achieved_GBps": round(PACK_BYTES_PER_BASE * my_bases / (avg_pack_ms * 1e-3) / 1e9, 1),
                                          "frac_of_hbm_peak": round(PACK_BYTES_PER_BASE * my_bases / (avg_pack_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                          "binding_note": "the scan moves 0.25 B per base: its binding resources are VALU issue and LDS latency, "
-                                         "not HBM (DESIGN.md section 4; `pmc` holds VALU instructions per cycle per SIMD "
-                                         "against the 0.5 issue peak of gfx950); the pack kernel is the HBM-bound one"},
+                                         "not HBM (DESIGN.md section 4; `pmc` holds VALU instructions per cycle per SIMD: "
+                                         "0.21-0.24 is what gfx950 issues of 3-operand forms, 0.38-0.41 of 2-operand ones, "
+                                         "profiles/r01_valu_issue_rates.txt); the pack kernel is the HBM-bound one"},
         }
         if world == 1 and not args.no_secondary:
             # one step with the Float64 chain replay (host-side tie decider), for the record
