@@ -256,6 +256,14 @@ int kgma_host_semiglobal_cigar(const uint8_t *a, int64_t m, const uint8_t *b, in
                                int32_t gap_open_score, int32_t gap_extend_score, char *cigar,
                                int64_t cigar_cap, int64_t *score_out);
 
+/* HOST-side helper (no device): the reference's running Float64 distance kmerDist (src/GenomeMiner.jl:46-47,70-77; the same
+ * update in src/OmnGenomeMiner.jl:73-74,101-108) of one sequence, from its first window on, sampled at the windows of
+ * the given intervals (1-based window starts, sorted, disjoint): what KGMA_F_CHAIN_REPLAY runs for the (record, KFV) pairs
+ * that contain a rounding-dependent tie.  Two-call pattern via cap / *n_out as elsewhere. */
+int kgma_host_chain_values(const uint8_t *seq, int64_t len, const double *ref, int32_t k, int64_t windowsize,
+                           const int64_t *win_lo, const int64_t *win_hi, int64_t n_intervals, double *out, int64_t cap,
+                           int64_t *n_out);
+
 /* ---- scans sharded INSIDE a record (one process per GPU; kmergma_amd.parallel.scan_sharded) ----------
  * A rank scans its slice of the records with kgma_scan_device, decides the ties that need its residues
  * (kgma_resolve_ties_local), and ships kgma_get_dips + kgma_get_dip_last_min (+ kgma_get_first_window for

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "kgma_chain.h"
+#include "../../include/kgma.h"
 
 namespace kgma {
 
@@ -129,3 +130,31 @@ void run_chain_jobs(ChainJob *jobs, size_t n_jobs, int n_threads)
 }
 
 }  // namespace kgma
+
+// C ABI: the chain on one sequence, for hosts and tests (no device involved)
+extern "C" int kgma_host_chain_values(const uint8_t *seq, int64_t len, const double *ref, int32_t k, int64_t windowsize,
+                                      const int64_t *win_lo, const int64_t *win_hi, int64_t n_intervals, double *out,
+                                      int64_t cap, int64_t *n_out)
+{
+    if (!seq || !ref || !win_lo || !win_hi || !out || !n_out || k < 1 || k > 10 || windowsize < k || len < windowsize || n_intervals < 1)
+        return KGMA_E_ARG;
+    std::vector<kgma::ChainInterval> iv((size_t)n_intervals);
+    int64_t total = 0, prev = 0;
+    for (int64_t i = 0; i < n_intervals; i++) {
+        if (win_lo[i] < 1 || win_hi[i] < win_lo[i] || win_lo[i] <= prev || win_hi[i] > len - windowsize + 1) return KGMA_E_ARG;
+        iv[(size_t)i] = kgma::ChainInterval{win_lo[i], win_hi[i]};
+        total += win_hi[i] - win_lo[i] + 1;
+        prev = win_hi[i];
+    }
+    *n_out = total;
+    if (cap < total) return KGMA_E_ARG;
+    for (int64_t i = 0; i < windowsize + iv.back().hi - 1; i++) {
+        const uint8_t c = (uint8_t)(seq[i] & 0xDF);
+        if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') return KGMA_E_BADBASE;
+    }
+    kgma::ChainJob J;
+    J.seq = seq; J.n_res = len; J.ref = ref; J.k = k; J.W = windowsize; J.last_window = iv.back().hi;
+    J.iv = iv.data(); J.n_iv = iv.size(); J.out = out; J.n_out = 0; J.ok = false;
+    kgma::run_chain_jobs(&J, 1, 1);
+    return J.ok && J.n_out == total ? KGMA_OK : KGMA_E_ARG;
+}

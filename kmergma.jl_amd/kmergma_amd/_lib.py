@@ -31,7 +31,7 @@ EXPORTS = [
     "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_header", "kgma_scan_kernel_name",
     "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips", "kgma_align_hits_device", "kgma_repack_scan_hits",
     "kgma_kmer_count_batch", "kgma_kmer_dist_batch", "kgma_step_begin", "kgma_step_end", "kgma_set_reserved_cus",
-    "kgma_scan_aligned", "kgma_get_alignments", "kgma_set_residue_source",
+    "kgma_scan_aligned", "kgma_get_alignments", "kgma_set_residue_source", "kgma_host_chain_values",
 ]
 
 
@@ -146,12 +146,30 @@ def load():
     L.kgma_scan_aligned.argtypes = [vp, vp, i32, i64, i64, C.c_uint32, P(C.c_char_p), P(i64), i32, i32]
     L.kgma_get_alignments.argtypes = [vp, P(KgmaAlignment), i64, P(i64), P(i64), P(i64)]
     L.kgma_set_residue_source.argtypes = [vp, FETCH_FN, vp]
+    L.kgma_host_chain_values.argtypes = [C.c_char_p, i64, P(dbl), i32, i64, P(i64), P(i64), i64, P(dbl), i64, P(i64)]
     L.kgma_stream.argtypes = [vp]
     L.kgma_stream.restype = vp
     L.kgma_scan_kernel_name.argtypes = [vp]
     L.kgma_scan_kernel_name.restype = C.c_char_p
     _lib = L
     return L
+
+
+def host_chain_values(seq: bytes, ref, k: int, windowsize: int, intervals) -> np.ndarray:
+    """kgma_host_chain_values: the reference's running Float64 distance of `seq` at the windows of `intervals`
+    (list of (lo, hi), 1-based window starts).  Host only: needs no GPU."""
+    r = np.ascontiguousarray(ref, dtype=np.float64)
+    lo = np.asarray([a for a, _ in intervals], dtype=np.int64)
+    hi = np.asarray([b for _, b in intervals], dtype=np.int64)
+    n = int((hi - lo + 1).sum())
+    out = np.zeros(max(n, 1), dtype=np.float64)
+    nn = C.c_int64(0)
+    st = load().kgma_host_chain_values(bytes(seq), len(seq), r.ctypes.data_as(C.POINTER(C.c_double)), int(k), int(windowsize),
+                                       lo.ctypes.data_as(C.POINTER(C.c_int64)), hi.ctypes.data_as(C.POINTER(C.c_int64)), lo.size,
+                                       out.ctypes.data_as(C.POINTER(C.c_double)), out.size, C.byref(nn))
+    if st != KGMA_OK:
+        raise KgmaError(st, "kgma_host_chain_values failed")
+    return out[:nn.value]
 
 
 def _np_ptr(a, t):

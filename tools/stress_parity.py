@@ -2,7 +2,8 @@
 """Randomised differential test of the HIP path against the CPU oracle (run on a GPU box):
 random k, window sizes, numbers of KFVs, thresholds, genomes with repeats / N runs / planted genes.
 Exact-arithmetic mode must equal the integer oracle bit for bit; default mode must equal the
-reference-order Float64 oracle except on hits flagged rounding-history dependent.
+reference-order Float64 oracle except on hits flagged rounding-history dependent; chain-replay mode
+(KGMA_F_CHAIN_REPLAY) must equal the Float64 oracle without exception.
 
 usage: python tools/stress_parity.py [--seconds 300] [--seed 1]
 """
@@ -91,7 +92,9 @@ def one_case(ctx, rng, case):
             ctx.scan(gen, _lib.MODE_SINGLE, buff, 0, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
             hits, d = ctx.hits(), ctx.dists(1)
             ctx.scan(gen, _lib.MODE_SINGLE, buff, 0, 0, None)
-            hits_f = ctx.hits()
+            hits_f, dips_f, st_f = ctx.hits(), ctx.dips(), ctx.stats()
+            ctx.scan(gen, _lib.MODE_SINGLE, buff, 0, _lib.F_CHAIN_REPLAY, None)
+            hits_c, st_c = ctx.hits(), ctx.stats()
             T = orc.int_threshold(thr[0], k, Ns[0])
             ohi, oD, _ = orc.single_scan_int(contigs, Ss[0], Ns[0], k, ws[0], T, buff, return_D=True)
             ohf, _ = orc.single_scan(contigs, KFVs[0], k, ws[0], thr[0], buff)
@@ -103,7 +106,9 @@ def one_case(ctx, rng, case):
             hits = ctx.hits()
             dl = [ctx.dists(j + 1) for j in range(m)]
             ctx.scan(gen, _lib.MODE_OMN, buff, gp0, 0, None)
-            hits_f = ctx.hits()
+            hits_f, dips_f, st_f = ctx.hits(), ctx.dips(), ctx.stats()
+            ctx.scan(gen, _lib.MODE_OMN, buff, gp0, _lib.F_CHAIN_REPLAY, None)
+            hits_c, st_c = ctx.hits(), ctx.stats()
             T = [orc.int_threshold(t, k, n) for t, n in zip(thr, Ns)]
             ohi, oD = orc.omn_scan_int(contigs, Ss, Ns, k, ws, T, buff, gp0, return_D=True)
             ohf, _ = orc.omn_scan(contigs, KFVs, k, ws, thr, buff, gp0)
@@ -111,6 +116,12 @@ def one_case(ctx, rng, case):
                 assert np.array_equal(dl[j], oD[j] / (2.0 * k * Ns[j] ** 2)), f"dists kfv {j}"
         assert [key(h) for h in hits] == [key(h) for h in ohi], "hits vs integer oracle"
         assert [h["D"] for h in hits] == [h["D"] for h in ohi], "D vs integer oracle"
+        # chain replay: identical to the reference-order Float64 oracle, chain-decided hits carry its distance bit for bit
+        assert [key(h) for h in hits_c] == [key(h) for h in ohf], "chain replay vs float oracle"
+        assert st_c["n_tie_flagged"] == 0, "chain replay left a tie flagged"
+        for a, b in zip(hits_c, ohf):
+            if a["flags"] & _lib.HIT_CHAIN:
+                assert a["dist"] == b["dist"], "chain replay distance"
         nflag = 0
         if [key(h) for h in hits_f] != [key(h) for h in ohf]:
             # Float64 rounding decided something exact arithmetic cannot: legitimate only downstream
@@ -120,8 +131,8 @@ def one_case(ctx, rng, case):
             cands = [h for h in (hits_f[first:first + 1] + ohf[first:first + 1])]
             c0, p0 = min((h["contig"], h["cmi"]) for h in cands)
             # (the cluster engine emits hits in exit order, not in position order: any flagged dip of the record counts)
-            flagged = [d for d in ctx.dips() if d["contig"] == c0 and (d["flags"] & 3) and (not mode_single or d["start"] <= p0 + max(ws))]
-            assert flagged or ctx.stats()["n_at_threshold"] > 0, "float oracle: difference with no flagged dip upstream"
+            flagged = [d for d in dips_f if d["contig"] == c0 and (d["flags"] & 3) and (not mode_single or d["start"] <= p0 + max(ws))]
+            assert flagged or st_f["n_at_threshold"] > 0, "float oracle: difference with no flagged dip upstream"
             nflag = 1
         # the same scan sharded INSIDE records (the ranks' parts run one after the other): identical hits
         if not (mode_single is False and any(len(c) < k - 1 for c in contigs)):
