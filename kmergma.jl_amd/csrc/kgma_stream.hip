@@ -547,7 +547,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
     constexpr size_t tab_words_1 = S16 ? NB / 2 : NB;
     constexpr size_t per_wave_words = NB / 4 + (NKFV > 1 ? NKFV * ST_WORDS : 0);
     int32_t *sTab32 = reinterpret_cast<int32_t *>(smem);
-    int16_t *sTab16 = reinterpret_cast<int16_t *>(smem);
+    uint16_t *sTab16 = reinterpret_cast<uint16_t *>(smem);          // S >= 0 (sums of counts): read zero-extended
     uint32_t *C = smem + (SGLOBAL ? 0 : tab_words_1 * NKFV) + (size_t)wave * per_wave_words;
     int32_t *sState = reinterpret_cast<int32_t *>(C + NB / 4);
     if constexpr (!SGLOBAL) {
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
             if (j >= n_kfv) continue;
             const int32_t *Sg = a.Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
             for (int i = threadIdx.x; i < NB; i += blockDim.x) {
-                if constexpr (S16) sTab16[(size_t)j * NB + i] = (int16_t)Sg[i];
+                if constexpr (S16) sTab16[(size_t)j * NB + i] = (uint16_t)Sg[i];
                 else sTab32[(size_t)j * NB + i] = Sg[i];
             }
         }
@@ -658,8 +658,8 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
             }
 #pragma unroll
             for (int j = 0; j < NKFV; j++) {
-                Sr[j] = (int32_t)(int16_t)(uint16_t)(vr[j / 2] >> (16 * (j & 1)));
-                Sl[j] = (int32_t)(int16_t)(uint16_t)(vl[j / 2] >> (16 * (j & 1)));
+                Sr[j] = (int32_t)(uint16_t)(vr[j / 2] >> (16 * (j & 1)));   // S >= 0: zero-extended
+                Sl[j] = (int32_t)(uint16_t)(vl[j / 2] >> (16 * (j & 1)));
             }
         } else {
 #pragma unroll
@@ -676,7 +676,9 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
         // this lane's transition; the old values tell whether another lane touched the k-mer.  Lanes without a
         // transition (left == right: homopolymer / N runs) issue nothing: 64 lanes adding 0 to one address would
         // serialise in the LDS for nothing
-        uint32_t wop = 0, wos = 0;
+        // (lanes that issue nothing keep whatever the registers hold: their bits of the pending masks are cleared by AE / AL)
+        uint32_t wop, wos;
+        asm volatile("" : "=v"(wop), "=v"(wos));
         if (actE) wop = atomicAdd(&C[kp >> 2], one << shp);           // (`one` lives in a vector register: v_lshlrev in its short form)
         if (actL) wos = atomicSub(&C[ks >> 2], one << shs);
 
