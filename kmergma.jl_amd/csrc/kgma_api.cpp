@@ -37,7 +37,8 @@ hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int
 hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 int stream_waves(int k, int nk, int n_kfv, int n_sizes);
-int stream_slots_per_cu(int k, int nk, int n_kfv, int n_sizes, bool s16, int64_t n_ref);
+int stream_slots_per_cu(int k, int nk, int nk_min, int n_longer, int n_kfv, int n_sizes, bool s16, int64_t n_ref);
+bool stream8_derive_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool s16);
 bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16);
 int stream8_variant(int n_kfv);
 hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
@@ -311,9 +312,12 @@ void threshold_band(double thr, int k, int64_t N, int64_t *T_lo, int64_t *T_hi)
 
 // Launch groups: KFVs sorted by window size; a launch takes up to KGMA_MAX_GROUP KFVs whose sizes
 // span at most KGMA_MAX_DW with at most KGMA_MAX_SIZES distinct values (the match loop runs once, for
-// the largest).
-std::vector<Group> make_groups(const kgma_ctx *ctx, int mode, bool same_size_only = false)
+// the largest).  For the 8-bit stream kernel (s8): the KFVs of ONE window size, up to KGMA_MAX_GROUP -- or 2-4 KFVs of
+// sizes W and W + 1 (the kernel keeps the table for W and derives the longer windows; int16 S tables only).
+std::vector<Group> make_groups(const kgma_ctx *ctx, int mode, bool s8 = false)
 {
+    const char *de = getenv("KGMA_STREAM8_DERIVE");
+    const bool derive_ok = s8 && !(de && atoi(de) == 0);
     std::vector<Group> gs;
     if (mode == KGMA_MODE_SINGLE) {
         gs.push_back(Group{ctx->kfv[0].W, {0}});
@@ -331,7 +335,16 @@ std::vector<Group> make_groups(const kgma_ctx *ctx, int mode, bool same_size_onl
             int64_t last = -1;
             for (int u : g.kfvs) { if (ctx->kfv[(size_t)u].W != last) { distinct++; last = ctx->kfv[(size_t)u].W; } }
             const int64_t wmin = ctx->kfv[(size_t)g.kfvs.front()].W;
-            if ((int)g.kfvs.size() < KGMA_MAX_GROUP && W - wmin <= KGMA_MAX_DW && (W == last || (distinct < KGMA_MAX_SIZES && !same_size_only))) {
+            bool fits;
+            if (s8) {
+                bool s16 = ctx->kfv[(size_t)j].Smax <= 32767;
+                for (int u : g.kfvs) s16 = s16 && ctx->kfv[(size_t)u].Smax <= 32767;
+                fits = (W == wmin && last == wmin && (int)g.kfvs.size() < KGMA_MAX_GROUP) ||
+                       (derive_ok && s16 && W <= wmin + 1 && (int)g.kfvs.size() < 4);
+            } else {
+                fits = (int)g.kfvs.size() < KGMA_MAX_GROUP && W - wmin <= KGMA_MAX_DW && (W == last || distinct < KGMA_MAX_SIZES);
+            }
+            if (fits) {
                 g.kfvs.push_back(j);
                 g.W = W;        // largest so far (sorted)
                 placed = true;
@@ -1321,8 +1334,10 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     auto group_nmax = [&](const Group &gr) { int64_t n = 0; for (int j : gr.kfvs) n = std::max(n, ctx->kfv[(size_t)j].N); return n; };
     auto group_one_size = [&](const Group &gr) { return ctx->kfv[(size_t)gr.kfvs.front()].W == ctx->kfv[(size_t)gr.kfvs.back()].W; };
     auto group_s16 = [&](const Group &gr) { bool ok = true; for (int j : gr.kfvs) ok = ok && ctx->kfv[(size_t)j].Smax <= 32767; return ok; };
+    auto group_nk_min = [&](const Group &gr) { return (int)(ctx->kfv[(size_t)gr.kfvs.front()].W - k + 1); };
     auto group_s8 = [&](const Group &gr) {
-        return group_one_size(gr) && stream8_applies(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr));
+        if (group_one_size(gr)) return stream8_applies(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr));
+        return stream8_derive_applies(k, group_nk_min(gr), (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr));
     };
     bool use_stream = (k >= 5 && k <= 6) || (k == 7 && s8_all);   // k = 7: only the 8-bit kernel (S tables in global memory) beats the bit-sliced one
     for (const Group &gr : groups)
@@ -1339,7 +1354,9 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             for (int j : gr.kfvs) { if (ctx->kfv[(size_t)j].W != prev) n_sizes++; prev = ctx->kfv[(size_t)j].W; }
             bool s16 = true;
             for (int j : gr.kfvs) s16 = s16 && ctx->kfv[(size_t)j].Smax <= 32767;
-            const int nw = stream_slots_per_cu(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), n_sizes, s16, group_nmax(gr));
+            int n_longer = 0;                  // KFVs whose window is longer than the launch's shortest
+            for (int j : gr.kfvs) n_longer += ctx->kfv[(size_t)j].W != ctx->kfv[(size_t)gr.kfvs.front()].W ? 1 : 0;
+            const int nw = stream_slots_per_cu(k, (int)(gr.W - k + 1), group_nk_min(gr), n_longer, (int)gr.kfvs.size(), n_sizes, s16, group_nmax(gr));
             if (nw < 1) use_stream = false;
             stream_nw = std::min(stream_nw, nw);
         }

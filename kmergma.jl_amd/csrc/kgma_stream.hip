@@ -520,9 +520,11 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
 // ------------------------------------------------------------------------------------------
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
-template <int K, bool S16, int NKFV>
+template <int K, bool S16, int NKFV, int ND = 0>
 __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 : 4))) void stream8_kernel(ScanArgs a, GroupParams gp)
 {
+    constexpr bool DERIVE = ND > 0;                                   // the LAST ND KFVs of the launch have a window one k-mer longer
+    static_assert(!DERIVE || (NKFV >= 2 && NKFV <= 4 && ND < NKFV && S16), "derived windows: 2-4 KFVs with int16 S tables");
     // k = 7: a wave's table is 16 KiB, so the LDS holds 10 of them and nothing else; the S tables stay in global memory,
     // interleaved per k-mer ([k-mer][NKFV] int16: ONE gather per k-mer serves every KFV of the launch; 32-256 KiB, L2-resident)
     constexpr bool SGLOBAL = K >= 7;
@@ -575,6 +577,15 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
 #pragma unroll
     for (int j = 0; j < NKFV; j++) { h_carry[j] = 0; h_TE[j] = 0; }
     uint32_t inrun_mask = 0, att_mask = 0, dist_mask = 0;
+    // DERIVE: the last ND KFVs have a window ONE k-mer longer than the table's.  The window of n + 1 k-mers that
+    // starts where lane p's pre-transition window starts is that window plus its entering k-mer y = kp, so
+    //     D(n+1) = D(n) + N (N (2 c[y] + 1) - 2 S[y])        (c[y]: this lane's exact count before its own transition)
+    // -- the count and the S value the step has anyway.  In E units: E' = E_before + (N c[y] - S[y]) - K0, K0 fixed by
+    // the first such window (whose D becomes the stream's D0 for that KFV).  Such a KFV's window index is q - 1.
+    constexpr uint32_t dmask = DERIVE ? ((1u << NKFV) - 1u) & ~((1u << (NKFV - ND)) - 1u) : 0u;
+    int32_t h_K0[NKFV];
+#pragma unroll
+    for (int j = 0; j < NKFV; j++) h_K0[j] = 0;
 #pragma unroll
     for (int j = 0; j < NKFV; j++)
         if (j < n_kfv && a.dist[j] != nullptr) dist_mask |= 1u << j;
@@ -587,7 +598,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
     const int nk = gp.nk;
     // the stream reads the 2-bit interleaved genome (16 bases per dword): its first base is bit 0 of gi[0]
     const uint32_t *gi = a.inter + 2 * td.word_base;
-    const int n_pos = n_valid + nk - 1;
+    const int n_pos = n_valid + nk - 1 + (DERIVE ? 1 : 0);        // (a derived window ends one position later)
     const int n_blocks = (n_pos + 63) >> 6;
 
     // k-mer at position p = 64 b + lane: bits 2 (p & 15) ... of the dword pair starting at dword p >> 4.
@@ -620,6 +631,27 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
     uint32_t one = 1u;
     asm volatile("" : "+v"(one));
 
+    // the stream's first window of KFV j has distance D0: thresholds in E units
+    auto set_first_window = [&](const int j, int32_t *st, const int64_t D0) {
+        const int64_t twoN = 2 * (int64_t)gpp->N[j];
+        st[ST_D0LO] = (int32_t)(uint32_t)D0;
+        st[ST_D0HI] = (int32_t)(uint32_t)((uint64_t)D0 >> 32);
+        // E_q < TE  <=>  D0 + 2N E_q < T; windows with TE <= E_q < TE + natt are at threshold
+        const int64_t Tj = gpp->T[j], Thj = gpp->T_hi[j];
+        const int64_t num = Tj - D0;
+        int64_t TE64 = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
+        const int64_t numh = Thj - D0;
+        const int64_t TH64 = numh >= 0 ? numh / twoN : -((-numh + twoN - 1) / twoN);
+        int64_t na = Thj >= Tj ? TH64 - TE64 + 1 : 0;
+        if (na < 0) na = 0;
+        if (na > 0x3FFFFFFF) na = 0x3FFFFFFF;
+        if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; na = 0; }
+        if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; na = 0; }
+        h_TE[j] = uni((int32_t)TE64);
+        st[ST_NATT] = (int32_t)na;
+        att_mask = (att_mask & ~(1u << j)) | (uni((int32_t)na) != 0 ? 1u << j : 0u);
+    };
+
     auto step = [&](const int b, auto generic_tag) {
         constexpr bool GENERIC = decltype(generic_tag)::value;
         const int p = (b << 6) + lane;
@@ -632,10 +664,21 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
         bool haveL = true;
         if constexpr (GENERIC) { haveL = p >= nk; ks = haveL ? ks : kp; }
         const bool differ = kp != ks;                                 // GenomeMiner.jl:66: nothing happens if left == right
-        const bool actE = differ || !haveL, actL = differ && haveL;
+        bool actE = differ || !haveL, actL = differ && haveL;
         // lane masks as scalar values (v_cmp straight into a scalar pair; no ballot of a combined predicate)
         uint64_t AE = __builtin_amdgcn_uicmp(kp, ks, 33 /* ne */), AL = AE;
         if constexpr (GENERIC) { AE = __ballot(actE); AL = __ballot(actL); }
+        if constexpr (DERIVE) {
+            // A derived window needs the exact count of EVERY lane's entering k-mer, also of a lane without a transition
+            // (left == right), whose count changes when other lanes touch that k-mer.  The counts are exact for every
+            // k-mer that two table operations of the step meet on -- so in a step that has transitions at all, the
+            // lanes without one add and subtract their k-mer too (net zero; the subtract meets the add and sends the
+            // lane through a correction round).  Inside a homopolymer / repeat run no lane has a transition: nothing to do.
+            if (AE != 0 && AE != ~(uint64_t)0) {
+                actE = true; actL = haveL;
+                AE = ~(uint64_t)0; AL = GENERIC ? __ballot(haveL) : ~(uint64_t)0;
+            }
+        }
 
         // ---- every LDS operation of the step back to back (the S lookups first: LDS operations of a wave
         //      complete in order, so the wait for the count operations below covers them) -----------------
@@ -742,10 +785,11 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
         const int32_t dd = cS - cP - (differ ? 1 : 0);
         // ---- per KFV (all of this launch's KFVs have the same window: same k-mers, same counts) ----------------
         // Phase 1: e of every KFV (and, in warm-up steps, the first-window D)
-        int32_t sc[NKFV];
+        int32_t sc[NKFV], ev[DERIVE ? NKFV : 1];
 #pragma unroll
         for (int j = 0; j < NKFV; j++) {
             sc[j] = 0;
+            if constexpr (DERIVE) ev[j] = 0;
             if (NKFV == 8 && j >= n_kfv) continue;                    // (smaller variants are launched full)
             int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
             const int32_t Nj = gp.N[j];
@@ -754,6 +798,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
             int32_t e = Sl[j] - Sr[j] - __mul24(Nj, dd);
             if constexpr (GENERIC) e = actL ? e : 0;
             sc[j] = e;
+            if constexpr (DERIVE) ev[j] = e;
 
             if constexpr (GENERIC) {
                 if ((b << 6) < nk) {                                  // warm-up steps: first-window D
@@ -769,22 +814,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
                     if (nk - 1 < (b << 6) + 64) {                     // last warm-up position is in this step
                         const int64_t D0 = gpp->sumS2[j] - twoN * sumS + (int64_t)Nj * Nj * ((int64_t)nk + 2 * (int64_t)pairs);
                         if (lane == 0) a.D0out[(size_t)(gpp->kfv_id[j] - 1) * a.n_tiles + tile] = D0;
-                        st[ST_D0LO] = (int32_t)(uint32_t)D0;
-                        st[ST_D0HI] = (int32_t)(uint32_t)((uint64_t)D0 >> 32);
-                        // E_q < TE  <=>  D0 + 2N E_q < T; windows with TE <= E_q < TE + natt are at threshold
-                        const int64_t Tj = gpp->T[j], Thj = gpp->T_hi[j];
-                        const int64_t num = Tj - D0;
-                        int64_t TE64 = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
-                        const int64_t numh = Thj - D0;
-                        const int64_t TH64 = numh >= 0 ? numh / twoN : -((-numh + twoN - 1) / twoN);
-                        int64_t na = Thj >= Tj ? TH64 - TE64 + 1 : 0;
-                        if (na < 0) na = 0;
-                        if (na > 0x3FFFFFFF) na = 0x3FFFFFFF;
-                        if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; na = 0; }
-                        if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; na = 0; }
-                        h_TE[j] = uni((int32_t)TE64);
-                        st[ST_NATT] = (int32_t)na;
-                        if (uni((int32_t)na) != 0) att_mask |= 1u << j;
+                        set_first_window(j, st, D0);
                     }
                 }
             }
@@ -802,9 +832,12 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
 #undef KGMA_SCAN_STAGE
         // Phase 3: thresholds; one combined test decides whether any KFV has a dip in this step
         const int q = p - nk + 1;                                     // window start (local) this transition leads to
-        bool tested = true;
-        uint64_t TESTED = ~(uint64_t)0;
-        if constexpr (GENERIC) { tested = q >= first_test && q < n_valid; TESTED = __ballot(tested); }
+        bool tested = true, tested_d = true;                           // (tested_d: KFVs with a derived window, index q - 1)
+        uint64_t TESTED = ~(uint64_t)0, TESTED_D = ~(uint64_t)0;
+        if constexpr (GENERIC) {
+            tested = q >= first_test && q < n_valid; TESTED = __ballot(tested);
+            if constexpr (DERIVE) { tested_d = q - 1 >= first_test && q - 1 < n_valid; TESTED_D = __ballot(tested_d); }
+        }
         int32_t E[NKFV];
         uint64_t Um[NKFV];
         uint64_t anyU = 0;
@@ -814,17 +847,37 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
             if (NKFV == 8 && j >= n_kfv) continue;
             E[j] = sc[j] + h_carry[j];
             h_carry[j] = __builtin_amdgcn_readlane(E[j], 63);
-            Um[j] = __builtin_amdgcn_sicmp(E[j], h_TE[j], 40 /* slt */) & TESTED;
+            if (DERIVE && ((dmask >> j) & 1u)) {
+                // E of this lane's pre-transition window, plus the entering k-mer's term
+                const int32_t X = E[j] - ev[j] + (__mul24(gp.N[j], cP) - Sr[j]);
+                if constexpr (GENERIC) {
+                    if (b == (nk >> 6)) {                             // position nk is in this step: the KFV's first window
+                        int32_t *st = sState + j * ST_WORDS;
+                        const int32_t K0 = __builtin_amdgcn_readlane(X, nk & 63);
+                        const int64_t Nj = gpp->N[j];
+                        const int64_t D0b = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
+                        const int64_t D0 = D0b + 2 * Nj * (int64_t)K0 + Nj * Nj;
+                        if (lane == 0) a.D0out[(size_t)(gpp->kfv_id[j] - 1) * a.n_tiles + tile] = D0;
+                        set_first_window(j, st, D0);
+                        h_K0[j] = K0;
+                    }
+                }
+                E[j] = X - h_K0[j];
+                Um[j] = __builtin_amdgcn_sicmp(E[j], h_TE[j], 40 /* slt */) & TESTED_D;
+            } else {
+                Um[j] = __builtin_amdgcn_sicmp(E[j], h_TE[j], 40 /* slt */) & TESTED;
+            }
             anyU |= Um[j];
         }
         if (dist_mask != 0) {
 #pragma unroll
             for (int j = 0; j < NKFV; j++) {
-                if (!((dist_mask >> j) & 1u) || !tested) continue;
+                const int dj = DERIVE ? (int)((dmask >> j) & 1u) : 0;
+                if (!((dist_mask >> j) & 1u) || !(dj ? tested_d : tested)) continue;
                 const int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
                 const int64_t twoN = 2 * (int64_t)gp.N[j];
                 const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
-                a.dist[j][td.dist_base + q] = (double)(D0 + twoN * (int64_t)E[j]) / gpp->inv_scale[j];
+                a.dist[j][td.dist_base + q - dj] = (double)(D0 + twoN * (int64_t)E[j]) / gpp->inv_scale[j];
             }
         }
         if (anyU == 0 && inrun_mask == 0 && att_mask == 0) return;    // fast path: nothing near any threshold
@@ -837,10 +890,11 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
             const int32_t TE = h_TE[j];
             const uint64_t U = Um[j];
             const bool under = (U >> lane) & 1u;
+            const int dj = DERIVE ? (int)((dmask >> j) & 1u) : 0;
             bool att = false;
             uint64_t A = 0;
             if ((att_mask >> j) & 1u) {                                // (only when the threshold sits on the distance lattice)
-                att = tested && !under && Ej - TE < uni(st[ST_NATT]);
+                att = (dj ? tested_d : tested) && !under && Ej - TE < uni(st[ST_NATT]);
                 A = __ballot(att);
             }
             int in_run = (int)((inrun_mask >> j) & 1u);
@@ -849,12 +903,12 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
 
             // ---- a dip touches this step: walk its runs (wave-uniform) ----------------------------
             const int kid = gpp->kfv_id[j];
-            const int q0 = (b << 6) - nk + 1;                         // window of lane 0
+            const int q0 = (b << 6) - nk + 1 - dj;                    // window of lane 0
             if (att) {
                 DevRecord rec;
                 rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8);
-                rec.start = q; rec.end = q; rec.minE = E;
-                rec.argf = rec.argl = q; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
+                rec.start = q - dj; rec.end = q - dj; rec.minE = E;
+                rec.argf = rec.argl = q - dj; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
                 emit_global(a, rec);
                 atomicAdd(a.n_att, 1ull);
             }
@@ -902,7 +956,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
         }
     };
 
-    int b_warm = (nk + 63) >> 6;
+    int b_warm = (nk + (DERIVE ? 64 : 63)) >> 6;                      // (DERIVE: position nk, the first derived window, is in a generic step)
     if (b_warm > n_blocks) b_warm = n_blocks;
     int b_tail = n_valid + nk - 65;                                   // steps b <= b_tail/64 have all windows < n_valid
     b_tail = b_tail >= 0 ? (b_tail >> 6) + 1 : 0;
@@ -1005,6 +1059,31 @@ static size_t stream8_lds(int k, bool s16, int nkfv, int nw)
     return tabs + (size_t)nw * (NB + (nkfv > 1 ? (size_t)nkfv * ST_WORDS * 4 : 0));
 }
 
+static bool stream8_derive_env_on()                  // KGMA_STREAM8_DERIVE=0 (testing): one window size per launch only
+{
+    const char *e = getenv("KGMA_STREAM8_DERIVE");
+    return !(e && atoi(e) == 0);
+}
+
+// a launch of 2-4 KFVs whose windows are n and n + 1 k-mers: the table is kept for n, the longer windows are derived
+bool stream8_derive_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool s16)
+{
+    return stream8_derive_env_on() && nk_max == nk_min + 1 && n_kfv >= 2 && n_kfv <= 4 && s16 && stream8_applies(k, nk_max, n_kfv, n_ref, s16);
+}
+
+template <int K>
+static const void *stream8_fn_derive(int nkfv, int nd)
+{
+    switch (nkfv * 4 + nd) {
+    case 2 * 4 + 1: return reinterpret_cast<const void *>(&stream8_kernel<K, true, 2, 1>);
+    case 3 * 4 + 1: return reinterpret_cast<const void *>(&stream8_kernel<K, true, 3, 1>);
+    case 3 * 4 + 2: return reinterpret_cast<const void *>(&stream8_kernel<K, true, 3, 2>);
+    case 4 * 4 + 1: return reinterpret_cast<const void *>(&stream8_kernel<K, true, 4, 1>);
+    case 4 * 4 + 2: return reinterpret_cast<const void *>(&stream8_kernel<K, true, 4, 2>);
+    default: return reinterpret_cast<const void *>(&stream8_kernel<K, true, 4, 3>);
+    }
+}
+
 template <int K, bool S16>
 static const void *stream8_fn_k(int nkfv)
 {
@@ -1017,8 +1096,9 @@ static const void *stream8_fn_k(int nkfv)
     }
 }
 
-static const void *stream8_fn_of(int k, bool s16, int nkfv)
+static const void *stream8_fn_of(int k, bool s16, int nkfv, int nd = 0)       // nd: KFVs with a derived window
 {
+    if (nd > 0) return k == 5 ? stream8_fn_derive<5>(nkfv, nd) : k == 7 ? stream8_fn_derive<7>(nkfv, nd) : stream8_fn_derive<6>(nkfv, nd);
     if (k == 5) return s16 ? stream8_fn_k<5, true>(nkfv) : stream8_fn_k<5, false>(nkfv);
     if (k == 7) return stream8_fn_k<7, true>(nkfv);
     return s16 ? stream8_fn_k<6, true>(nkfv) : stream8_fn_k<6, false>(nkfv);
@@ -1026,20 +1106,20 @@ static const void *stream8_fn_of(int k, bool s16, int nkfv)
 
 // waves per workgroup and workgroups per CU that keep the most streams resident (asked of the runtime, which knows
 // the LDS allocation granule and the kernel's registers); one KFV: two 16-wave workgroups = 32 waves per CU
-void stream8_geometry(int k, bool s16, int nkfv, int *nw_out, int *blocks_out)
+void stream8_geometry(int k, bool s16, int nkfv, int nd, int *nw_out, int *blocks_out)
 {
-    static int cache[3][2][9][2];
+    static int cache[3][2][9][4][2];
     static bool init = false;
     if (!init) { memset(cache, 0, sizeof cache); init = true; }
-    int *c = cache[k - 5][s16 ? 1 : 0][nkfv];
+    int *c = cache[k - 5][s16 ? 1 : 0][nkfv][nd];
     if (c[0] == 0) {
         int best_nw = 0, best_blocks = 0;
         for (int nw = 16; nw >= 4; nw--) {
             const size_t lds = stream8_lds(k, s16, nkfv, nw);
             if (lds > ((size_t)160 << 10)) continue;
             int blocks = 0;
-            if (hipFuncSetAttribute(stream8_fn_of(k, s16, nkfv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, stream8_fn_of(k, s16, nkfv), 64 * nw, lds) != hipSuccess) continue;
+            if (hipFuncSetAttribute(stream8_fn_of(k, s16, nkfv, nd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, stream8_fn_of(k, s16, nkfv, nd), 64 * nw, lds) != hipSuccess) continue;
             if (blocks * nw > 32) blocks = 32 / nw;
             if (blocks * nw > best_blocks * best_nw) { best_blocks = blocks; best_nw = nw; }
         }
@@ -1061,12 +1141,36 @@ static void stream8_launch_ks(int nkfv, unsigned grid, unsigned threads, size_t 
     }
 }
 
-static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+template <int K>
+static void stream8_launch_derive(int nkfv, int nd, unsigned grid, unsigned threads, size_t lds, hipStream_t st, const ScanArgs &a, const GroupParams &gp)
 {
+    switch (nkfv * 4 + nd) {
+    case 2 * 4 + 1: hipLaunchKernelGGL((stream8_kernel<K, true, 2, 1>), dim3(grid), dim3(threads), lds, st, a, gp); break;
+    case 3 * 4 + 1: hipLaunchKernelGGL((stream8_kernel<K, true, 3, 1>), dim3(grid), dim3(threads), lds, st, a, gp); break;
+    case 3 * 4 + 2: hipLaunchKernelGGL((stream8_kernel<K, true, 3, 2>), dim3(grid), dim3(threads), lds, st, a, gp); break;
+    case 4 * 4 + 1: hipLaunchKernelGGL((stream8_kernel<K, true, 4, 1>), dim3(grid), dim3(threads), lds, st, a, gp); break;
+    case 4 * 4 + 2: hipLaunchKernelGGL((stream8_kernel<K, true, 4, 2>), dim3(grid), dim3(threads), lds, st, a, gp); break;
+    default: hipLaunchKernelGGL((stream8_kernel<K, true, 4, 3>), dim3(grid), dim3(threads), lds, st, a, gp); break;
+    }
+}
+
+// KFVs of a launch whose window is the longer of its two sizes (the launch's KFVs are sorted by size)
+static int derived_kfvs(const GroupParams &gp)
+{
+    int nd = 0;
+    for (int j = 0; j < gp.n_kfv; j++) nd += gp.nk_of[j] != gp.nk_min ? 1 : 0;
+    return nd;
+}
+
+static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp_in, hipStream_t st, bool derive_launch)
+{
+    GroupParams gp = gp_in;
+    const int derive = derive_launch ? derived_kfvs(gp) : 0;
+    if (derive) gp.nk = gp.nk_min;                  // the count table is kept for the SHORTER window
     const bool s16 = gp.s_fits_i16 != 0;
     const int nkfv = stream8_variant(gp.n_kfv);
     int nw = 16, blocks = 1;
-    stream8_geometry(gp.k, s16, nkfv, &nw, &blocks);
+    stream8_geometry(gp.k, s16, nkfv, derive, &nw, &blocks);
     // all launches of a scan share one stream table, sized for the launch that keeps the fewest streams resident:
     // use workgroups that fill exactly that many wave slots per CU, so that every CU gets the same number of streams
     if (gp.stream_slots > 0 && gp.stream_slots < nw * blocks) {
@@ -1076,20 +1180,26 @@ static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp, hipSt
     }
     const size_t lds = stream8_lds(gp.k, s16, nkfv, nw);
     const unsigned grid = (unsigned)((a.n_tiles + nw - 1) / nw);
-    hipError_t e = hipFuncSetAttribute(stream8_fn_of(gp.k, s16, nkfv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(stream8_fn_of(gp.k, s16, nkfv, derive), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (gp.k == 5) { if (s16) stream8_launch_ks<5, true>(nkfv, grid, 64u * nw, lds, st, a, gp); else stream8_launch_ks<5, false>(nkfv, grid, 64u * nw, lds, st, a, gp); }
+    if (derive) {
+        if (gp.k == 5) stream8_launch_derive<5>(nkfv, derive, grid, 64u * nw, lds, st, a, gp);
+        else if (gp.k == 7) stream8_launch_derive<7>(nkfv, derive, grid, 64u * nw, lds, st, a, gp);
+        else stream8_launch_derive<6>(nkfv, derive, grid, 64u * nw, lds, st, a, gp);
+    }
+    else if (gp.k == 5) { if (s16) stream8_launch_ks<5, true>(nkfv, grid, 64u * nw, lds, st, a, gp); else stream8_launch_ks<5, false>(nkfv, grid, 64u * nw, lds, st, a, gp); }
     else if (gp.k == 7) stream8_launch_ks<7, true>(nkfv, grid, 64u * nw, lds, st, a, gp);
     else           { if (s16) stream8_launch_ks<6, true>(nkfv, grid, 64u * nw, lds, st, a, gp); else stream8_launch_ks<6, false>(nkfv, grid, 64u * nw, lds, st, a, gp); }
     return hipGetLastError();
 }
 
 // streams resident per CU (what the host sizes the streams for); n_ref = largest reference count of the launch's KFVs
-int stream_slots_per_cu(int k, int nk, int n_kfv, int n_sizes, bool s16, int64_t n_ref)
+int stream_slots_per_cu(int k, int nk, int nk_min, int n_longer, int n_kfv, int n_sizes, bool s16, int64_t n_ref)
 {
-    if (n_sizes == 1 && stream8_applies(k, nk, n_kfv, n_ref, s16)) {
+    const bool derive = n_sizes == 2 && stream8_derive_applies(k, nk_min, nk, n_kfv, n_ref, s16);
+    if ((n_sizes == 1 && stream8_applies(k, nk, n_kfv, n_ref, s16)) || derive) {
         int nw = 16, blocks = 1;
-        stream8_geometry(k, s16, stream8_variant(n_kfv), &nw, &blocks);
+        stream8_geometry(k, s16, stream8_variant(n_kfv), derive ? n_longer : 0, &nw, &blocks);
         return nw * blocks;
     }
     return stream_waves(k, nk, n_kfv, n_sizes);
@@ -1100,7 +1210,8 @@ hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t s
     {
         int64_t nmax = 0;
         for (int j = 0; j < gp.n_kfv; j++) nmax = gp.N[j] > nmax ? gp.N[j] : nmax;
-        if (gp.n_sizes == 1 && stream8_applies(gp.k, gp.nk, gp.n_kfv, nmax, gp.s_fits_i16 != 0)) return launch_stream8(a, gp, st);
+        if (gp.n_sizes == 1 && stream8_applies(gp.k, gp.nk, gp.n_kfv, nmax, gp.s_fits_i16 != 0)) return launch_stream8(a, gp, st, false);
+        if (gp.n_sizes == 2 && stream8_derive_applies(gp.k, gp.nk_min, gp.nk, gp.n_kfv, nmax, gp.s_fits_i16 != 0)) return launch_stream8(a, gp, st, true);
     }
     switch (gp.k) {
     case 2: return launch_stream_k<2>(a, gp, st);

@@ -803,3 +803,59 @@ def test_stream8_heavy_kmers(ctx, k, gene_len):
     n = ws - k + 1
     name = ctx.kernel_name()
     assert name.startswith("stream8_kernel") == (n <= 383), (name, n)
+
+
+@pytest.mark.parametrize("k,lens", [
+    (6, [261, 262]),                       # 256 k-mers in the shorter window: the first derived window is lane 0 of a step
+    (6, [288, 288, 289]), (6, [288, 289, 289]),
+    (6, [288, 288, 288, 289]), (6, [288, 288, 289, 289]), (6, [288, 289, 289, 289]),
+    (6, [387, 388]),                       # 382 / 383 k-mers: the 8-bit kernel's largest windows
+    (5, [150, 150, 151]),
+    (7, [288, 288, 288, 288, 289, 289, 289, 290]),   # the config-5 shape: launches {288 x 4} and {289 x 3 + 290 derived}
+    (6, [100, 101, 102, 103]),             # {100, 101 derived} and {102, 103 derived}
+])
+def test_stream8_derived_windows(ctx, k, lens, monkeypatch):
+    """Cluster-mode launches of the 8-bit stream kernel that hold windows of n AND n + 1 k-mers: the count table is kept
+    for n, the longer windows' distances follow from the entering k-mer's count and S value.  Every distance of every
+    KFV against the integer oracle (homopolymer / repeat / N stretches included), and the same hits, dips and distances
+    as with one window size per launch (KGMA_STREAM8_DERIVE=0)."""
+    from kmergma_amd.fasta import Record
+    from tests.helpers import mutate
+    rng = np.random.default_rng(77 * k + sum(lens))
+    KFVs, ws, S, N = [], [], [], []
+    genes = []
+    for i, L in enumerate(lens):
+        base = random_dna(rng, L)
+        genes.append(base)
+        refs = [Record(f"g{i}_{u}", mutate(rng, base, 0.03)) for u in range(4 + i)]
+        RV, w, cons, (s, n) = refprep.gen_ref_ws_cons(refs, k, return_int=True)
+        assert w == L
+        KFVs.append(RV); ws.append(w); S.append(s); N.append(n)
+    maxws = max(ws)
+    g1 = bytearray(_low_complexity_genome(rng, 150_000, maxws))
+    for i, gene in enumerate(genes):                                  # each gene planted a few times (true dips)
+        for pos in (5000 + 9000 * i, 90_000 + 7000 * i):
+            g1[pos:pos + len(gene)] = mutate(rng, gene, 0.05)[:len(gene)]
+    g2 = b"A" * 3000 + random_dna(rng, 3000) + b"AC" * 2000 + random_dna(rng, 40_000) + b"N" * 1000
+    contigs = [bytes(g1), g2, random_dna(rng, maxws + k - 2), random_dna(rng, maxws + k - 1), random_dna(rng, maxws + k), genes[-1] + random_dna(rng, 700)]
+    thr = [float(np.median([orc.kmer_dist_kfv(random_dna(rng, w), RV, k) for _ in range(10)])) * 0.8 for RV, w in zip(KFVs, ws)]
+    T = [orc.int_threshold(t, k, n) for t, n in zip(thr, N)]
+    ohi, oD = orc.omn_scan_int(contigs, S, N, k, ws, T, 100, 55, return_D=True)
+    assert len(ohi) > 0
+    res = {}
+    for derive in ("1", "0"):
+        monkeypatch.setenv("KGMA_STREAM8_DERIVE", derive)
+        ctx.set_refs(k, KFVs, ws, thr, N)
+        gen = ctx.genome_from_host(contigs)
+        ctx.scan(gen, _lib.MODE_OMN, 100, 55, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
+        assert ctx.kernel_name().startswith("stream8_kernel")
+        hits, dips, st = ctx.hits(), ctx.dips(), ctx.stats()
+        dists = [ctx.dists(j + 1) for j in range(len(ws))]
+        gen.free()
+        assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi]
+        assert [h["D"] for h in hits] == [h["D"] for h in ohi]
+        for j in range(len(ws)):
+            assert np.array_equal(dists[j], oD[j] / (2.0 * k * N[j] ** 2)), (derive, j)
+        res[derive] = (hits, dips, st["n_launches"])
+    assert res["1"][0] == res["0"][0] and res["1"][1] == res["0"][1]
+    assert res["1"][2] < res["0"][2]                                   # fewer launches with derived windows
