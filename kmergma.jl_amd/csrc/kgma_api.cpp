@@ -1347,6 +1347,8 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         if (!strcmp(kv, "stream")) use_stream = k <= KGMA_STREAM_MAX_K;
     }
     int stream_nw = 1 << 20;         // streams resident per CU (smallest over the launch groups)
+    std::vector<int> launch_slots;
+    std::vector<double> launch_weight;
     if (use_stream)
         for (const Group &gr : groups) {
             int n_sizes = 0;
@@ -1359,7 +1361,36 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             const int nw = stream_slots_per_cu(k, (int)(gr.W - k + 1), group_nk_min(gr), n_longer, (int)gr.kfvs.size(), n_sizes, s16, group_nmax(gr));
             if (nw < 1) use_stream = false;
             stream_nw = std::min(stream_nw, nw);
+            launch_slots.push_back(nw);
+            launch_weight.push_back(4.0 + (double)gr.kfvs.size());      // (a launch costs about 55 + 13 per KFV, in arbitrary units)
         }
+    // Launches that keep different numbers of streams resident (one KFV: 32 per CU; four: 22): all launches share one
+    // stream table.  Its streams per CU, S, are chosen so that every launch runs at its OWN residency s in
+    // ceil(S / s) nearly full rounds (s = 22 and 32: S = 64 is 3 rounds of 22 and 2 of 32), weighing the launches by
+    // their cost; with one residency (or nothing to gain) S = s and there is one round.
+    bool natural_slots = false;
+    if (use_stream && !getenv("KGMA_STREAM_MINSLOTS")) {
+        int s_max = 0;
+        for (int sl : launch_slots) s_max = std::max(s_max, sl);
+        if (s_max > stream_nw) {
+            auto cost = [&](int S) {
+                double c = 0;
+                for (size_t i = 0; i < launch_slots.size(); i++) {
+                    const int sl = launch_slots[i];
+                    c += launch_weight[i] * (double)(((S + sl - 1) / sl) * sl) / (double)S;
+                }
+                return c;
+            };
+            // (cutting every launch down to the smallest residency costs the others s / s_min; 0.9: fewer waves run a little faster each)
+            double best = 0;
+            for (size_t i = 0; i < launch_slots.size(); i++)
+                best += launch_weight[i] * std::max(1.0, 0.9 * (double)launch_slots[i] / (double)stream_nw);
+            int best_S = 0;
+            for (int S = s_max; S <= 4 * s_max; S++)
+                if (cost(S) < best * 0.99) { best = cost(S); best_S = S; }
+            if (best_S > 0) { natural_slots = true; stream_nw = best_S; }
+        }
+    }
     const int64_t nc = g->n_contigs;
     const bool want_dists = (flags & KGMA_F_RETURN_DISTS) != 0;
     const int geom_version = use_stream ? 2 + 16 * ctx->reserved_cus + 16 * 1024 * ctx->n_cus + (stream_nw << 24) : 1;
@@ -1572,7 +1603,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             gp.nk = (int32_t)(gr.W - k + 1);                                  // largest window of the launch
             gp.nk_min = (int32_t)(ctx->kfv[(size_t)gr.kfvs.front()].W - k + 1);
             gp.nblocks = scan_nblocks(gp.nk);
-            gp.stream_slots = use_stream ? stream_nw : 0;
+            gp.stream_slots = use_stream && !natural_slots ? stream_nw : 0;
             if (const char *ds = getenv("KGMA_DEBUG_SKIP")) gp.debug_skip = atoi(ds);   // timing experiments only
             for (size_t u = 0; u < gr.kfvs.size(); u++) {
                 const int j = gr.kfvs[u];
