@@ -318,6 +318,10 @@ std::vector<Group> make_groups(const kgma_ctx *ctx, int mode, bool s8 = false)
 {
     const char *de = getenv("KGMA_STREAM8_DERIVE");
     const bool derive_ok = s8 && !(de && atoi(de) == 0);
+    // one window size: up to 8 KFVs per launch at k = 7; at k <= 6 two launches of up to 4 beat one of 5-8 (the 5-8 KFV
+    // variant keeps 16 waves per CU instead of 22-24 and spills; measured, 400 Mb, 8 KFVs: 3.17 ms against 2.56 ms)
+    int s8_max_same = ctx->k >= 7 ? KGMA_MAX_GROUP : 4;
+    if (const char *mg = getenv("KGMA_S8_MAXGROUP")) s8_max_same = std::max(1, std::min(KGMA_MAX_GROUP, atoi(mg)));   // experiments
     std::vector<Group> gs;
     if (mode == KGMA_MODE_SINGLE) {
         gs.push_back(Group{ctx->kfv[0].W, {0}});
@@ -339,7 +343,7 @@ std::vector<Group> make_groups(const kgma_ctx *ctx, int mode, bool s8 = false)
             if (s8) {
                 bool s16 = ctx->kfv[(size_t)j].Smax <= 32767;
                 for (int u : g.kfvs) s16 = s16 && ctx->kfv[(size_t)u].Smax <= 32767;
-                fits = (W == wmin && last == wmin && (int)g.kfvs.size() < KGMA_MAX_GROUP) ||
+                fits = (W == wmin && last == wmin && (int)g.kfvs.size() < s8_max_same) ||
                        (derive_ok && s16 && W <= wmin + 1 && (int)g.kfvs.size() < 4);
             } else {
                 fits = (int)g.kfvs.size() < KGMA_MAX_GROUP && W - wmin <= KGMA_MAX_DW && (W == last || distinct < KGMA_MAX_SIZES);
@@ -1640,10 +1644,12 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             a.Sinter = nullptr;
             if (use_stream && group_s8(gr) && k >= 7) {
                 // the launch's S tables interleaved per k-mer, int16, in the interleaved-code index order; built once per group
-                auto it = ctx->sinter.find(gr.kfvs);
+                const int nv0 = stream8_variant((int)gr.kfvs.size());
+                const int nv = nv0 == 3 ? 4 : nv0;                     // row width in int16 slots (the kernel variant's)
+                std::vector<int> key = gr.kfvs;
+                key.push_back(-nv);
+                auto it = ctx->sinter.find(key);
                 if (it == ctx->sinter.end()) {
-                    const int nv0 = stream8_variant((int)gr.kfvs.size());
-                    const int nv = nv0 == 3 ? 4 : nv0;                 // row width in int16 slots
                     const int64_t NBk = (int64_t)1 << (2 * k);
                     std::vector<int16_t> tab((size_t)NBk * (size_t)nv, 0);
                     for (size_t u = 0; u < gr.kfvs.size(); u++)
@@ -1652,7 +1658,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
                     int16_t *d = nullptr;
                     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d), tab.size() * sizeof(int16_t)));
                     HIP_TRY(ctx, hipMemcpy(d, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice));
-                    it = ctx->sinter.emplace(gr.kfvs, d).first;
+                    it = ctx->sinter.emplace(key, d).first;
                 }
                 a.Sinter = it->second;
             }

@@ -581,11 +581,9 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
     // starts where lane p's pre-transition window starts is that window plus its entering k-mer y = kp, so
     //     D(n+1) = D(n) + N (N (2 c[y] + 1) - 2 S[y])        (c[y]: this lane's exact count before its own transition)
     // -- the count and the S value the step has anyway.  In E units: E' = E_before + (N c[y] - S[y]) - K0, K0 fixed by
-    // the first such window (whose D becomes the stream's D0 for that KFV).  Such a KFV's window index is q - 1.
-    constexpr uint32_t dmask = DERIVE ? ((1u << NKFV) - 1u) & ~((1u << (NKFV - ND)) - 1u) : 0u;
-    int32_t h_K0[NKFV];
-#pragma unroll
-    for (int j = 0; j < NKFV; j++) h_K0[j] = 0;
+    // the first such window (whose D becomes the stream's D0 for that KFV; K0 is taken off the running prefix carry
+    // once, at that window).  Such a KFV's window index is q - 1.
+    constexpr uint32_t dm1 = DERIVE ? ((1u << NKFV) - 1u) & ~((1u << (NKFV - ND)) - 1u) : 0u;
 #pragma unroll
     for (int j = 0; j < NKFV; j++)
         if (j < n_kfv && a.dist[j] != nullptr) dist_mask |= 1u << j;
@@ -847,9 +845,9 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
             if (NKFV == 8 && j >= n_kfv) continue;
             E[j] = sc[j] + h_carry[j];
             h_carry[j] = __builtin_amdgcn_readlane(E[j], 63);
-            if (DERIVE && ((dmask >> j) & 1u)) {
+            if (DERIVE && ((dm1 >> j) & 1u)) {
                 // E of this lane's pre-transition window, plus the entering k-mer's term
-                const int32_t X = E[j] - ev[j] + (__mul24(gp.N[j], cP) - Sr[j]);
+                int32_t X = E[j] - ev[j] + (__mul24(gp.N[j], cP) - Sr[j]);
                 if constexpr (GENERIC) {
                     if (b == (nk >> 6)) {                             // position nk is in this step: the KFV's first window
                         int32_t *st = sState + j * ST_WORDS;
@@ -859,10 +857,11 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
                         const int64_t D0 = D0b + 2 * Nj * (int64_t)K0 + Nj * Nj;
                         if (lane == 0) a.D0out[(size_t)(gpp->kfv_id[j] - 1) * a.n_tiles + tile] = D0;
                         set_first_window(j, st, D0);
-                        h_K0[j] = K0;
+                        X -= K0;                                      // from here on E is relative to this window
+                        h_carry[j] -= K0;
                     }
                 }
-                E[j] = X - h_K0[j];
+                E[j] = X;
                 Um[j] = __builtin_amdgcn_sicmp(E[j], h_TE[j], 40 /* slt */) & TESTED_D;
             } else {
                 Um[j] = __builtin_amdgcn_sicmp(E[j], h_TE[j], 40 /* slt */) & TESTED;
@@ -872,7 +871,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
         if (dist_mask != 0) {
 #pragma unroll
             for (int j = 0; j < NKFV; j++) {
-                const int dj = DERIVE ? (int)((dmask >> j) & 1u) : 0;
+                const int dj = DERIVE ? (int)((dm1 >> j) & 1u) : 0;
                 if (!((dist_mask >> j) & 1u) || !(dj ? tested_d : tested)) continue;
                 const int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
                 const int64_t twoN = 2 * (int64_t)gp.N[j];
@@ -890,7 +889,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
             const int32_t TE = h_TE[j];
             const uint64_t U = Um[j];
             const bool under = (U >> lane) & 1u;
-            const int dj = DERIVE ? (int)((dmask >> j) & 1u) : 0;
+            const int dj = DERIVE ? (int)((dm1 >> j) & 1u) : 0;
             bool att = false;
             uint64_t A = 0;
             if ((att_mask >> j) & 1u) {                                // (only when the threshold sits on the distance lattice)
@@ -1065,7 +1064,10 @@ static bool stream8_derive_env_on()                  // KGMA_STREAM8_DERIVE=0 (t
     return !(e && atoi(e) == 0);
 }
 
-// a launch of 2-4 KFVs whose windows are n and n + 1 k-mers: the table is kept for n, the longer windows are derived
+// a launch of 2-4 KFVs whose windows are n and n + 1 k-mers: the table is kept for n, the longer windows are derived.
+// (Tried and dropped: windows of n + 2 k-mers from the lane below over a wave shift, and a 5-8 KFV variant that reads
+//  each KFV's extra length from the launch parameters -- at k = 7, 400 Mb, 8 KFVs of 3 sizes: 5.27 ms in one such launch
+//  against 4.86 ms in two launches of four; 3 KFVs of 3 sizes: 3.91 against 3.07 ms.)
 bool stream8_derive_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool s16)
 {
     return stream8_derive_env_on() && nk_max == nk_min + 1 && n_kfv >= 2 && n_kfv <= 4 && s16 && stream8_applies(k, nk_max, n_kfv, n_ref, s16);

@@ -813,6 +813,8 @@ def test_stream8_heavy_kmers(ctx, k, gene_len):
     (5, [150, 150, 151]),
     (7, [288, 288, 288, 288, 289, 289, 289, 290]),   # the config-5 shape: launches {288 x 4} and {289 x 3 + 290 derived}
     (6, [100, 101, 102, 103]),             # {100, 101 derived} and {102, 103 derived}
+    (7, [134, 135, 135, 134]),             # k = 7, 128 k-mers: the first derived window is lane 0 of a step
+    (6, [288, 288, 288, 288, 288, 289]),   # six KFVs at k = 6: {288 x 4}, {288, 289 derived}
 ])
 def test_stream8_derived_windows(ctx, k, lens, monkeypatch):
     """Cluster-mode launches of the 8-bit stream kernel that hold windows of n AND n + 1 k-mers: the count table is kept
