@@ -545,12 +545,16 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
     const int lane = threadIdx.x & 63;
     const int wave = uni((int)(threadIdx.x >> 6));
 
-    // ---- LDS: [S tables: NKFV x (int16 or int32 per k-mer)] then per wave [NB byte counters | cold per-KFV dip state (NKFV > 1)]
-    constexpr size_t tab_words_1 = S16 ? NB / 2 : NB;
+    // ---- LDS: [S tables] then per wave [NB byte counters | cold per-KFV dip state (NKFV > 1)].
+    // S tables: int32 [KFV][k-mer], or int16 -- for several KFVs as ROWS [k-mer][NV slots], so that one read per k-mer
+    // serves every KFV of the launch (2 LDS reads per step instead of 2 per KFV); k = 7 reads the same rows from global memory
+    constexpr bool SROWS = S16 && NKFV >= 2;
+    constexpr int NV = NKFV >= 5 ? 8 : (NKFV >= 3 ? 4 : NKFV);          // int16 slots per row
+    constexpr size_t tab_words = SROWS ? (size_t)NB * NV / 2 : (S16 ? NB / 2 : NB) * (size_t)NKFV;
     constexpr size_t per_wave_words = NB / 4 + (NKFV > 1 ? NKFV * ST_WORDS : 0);
     int32_t *sTab32 = reinterpret_cast<int32_t *>(smem);
     uint16_t *sTab16 = reinterpret_cast<uint16_t *>(smem);          // S >= 0 (sums of counts): read zero-extended
-    uint32_t *C = smem + (SGLOBAL ? 0 : tab_words_1 * NKFV) + (size_t)wave * per_wave_words;
+    uint32_t *C = smem + (SGLOBAL ? 0 : tab_words) + (size_t)wave * per_wave_words;
     int32_t *sState = reinterpret_cast<int32_t *>(C + NB / 4);
     if constexpr (!SGLOBAL) {
 #pragma unroll
@@ -558,7 +562,8 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
             if (j >= n_kfv) continue;
             const int32_t *Sg = a.Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
             for (int i = threadIdx.x; i < NB; i += blockDim.x) {
-                if constexpr (S16) sTab16[(size_t)j * NB + i] = (uint16_t)Sg[i];
+                if constexpr (SROWS) sTab16[(size_t)i * NV + j] = (uint16_t)Sg[i];
+                else if constexpr (S16) sTab16[(size_t)j * NB + i] = (uint16_t)Sg[i];
                 else sTab32[(size_t)j * NB + i] = Sg[i];
             }
         }
@@ -681,20 +686,29 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
         // ---- every LDS operation of the step back to back (the S lookups first: LDS operations of a wave
         //      complete in order, so the wait for the count operations below covers them) -----------------
         int32_t Sr[NKFV], Sl[NKFV];
-        if constexpr (SGLOBAL) {
-            // one gather per k-mer for all KFVs of the launch (issued first: the longest latency of the step)
-            constexpr int NW = NKFV >= 2 ? (NKFV + 1) / 2 : 1;       // dwords per table row (NKFV = 3: a 4-slot row)
+        if constexpr (SGLOBAL || SROWS) {
+            // one read per k-mer for all KFVs of the launch (k = 7: a gather from global memory, issued first: the longest
+            // latency of the step; k <= 6: a row of the LDS table)
+            constexpr int NW = NKFV >= 2 ? NV / 2 : 1;               // dwords per table row (NKFV = 3: a 4-slot row)
             uint32_t vr[NW], vl[NW];
             if constexpr (NKFV == 1) {
                 vr[0] = (uint32_t)(uint16_t)a.Sinter[kp]; vl[0] = (uint32_t)(uint16_t)a.Sinter[ks];
             } else {
                 typedef uint32_t rowv __attribute__((ext_vector_type(NW)));
-                const rowv *rows = reinterpret_cast<const rowv *>(a.Sinter);
-                if constexpr (NW == 1) { vr[0] = reinterpret_cast<const uint32_t *>(a.Sinter)[kp]; vl[0] = reinterpret_cast<const uint32_t *>(a.Sinter)[ks]; }
-                else {
-                    const rowv r = rows[kp], l = rows[ks];
+                auto rows_of = [&](auto base) {
+                    if constexpr (NW == 1) { vr[0] = base[kp]; vl[0] = base[ks]; }
+                    else {
+                        const auto r = base[kp], l = base[ks];
 #pragma unroll
-                    for (int w = 0; w < NW; w++) { vr[w] = r[w]; vl[w] = l[w]; }
+                        for (int w = 0; w < NW; w++) { vr[w] = r[w]; vl[w] = l[w]; }
+                    }
+                };
+                if constexpr (NW == 1) {
+                    if constexpr (SGLOBAL) rows_of(reinterpret_cast<const uint32_t *>(a.Sinter));
+                    else rows_of(reinterpret_cast<const uint32_t *>(smem));
+                } else {
+                    if constexpr (SGLOBAL) rows_of(reinterpret_cast<const rowv *>(a.Sinter));
+                    else rows_of(reinterpret_cast<const rowv *>(smem));
                 }
             }
 #pragma unroll
@@ -1054,7 +1068,8 @@ int stream8_variant(int n_kfv) { return n_kfv <= 4 ? (n_kfv < 1 ? 1 : n_kfv) : 8
 static size_t stream8_lds(int k, bool s16, int nkfv, int nw)
 {
     const size_t NB = (size_t)1 << (2 * k);
-    const size_t tabs = k >= 7 ? 0 : NB * (s16 ? 2 : 4) * (size_t)nkfv;            // k = 7: the S tables stay in global memory
+    const size_t slots = s16 && nkfv >= 2 ? (nkfv >= 5 ? 8 : nkfv >= 3 ? 4 : 2) : (size_t)nkfv;   // int16 tables of several KFVs: rows of 2 / 4 / 8 slots
+    const size_t tabs = k >= 7 ? 0 : NB * (s16 ? 2 : 4) * slots;                  // k = 7: the S tables stay in global memory
     return tabs + (size_t)nw * (NB + (nkfv > 1 ? (size_t)nkfv * ST_WORDS * 4 : 0));
 }
 
