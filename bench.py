@@ -9,7 +9,7 @@ scaling ... on a synthetic 100 Gb genome"): findGenes k=6, one reference cluster
 alpaca IGHV fixture, 84 genes, W=289, thr=30, buff=50, do_align=false) against ONE fixed synthetic
 genome of 100 records x 1e9 bases (iid bases, a leading N run per record, 2000 planted mutated
 genes), generated on the device (no real genome is available offline).  The whole genome fits one
-MI355X (100 GB ASCII + 25 GB bit-planes + 25 GB 2-bit interleaved copy of 288 GB), so N = 1 scans all of it; with N ranks the
+MI355X (100 GB ASCII + 25 GB 2-bit interleaved copy of 288 GB; no bit-plane copy: the 8-bit stream kernel does not read one), so N = 1 scans all of it; with N ranks the
 RECORDS of the same genome are sharded (parallel.shard_contigs: contiguous, balanced by bases),
 every rank generates and scans its own records, and one RCCL all_gather per step brings the 64-byte
 hit records to rank 0, which restores record indices and genome_pos: STRONG scaling, the exchange is
@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ALGO_BYTES_PER_BASE = 0.25     # scan kernel reads the 2-bit genome once
-PACK_BYTES_PER_BASE = 1.5      # pack kernel: 1 B ASCII read + 0.25 B bit-planes + 0.25 B 2-bit interleaved copy written
+PACK_BYTES_PER_BASE = 1.25     # pack kernel: 1 B ASCII read + 0.25 B 2-bit interleaved copy written (the bit-plane copy is only made for kernels that read it)
 N_RECORDS = 100
 SEED_STRIDE = 0xD1B54A32D192ED03   # synth_kernel keys record c by seed + (c + 1) * this
 

@@ -828,7 +828,7 @@ static int genome_layout(kgma_ctx *ctx, kgma_genome *g, const int64_t *contig_le
     g->total_bases = total;
     (void)hipSetDevice(ctx->device);
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_ascii), (size_t)g->ascii_bytes));
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_planes), (size_t)g->total_words * 8));
+    g->d_planes = nullptr;       // bit planes: allocated and written once a scan needs them (ensure_planes)
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_inter), (size_t)g->total_words * 8));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_cd), std::max<size_t>(1, (size_t)n_contigs) * sizeof(ContigDesc)));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_first_bad), std::max<size_t>(1, (size_t)n_contigs) * sizeof(unsigned long long)));
@@ -850,7 +850,7 @@ static int genome_layout(kgma_ctx *ctx, kgma_genome *g, const int64_t *contig_le
         HIP_TRY(ctx, hipMemcpy(g->d_block_contig, bc.data(), bc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         g->device_bytes += (int64_t)bc.size() * 4;
     }
-    g->device_bytes += g->ascii_bytes + g->total_words * 16 + n_contigs * (int64_t)(sizeof(ContigDesc) + 8);
+    g->device_bytes += g->ascii_bytes + g->total_words * 8 + n_contigs * (int64_t)(sizeof(ContigDesc) + 8);
     if (n_contigs > 0)
         HIP_TRY(ctx, hipMemcpy(g->d_cd, g->cd.data(), (size_t)n_contigs * sizeof(ContigDesc), hipMemcpyHostToDevice));
     return KGMA_OK;
@@ -868,6 +868,21 @@ static int genome_sync(kgma_ctx *ctx, kgma_genome *g)
     return KGMA_OK;
 }
 
+// The bit-plane copy of the genome (read by the bit-sliced kernel, its window pass and the 16-bit stream kernel) is
+// made the first time a scan needs it and kept up to date by every later pack; genomes that only the 8-bit stream
+// kernel scans never have one.
+static int ensure_planes(kgma_ctx *ctx, kgma_genome *g)
+{
+    if (g->d_planes) return KGMA_OK;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&g->d_planes), (size_t)g->total_words * 8));
+    g->device_bytes += g->total_words * 8;
+    if (g->n_contigs > 0)
+        HIP_TRY(ctx, launch_pack(g->d_ascii, g->d_planes, g->d_inter, g->d_cd, (int)g->n_contigs, g->total_words, g->d_block_contig, g->d_first_bad, ctx->stream));
+    else
+        HIP_TRY(ctx, hipMemsetAsync(g->d_planes, 0, (size_t)g->total_words * 8, ctx->stream));
+    return KGMA_OK;
+}
+
 int kgma_genome_repack(kgma_ctx *ctx, kgma_genome *g)
 {
     if (!ctx || !g) return KGMA_E_ARG;
@@ -882,7 +897,7 @@ int kgma_genome_repack(kgma_ctx *ctx, kgma_genome *g)
         HIP_TRY(ctx, launch_pack(g->d_ascii, g->d_planes, g->d_inter, g->d_cd, (int)g->n_contigs, g->total_words, g->d_block_contig, g->d_first_bad, ctx->stream));
     else
     {
-        HIP_TRY(ctx, hipMemsetAsync(g->d_planes, 0, (size_t)g->total_words * 8, ctx->stream));
+        if (g->d_planes) HIP_TRY(ctx, hipMemsetAsync(g->d_planes, 0, (size_t)g->total_words * 8, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(g->d_inter, 0, (size_t)g->total_words * 8, ctx->stream));
     }
     HIP_TRY(ctx, hipEventRecord(ctx->evp1, ctx->stream));
@@ -1409,6 +1424,15 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     ctx->hits.clear();
     ctx->have_dists = false;
     ctx->last_mode = -1;
+    {
+        // every kernel but the 8-bit stream kernel reads the bit-plane copy of the genome
+        bool planes_needed = !use_stream;
+        for (const Group &gr : groups) planes_needed = planes_needed || !group_s8(gr);
+        if (planes_needed) {
+            const int prc = ensure_planes(ctx, g);
+            if (prc != KGMA_OK) return prc;
+        }
+    }
 
     // ---- which windows each record evaluates (tile table), cached per (genome, mode, W, k, kernel) ----
     const bool tiles_cached = ctx->tk_uid == g->uid && ctx->tk_mode == mode && ctx->tk_maxws == maxws &&

@@ -132,6 +132,8 @@ constexpr int PACK_BLOCK_WORDS = 256 * PACK_U;
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
+// `planes` may be null: the bit-plane copy is only kept for genomes that a kernel reading it has scanned (the 8-bit
+// stream kernel reads the interleaved copy alone), which saves a quarter byte per base of writes and of memory.
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii,
                                                    uint32_t *__restrict__ planes, uint32_t *__restrict__ inter,
                                                    const ContigDesc *__restrict__ cd, int n_contigs,
@@ -163,8 +165,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
             const uint2 r = pack_word(va[u], vb[u], 32, &bad);
             const int64_t g = g0 + u * 256 + threadIdx.x;
             if (bad) atomicMin(&first_bad[c0], (unsigned long long)((w0 + u * 256 + threadIdx.x) * 32 + __builtin_ctz(bad) + 1));
-            u32x2_t rv; rv.x = r.x; rv.y = r.y;
-            __builtin_nontemporal_store(rv, reinterpret_cast<u32x2_t *>(out + g));
+            if (planes != nullptr) {
+                u32x2_t rv; rv.x = r.x; rv.y = r.y;
+                __builtin_nontemporal_store(rv, reinterpret_cast<u32x2_t *>(out + g));
+            }
             const uint2 iw = interleave_word(r);
             u32x2_t iv; iv.x = iw.x; iv.y = iw.y;
             __builtin_nontemporal_store(iv, reinterpret_cast<u32x2_t *>(out2 + g));
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
             r = pack_word(p[0], p[1], nvalid, &bad);
             if (bad) atomicMin(&first_bad[c], (unsigned long long)(base0 + __builtin_ctz(bad) + 1));
         }
-        out[g] = r;
+        if (planes != nullptr) out[g] = r;
         out2[g] = interleave_word(r);
     }
 }
