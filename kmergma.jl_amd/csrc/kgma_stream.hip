@@ -548,6 +548,8 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
     // ---- LDS: [S tables] then per wave [NB byte counters | cold per-KFV dip state (NKFV > 1)].
     // S tables: int32 [KFV][k-mer], or int16 -- for several KFVs as ROWS [k-mer][NV slots], so that one read per k-mer
     // serves every KFV of the launch (2 LDS reads per step instead of 2 per KFV); k = 7 reads the same rows from global memory
+    // (measured at k = 6 too, for the residency it would buy -- 3 KFVs, 400 Mb: 1.45 ms with the rows in global memory
+    // against 1.15 ms in LDS)
     constexpr bool SROWS = S16 && NKFV >= 2;
     constexpr int NV = NKFV >= 5 ? 8 : (NKFV >= 3 ? 4 : NKFV);          // int16 slots per row
     constexpr size_t tab_words = SROWS ? (size_t)NB * NV / 2 : (S16 ? NB / 2 : NB) * (size_t)NKFV;
