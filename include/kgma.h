@@ -69,7 +69,7 @@ enum {
                                        the host re-runs the reference's Float64 update from the record's
                                        first window (GenomeMiner.jl:46-47,70-77) on its threads and takes
                                        the decisions from those values.  Costs host time per flagged
-                                       record (about 2 ns per window and KFV; kgma_stats.chain_ms); no dip
+                                       record (about 1.8 ns per window and KFV; kgma_stats.chain_ms); no dip
                                        is left KGMA_HIT_TIE / KGMA_HIT_AT_THRESHOLD.  The first window's
                                        sqeuclidean is summed left to right (Julia leaves the order of its
                                        @simd reduction to the machine).  Ignored with KGMA_F_NO_TIE_RESOLVE

@@ -137,6 +137,7 @@ struct kgma_ctx {
     int reserved_cus = 0;                                // CUs the stream kernel leaves free (kgma_set_reserved_cus)
     char kernel_name[48] = "";
     uint8_t *d_gath = nullptr, *h_gath = nullptr; size_t gath_cap = 0;   // tie-replay residue gather: [desc | residues]
+    uint32_t *h_chain = nullptr; size_t chain_cap = 0;                   // chain replay: pinned copy of the records' 2-bit codes (dwords)
     uint64_t next_uid = 1;
     // key of the tile table currently on the device
     uint64_t tk_uid = 0; int tk_mode = -1, tk_version = 0, tk_k = 0; int64_t tk_maxws = 0;
@@ -442,6 +443,7 @@ void kgma_destroy(kgma_ctx *ctx)
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->h_gath) (void)hipHostFree(ctx->h_gath);
+    if (ctx->h_chain) (void)hipHostFree(ctx->h_chain);
     if (ctx->d_gath) (void)hipFree(ctx->d_gath);
     if (ctx->evp0) (void)hipEventDestroy(ctx->evp0);
     if (ctx->evp1) (void)hipEventDestroy(ctx->evp1);
@@ -2286,16 +2288,20 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
     if (const char *e = getenv("KGMA_CHAIN_THREADS")) n_threads = atoi(e);
     n_threads = std::max(1, std::min(n_threads, 64));
     (void)hipSetDevice(ctx->device);
-    const int64_t BATCH_BYTES = (int64_t)2 << 30;
+    int64_t BATCH_BYTES = (int64_t)2 << 30;         // of 2-bit codes: 8 G residues per batch (one batch for a GRCh38-size genome)
+    if (const char *e = getenv("KGMA_CHAIN_BATCH_MB")) BATCH_BYTES = std::max<int64_t>(1, atoll(e)) << 20;   // experiments
     size_t pi = 0;
     int64_t windows = 0;
+    double copy_ms = 0, jobs_ms = 0;
     while (pi < pairs.size()) {
-        std::vector<std::vector<uint8_t>> bufs;
+        // the records of this batch: their 2-bit codes (the device's interleaved copy: a quarter of the residue text)
+        // are copied into one pinned buffer, kept by the context; all pairs of one record share its copy
+        struct Rec { int32_t c; size_t p0, p1; int64_t need; size_t dw_off, dw; };
+        std::vector<Rec> recs;
         std::vector<ChainJob> jobs;
         int64_t bytes = 0;
-        size_t pj = pi;
+        size_t pj = pi, total_dw = 0;
         while (pj < pairs.size() && (pj == pi || bytes < BATCH_BYTES)) {
-            // all pairs of one record share its residues
             const int32_t c = pairs[pj].c;
             size_t pe = pj;
             int64_t need = 0;
@@ -2304,28 +2310,46 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
                 pe++;
             }
             need = std::min(need, g->cd[(size_t)c].len);
-            bufs.emplace_back((size_t)need);
-            if (hipMemcpy(bufs.back().data(), g->d_ascii + g->cd[(size_t)c].ascii_off, (size_t)need, hipMemcpyDeviceToHost) != hipSuccess)
-                return fail(ctx, KGMA_E_HIP, "chain replay: cannot read the residues of record %d", c);
-            for (size_t u = pj; u < pe; u++) {
+            const size_t dw = (size_t)((need + 15) / 16);
+            recs.push_back(Rec{c, pj, pe, need, total_dw, dw});
+            total_dw += dw;
+            bytes += (int64_t)dw * 4;
+            pj = pe;
+        }
+        const double tc0 = now_ms();
+        if (total_dw > ctx->chain_cap) {
+            if (ctx->h_chain) (void)hipHostFree(ctx->h_chain);
+            ctx->h_chain = nullptr; ctx->chain_cap = 0;
+            const size_t cap = total_dw + (total_dw >> 3) + 1024;
+            if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_chain), cap * 4, hipHostMallocDefault) != hipSuccess)
+                return fail(ctx, KGMA_E_NOMEM, "chain replay: cannot allocate %zu bytes of pinned host memory", cap * 4);
+            ctx->chain_cap = cap;
+        }
+        for (const Rec &r : recs)
+            if (hipMemcpyAsync(ctx->h_chain + r.dw_off, g->d_inter + 2 * g->cd[(size_t)r.c].word_off, r.dw * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+                return fail(ctx, KGMA_E_HIP, "chain replay: cannot read record %d", r.c);
+        if (sync_spin(ctx->stream) != hipSuccess) return fail(ctx, KGMA_E_HIP, "chain replay: cannot read the records");
+        copy_ms += now_ms() - tc0;
+        for (const Rec &r : recs)
+            for (size_t u = r.p0; u < r.p1; u++) {
                 Pair &p = pairs[u];
                 ChainJob J;
-                J.seq = bufs.back().data(); J.n_res = need; J.ref = ctx->kfv[(size_t)p.j].ref.data(); J.k = k;
+                J.seq = nullptr; J.packed = ctx->h_chain + r.dw_off; J.n_res = r.need; J.ref = ctx->kfv[(size_t)p.j].ref.data(); J.k = k;
                 J.W = ctx->kfv[(size_t)p.j].W; J.last_window = p.last; J.iv = p.iv.data(); J.n_iv = p.iv.size();
                 J.out = p.val.data(); J.n_out = 0; J.ok = false;
                 jobs.push_back(J);
                 windows += p.last;
             }
-            bytes += need;
-            pj = pe;
-        }
+        const double tj0 = now_ms();
         run_chain_jobs(jobs.data(), jobs.size(), n_threads);
+        jobs_ms += now_ms() - tj0;
         for (size_t u = 0; u < jobs.size(); u++)
             if (!jobs[u].ok || jobs[u].n_out != (int64_t)pairs[pi + u].val.size())
                 return fail(ctx, KGMA_E_HIP, "internal: chain replay of record %d KFV %d failed", pairs[pi + u].c, pairs[pi + u].j + 1);
         pi = pj;
     }
 
+    if (getenv("KGMA_CHAIN_DEBUG")) fprintf(stderr, "chain replay: residues copied in %.1f ms, chains %.1f ms, %d threads\n", copy_ms, jobs_ms, n_threads);
     // ---- rebuild the dips of the chain pairs from the chain values ---------------------------
     struct DipX { kgma_dip d; int64_t argl, aux; double fmin, fexit; };
     std::vector<DipX> all;

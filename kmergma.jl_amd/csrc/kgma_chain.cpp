@@ -16,6 +16,7 @@
 // order Julia leaves to the machine; it is summed left to right here (exact, hence order-free, whenever
 // the KFV is dyadic, e.g. N a power of two).
 
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstring>
@@ -41,7 +42,41 @@ struct CodeTable {
 };
 const CodeTable CODE;
 
-void chain_one(ChainJob &J)
+// residue code at 0-based position i
+struct AsciiCodes {
+    const uint8_t *s;
+    inline uint64_t operator()(int64_t i) const { return CODE.c[s[i]]; }
+    struct Cursor {                                    // sequential reader from position i
+        const uint8_t *p;
+        inline uint64_t next() { return CODE.c[*p++]; }
+    };
+    Cursor cursor(int64_t i) const { return Cursor{s + i}; }
+};
+struct PackedCodes {
+    const uint32_t *w;
+    inline uint64_t operator()(int64_t i) const { return (w[i >> 4] >> (2 * (unsigned)(i & 15))) & 3u; }
+    struct Cursor {
+        const uint32_t *p;                             // next dword
+        uint32_t cur;                                  // codes not yet handed out, lowest first
+        int rem;
+        inline uint64_t next()
+        {
+            if (rem == 0) { cur = *p++; rem = 16; }
+            const uint64_t c = cur & 3u;
+            cur >>= 2; rem--;
+            return c;
+        }
+    };
+    Cursor cursor(int64_t i) const
+    {
+        const int used = (int)(i & 15);
+        if (used == 0) return Cursor{w + (i >> 4), 0u, 0};
+        return Cursor{w + (i >> 4) + 1, w[i >> 4] >> (2 * used), 16 - used};
+    }
+};
+
+template <class Codes>
+void chain_walk(ChainJob &J, const Codes code)
 {
     J.ok = false;
     const int k = J.k;
@@ -49,13 +84,12 @@ void chain_one(ChainJob &J)
     const uint64_t mask = (uint64_t)NB - 1;
     const int64_t last = J.last_window;
     if (k < 1 || W < k || last < 1 || J.n_res < W + last - 1 || J.n_iv == 0) return;
-    const uint8_t *s = J.seq;
     const double *ref = J.ref;
     std::vector<int32_t> cnt((size_t)NB, 0);
     // first window: kmer_count! (src/Kmers.jl:33-44) and the sqeuclidean call site (GenomeMiner.jl:46-47)
     uint64_t km = 0;
     for (int64_t i = 0; i < W; i++) {
-        km = ((km << 2) & mask) | CODE.c[s[i]];
+        km = ((km << 2) & mask) | code(i);
         if (i >= k - 1) cnt[(size_t)km]++;
     }
     double sq = 0.0;
@@ -66,8 +100,8 @@ void chain_one(ChainJob &J)
     const double SF = 1.0 / (double)k;                 // src/API.jl:86,204
     double dist = (SF * 0.5) * sq;                     // GenomeMiner.jl:29,46-47 / OmnGenomeMiner.jl:73-74
     uint64_t left = 0, right = 0;
-    for (int64_t i = 0; i < k - 1; i++) left = (left << 2) | CODE.c[s[i]];
-    for (int64_t i = W - k + 1; i < W; i++) right = (right << 2) | CODE.c[s[i]];
+    for (int64_t i = 0; i < k - 1; i++) left = (left << 2) | code(i);
+    for (int64_t i = W - k + 1; i < W; i++) right = (right << 2) | code(i);
 
     const ChainInterval *iv = J.iv;
     size_t ii = 0;
@@ -83,10 +117,10 @@ void chain_one(ChainJob &J)
         }
     };
     sample(1, dist);
-    const uint8_t *pl = s + (k - 1), *pr = s + W;
+    auto pl = code.cursor(k - 1), pr = code.cursor(W);
     for (int64_t w = 2; w <= last; w++) {              // roll window w-1 -> w  (GenomeMiner.jl:60-77)
-        left = ((left << 2) & mask) | CODE.c[*pl++];
-        right = ((right << 2) & mask) | CODE.c[*pr++];
+        left = ((left << 2) & mask) | pl.next();
+        right = ((right << 2) & mask) | pr.next();
         if (left != right) {
             const int32_t cl = cnt[(size_t)left], cr = cnt[(size_t)right];
             double t = (double)(1 + cr);               // Int (single engine) or Float64 (cluster engine) counts: same value
@@ -103,6 +137,13 @@ void chain_one(ChainJob &J)
     J.ok = true;
 }
 
+void chain_one(ChainJob &J)
+{
+    if (J.seq) chain_walk(J, AsciiCodes{J.seq});
+    else if (J.packed) chain_walk(J, PackedCodes{J.packed});
+    else J.ok = false;
+}
+
 }  // namespace
 
 void run_chain_jobs(ChainJob *jobs, size_t n_jobs, int n_threads)
@@ -114,12 +155,16 @@ void run_chain_jobs(ChainJob *jobs, size_t n_jobs, int n_threads)
         for (size_t i = 0; i < n_jobs; i++) chain_one(jobs[i]);
         return;
     }
+    // longest jobs first: a chain is sequential, so the longest one bounds the batch and must not start last
+    std::vector<size_t> order(n_jobs);
+    for (size_t i = 0; i < n_jobs; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return jobs[a].last_window > jobs[b].last_window; });
     std::atomic<size_t> next{0};
     auto worker = [&]() {
         for (;;) {
             const size_t i = next.fetch_add(1, std::memory_order_relaxed);
             if (i >= n_jobs) return;
-            chain_one(jobs[i]);
+            chain_one(jobs[order[i]]);
         }
     };
     std::vector<std::thread> pool;
@@ -153,7 +198,7 @@ extern "C" int kgma_host_chain_values(const uint8_t *seq, int64_t len, const dou
         if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') return KGMA_E_BADBASE;
     }
     kgma::ChainJob J;
-    J.seq = seq; J.n_res = len; J.ref = ref; J.k = k; J.W = windowsize; J.last_window = iv.back().hi;
+    J.seq = seq; J.packed = nullptr; J.n_res = len; J.ref = ref; J.k = k; J.W = windowsize; J.last_window = iv.back().hi;
     J.iv = iv.data(); J.n_iv = iv.size(); J.out = out; J.n_out = 0; J.ok = false;
     kgma::run_chain_jobs(&J, 1, 1);
     return J.ok && J.n_out == total ? KGMA_OK : KGMA_E_ARG;
