@@ -360,6 +360,26 @@ std::vector<Group> make_groups(const kgma_ctx *ctx, int mode, bool s8 = false)
     return gs;
 }
 
+// Host side of the ingest on a few threads: fn(t, begin, end) over [0, n) cut into equal ranges (one range: inline).
+int ingest_threads()
+{
+    int t = (int)std::thread::hardware_concurrency() / 2;
+    if (const char *e = getenv("KGMA_INGEST_THREADS")) t = atoi(e);
+    return std::max(1, std::min(t, 8));
+}
+template <class F>
+void parallel_ranges(int64_t n, int n_threads, int64_t min_per_thread, F fn)
+{
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, n / std::max<int64_t>(1, min_per_thread)));
+    if (T <= 1) { fn(0, (int64_t)0, n); return; }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)T - 1);
+    const int64_t per = (n + T - 1) / T;
+    for (int t = 1; t < T; t++) pool.emplace_back([=]() { fn(t, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per)); });
+    fn(0, (int64_t)0, std::min<int64_t>(n, per));
+    for (std::thread &th : pool) th.join();
+}
+
 double now_ms()
 {
     using namespace std::chrono;
@@ -1012,22 +1032,28 @@ int kgma_genome_from_fasta(kgma_ctx *ctx, const uint8_t *text, int64_t n, kgma_g
     (void)hipSetDevice(ctx->device);
     constexpr int64_t FB = 4096;
     // ---- host: locate the header lines (a '>' at the start of a line); O(file) memchr only ----
+    // (a header is a '>' right after a line break, wherever the scan starts: the ranges of the threads are independent)
     struct Hdr { int64_t begin, end; };            // [begin, end): from '>' to just past its '\n'
     std::vector<Hdr> hdrs;
+    const int n_thr = ingest_threads();
     {
-        const uint8_t *p = text, *e = text + n;
-        while (p < e) {
-            const uint8_t *q = static_cast<const uint8_t *>(memchr(p, '>', (size_t)(e - p)));
-            if (!q) break;
-            if (q == text || q[-1] == '\n') {
-                const uint8_t *nl = static_cast<const uint8_t *>(memchr(q, '\n', (size_t)(e - q)));
-                const int64_t hb = q - text, he = nl ? (nl - text) + 1 : n;
-                hdrs.push_back(Hdr{hb, he});
-                p = text + he;
-            } else {
-                p = q + 1;
+        std::vector<std::vector<Hdr>> found((size_t)n_thr);
+        parallel_ranges(n, n_thr, (int64_t)8 << 20, [&](int t, int64_t b0, int64_t e0) {
+            const uint8_t *p = text + b0, *e = text + e0;
+            while (p < e) {
+                const uint8_t *q = static_cast<const uint8_t *>(memchr(p, '>', (size_t)(e - p)));
+                if (!q) break;
+                if (q == text || q[-1] == '\n') {
+                    const uint8_t *nl = static_cast<const uint8_t *>(memchr(q, '\n', (size_t)(text + n - q)));
+                    const int64_t hb = q - text, he = nl ? (nl - text) + 1 : n;
+                    found[(size_t)t].push_back(Hdr{hb, he});
+                    p = text + he;
+                } else {
+                    p = q + 1;
+                }
             }
-        }
+        });
+        for (const std::vector<Hdr> &f : found) hdrs.insert(hdrs.end(), f.begin(), f.end());
     }
     const int64_t n_rec = (int64_t)hdrs.size();
     if (n_rec == 0 && n > 0) {
@@ -1078,7 +1104,8 @@ int kgma_genome_from_fasta(kgma_ctx *ctx, const uint8_t *text, int64_t n, kgma_g
             uint8_t *stage = pipe.acquire();               // (the other buffer may still be on its way to the device)
             const int64_t len = std::min<int64_t>((int64_t)stage_cap, n_pad - off);
             const int64_t data = std::max<int64_t>(0, std::min<int64_t>(len, n - off));
-            if (data) memcpy(stage, text + off, (size_t)data);
+            if (data)
+                parallel_ranges(data, n_thr, (int64_t)2 << 20, [&](int, int64_t b0, int64_t e0) { memcpy(stage + b0, text + off + b0, (size_t)(e0 - b0)); });
             if (len > data) memset(stage + data, '\n', (size_t)(len - data));
             while (hi < hdrs.size() && hdrs[hi].end <= off) hi++;
             for (size_t h = hi; h < hdrs.size() && hdrs[h].begin < off + len; h++) {
