@@ -960,6 +960,7 @@ int kgma_genome_from_host(kgma_ctx *ctx, const uint8_t *const *contig_ascii, con
         return e;
     };
     hipError_t he = hipSuccess;
+    const int n_thr = ingest_threads();                 // the staging copy runs on a few host threads
     for (int64_t c = 0; c < n_contigs && he == hipSuccess; c++) {
         const ContigDesc &d = g->cd[(size_t)c];
         const int64_t region = ((d.len + 31) & ~31ll) + 32;
@@ -971,7 +972,11 @@ int kgma_genome_from_host(kgma_ctx *ctx, const uint8_t *const *contig_ascii, con
             // part of [done, done+take) that is residue data
             const int64_t data_hi = std::min<int64_t>(d.len, done + (int64_t)take);
             size_t ndata = data_hi > done ? (size_t)(data_hi - done) : 0;
-            if (ndata) memcpy(stage + fill, contig_ascii[c] + done, ndata);
+            if (ndata) {
+                uint8_t *dst = stage + fill;
+                const uint8_t *src = contig_ascii[c] + done;
+                parallel_ranges((int64_t)ndata, n_thr, (int64_t)2 << 20, [=](int, int64_t b0, int64_t e0) { memcpy(dst + b0, src + b0, (size_t)(e0 - b0)); });
+            }
             if (take > ndata) memset(stage + fill + ndata, 0, take - ndata);
             fill += take;
             done += (int64_t)take;

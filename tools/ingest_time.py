@@ -38,6 +38,15 @@ def main():
         dt = time.perf_counter() - t0
         print("bytes object: %d MB text, %d records -> %.1f ms  %.2f GB/s" % (len(text) // 1_000_000, n, dt * 1e3, len(text) / dt / 1e9), flush=True)
         g.free()
+    contigs = [p[p.index(b"\n") + 1:].replace(b"\n", b"") for p in parts]
+    nbytes = sum(len(c) for c in contigs)
+    for rep in range(3):
+        t0 = time.perf_counter()
+        g = ctx.genome_from_host(contigs)
+        g.fetch(0, 1, 10)
+        dt = time.perf_counter() - t0
+        print("host records (kgma_genome_from_host): %d MB -> %.1f ms  %.2f GB/s" % (nbytes // 1_000_000, dt * 1e3, nbytes / dt / 1e9), flush=True)
+        g.free()
     with tempfile.NamedTemporaryFile(suffix=".fasta", dir="/tmp", delete=False) as f:
         f.write(text)
         path = f.name
