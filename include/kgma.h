@@ -178,8 +178,9 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
 int kgma_set_thresholds(kgma_ctx *ctx, const double *thr);
 
 /* Build a device-resident genome from host ASCII records (raw FASTA residue bytes, either case;
- * line breaks already removed).  The bytes are copied to the device and packed there to two
- * bit-planes (A0 C1 G2 T3 N->3, src/Consts.jl:22-28).  Residues outside A/C/G/T/N are recorded
+ * line breaks already removed).  The bytes are copied to the device and packed there to 2-bit
+ * codes (A0 C1 G2 T3 N->3, src/Consts.jl:22-28; 16 residues per 32-bit word -- plus a copy as two
+ * bit-planes, made the first time a scan picks a kernel that reads it).  Residues outside A/C/G/T/N are recorded
  * per record; kgma_scan raises KGMA_E_BADBASE for those the reference would have looked up. */
 int kgma_genome_from_host(kgma_ctx *ctx, const uint8_t *const *contig_ascii, const int64_t *contig_len,
                           int64_t n_contigs, kgma_genome **out);
@@ -214,7 +215,7 @@ void kgma_genome_free(kgma_ctx *ctx, kgma_genome *g);
 int kgma_genome_poke(kgma_ctx *ctx, kgma_genome *g, int64_t contig, int64_t pos, int64_t len,
                      const uint8_t *bytes);
 
-/* Re-run the ASCII -> bit-plane pack kernel of a resident genome (after kgma_genome_poke, and in
+/* Re-run the ASCII -> 2-bit pack kernel of a resident genome (after kgma_genome_poke, and in
  * benchmarks that time pack + scan). */
 int kgma_genome_repack(kgma_ctx *ctx, kgma_genome *g);
 
