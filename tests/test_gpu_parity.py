@@ -861,3 +861,43 @@ def test_stream8_derived_windows(ctx, k, lens, monkeypatch):
         res[derive] = (hits, dips, st["n_launches"])
     assert res["1"][0] == res["0"][0] and res["1"][1] == res["0"][1]
     assert res["1"][2] < res["0"][2]                                   # fewer launches with derived windows
+
+
+def test_lazy_bit_planes_follow_pokes_and_repacks(ctx, alp_ref, genes, monkeypatch):
+    """The bit-plane copy of a genome is made by the first scan whose kernel reads it and must then track the
+    residue text like the 2-bit copy does: ONE genome object scanned by the 8-bit stream kernel (no planes yet),
+    by the bit-sliced kernel (planes made), changed with kgma_genome_poke + kgma_genome_repack, and scanned by
+    both kernels again -- every time against the oracle on the current text."""
+    rng = np.random.default_rng(91)
+    contigs, _ = make_genome(rng, [90000, 30000, 400], genes, n_plants_per_mb=200)
+    ref = alp_ref
+    ctx.set_refs(6, [ref["RV"]], [ref["ws"]], [30.0], [ref["N"]])
+    g = ctx.genome_from_host(contigs)
+    T = orc.int_threshold(30.0, 6, ref["N"])
+
+    def check(expect_kernel):
+        ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_NO_TIE_RESOLVE, None)
+        assert ctx.kernel_name().startswith(expect_kernel)
+        ohi = orc.single_scan_int(contigs, ref["S"], ref["N"], 6, ref["ws"], T, 50)[0]
+        assert [hit_key(h) for h in ctx.hits()] == [hit_key(h) for h in ohi]
+        return len(ohi)
+
+    n0 = check("stream8_kernel")
+    bytes_without_planes = ctx.stats()["device_bytes"]
+    monkeypatch.setenv("KGMA_KERNEL", "bitslice")
+    assert check("scan_kernel") == n0
+    assert ctx.stats()["device_bytes"] > bytes_without_planes      # the planes were allocated by this scan
+    monkeypatch.delenv("KGMA_KERNEL")
+    # plant one more gene copy in record 1 and wipe one planted stretch of record 0 with N
+    gene = genes[3][:ref["ws"]]
+    c1 = bytearray(contigs[1]); c1[7000:7000 + len(gene)] = gene; contigs[1] = bytes(c1)
+    g.poke(1, 7001, gene)
+    c0 = bytearray(contigs[0]); c0[20000:24000] = b"N" * 4000; contigs[0] = bytes(c0)
+    g.poke(0, 20001, b"N" * 4000)
+    g.repack()
+    n1 = check("stream8_kernel")
+    monkeypatch.setenv("KGMA_KERNEL", "bitslice")
+    assert check("scan_kernel") == n1
+    monkeypatch.delenv("KGMA_KERNEL")
+    assert n1 >= 1
+    g.free()
