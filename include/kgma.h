@@ -205,6 +205,11 @@ int kgma_genome_synthetic(kgma_ctx *ctx, const int64_t *contig_len, int64_t n_co
  * (used to build the FASTA body of a hit: view(seq, seq_UnitRange)). */
 int kgma_genome_fetch(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int64_t pos, int64_t len,
                       uint8_t *out);
+/* The same for n ranges in ONE device gather + ONE download (the FASTA bodies of all hits of a scan:
+ * GenomeMiner.jl:100-103 / OmnGenomeMiner.jl:143-150 build one record per hit).  The ranges are written
+ * back to back into `out` (range i at the sum of len[0..i-1]); out_cap >= the sum of len. */
+int kgma_genome_fetch_batch(kgma_ctx *ctx, const kgma_genome *g, int64_t n, const int64_t *contig,
+                            const int64_t *pos, const int64_t *len, uint8_t *out, int64_t out_cap);
 int64_t kgma_genome_num_contigs(const kgma_genome *g);
 int64_t kgma_genome_contig_len(const kgma_genome *g, int64_t contig);
 int64_t kgma_genome_total_bases(const kgma_genome *g);

@@ -1199,6 +1199,49 @@ int kgma_genome_fetch(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int64
     return KGMA_OK;
 }
 
+int kgma_genome_fetch_batch(kgma_ctx *ctx, const kgma_genome *g, int64_t n, const int64_t *contig, const int64_t *pos,
+                            const int64_t *len, uint8_t *outp, int64_t out_cap)
+{
+    if (!ctx || !g) return KGMA_E_ARG;
+    if (n < 0 || (n > 0 && (!contig || !pos || !len))) return fail(ctx, KGMA_E_ARG, "kgma_genome_fetch_batch: null argument");
+    if (n > 0x7FFFFFF0ll) return fail(ctx, KGMA_E_UNSUPPORTED, "kgma_genome_fetch_batch: too many ranges");
+    std::vector<int64_t> desc;
+    desc.reserve((size_t)n * 3);
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t c = contig[i];
+        if (c < 0 || c >= g->n_contigs || pos[i] < 1 || len[i] < 0 || pos[i] + len[i] - 1 > g->cd[(size_t)c].len)
+            return fail(ctx, KGMA_E_ARG, "kgma_genome_fetch_batch: range %lld outside its record", (long long)i);
+        if (len[i] == 0) continue;
+        desc.push_back(g->cd[(size_t)c].ascii_off + (pos[i] - 1));
+        desc.push_back(total);
+        desc.push_back(len[i]);
+        total += len[i];
+    }
+    if (total > out_cap || (total > 0 && !outp)) return fail(ctx, KGMA_E_ARG, "kgma_genome_fetch_batch: output buffer too small (%lld bytes needed)", (long long)total);
+    if (total == 0) return KGMA_OK;
+    (void)hipSetDevice(ctx->device);
+    // one gather kernel into a staging buffer + one download (the tie resolver's buffers)
+    const size_t desc_bytes = (desc.size() * sizeof(int64_t) + 255) & ~(size_t)255;
+    const size_t need = desc_bytes + (size_t)total;
+    if (need > ctx->gath_cap) {
+        if (ctx->h_gath) (void)hipHostFree(ctx->h_gath);
+        if (ctx->d_gath) (void)hipFree(ctx->d_gath);
+        ctx->h_gath = ctx->d_gath = nullptr; ctx->gath_cap = 0;
+        const size_t cap = need + (need >> 1) + 65536;
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_gath), cap, hipHostMallocDefault));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_gath), cap));
+        ctx->gath_cap = cap;
+    }
+    memcpy(ctx->h_gath, desc.data(), desc.size() * sizeof(int64_t));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_gath, ctx->h_gath, desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, launch_gather_ranges(g->d_ascii, reinterpret_cast<const int64_t *>(ctx->d_gath), (int)(desc.size() / 3), ctx->d_gath + desc_bytes, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_gath + desc_bytes, ctx->d_gath + desc_bytes, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, sync_spin(ctx->stream));
+    memcpy(outp, ctx->h_gath + desc_bytes, (size_t)total);
+    return KGMA_OK;
+}
+
 int kgma_genome_poke(kgma_ctx *ctx, kgma_genome *g, int64_t contig, int64_t pos, int64_t len, const uint8_t *bytes)
 {
     if (!ctx || !g) return KGMA_E_ARG;

@@ -12,7 +12,7 @@
 # construction.  What moves to the GPU: FASTA parsing + encoding (kgma_genome_from_fasta: the file is mapped
 # and goes to the device ONCE; no LongDNA copy of the genome is made on the host) and the per-record body of
 # the engines (src/GenomeMiner.jl:32-107, src/OmnGenomeMiner.jl:55-160).  Residues are read back only for the
-# hits: `kgma_genome_fetch` serves the alignment segments and the record bodies (a few hundred bases each).
+# hits: `kgma_genome_fetch` serves the alignment segments, `kgma_genome_fetch_batch` the record bodies of all hits at once.
 
 module KmerGMAHIP
 
@@ -112,6 +112,21 @@ function subseq(g::DeviceGenome, contig::Integer, lo::Integer, hi::Integer)
     return KmerGMA.Seq(String(buf))
 end
 
+# view(seq, lo:hi) of every hit in ONE device gather + ONE download (kgma_genome_fetch_batch)
+function hit_bodies(g::DeviceGenome, hits)
+    n = length(hits)
+    n == 0 && return KmerGMA.Seq[]
+    contigs = Int64[h.contig for h in hits]
+    pos = Int64[h.lo for h in hits]
+    lens = Int64[max(h.hi - h.lo + 1, 0) for h in hits]
+    buf = Vector{UInt8}(undef, max(sum(lens), 1))
+    check(g.ctx, ccall((:kgma_genome_fetch_batch, libkgma), Cint,
+                       (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{UInt8}, Int64),
+                       g.ctx.h, g.h, n, contigs, pos, lens, buf, length(buf)))
+    offs = cumsum(vcat(0, lens))
+    return [KmerGMA.Seq(String(buf[offs[i]+1:offs[i+1]])) for i in 1:n]
+end
+
 function fetch_hits(ctx::Context)
     n = Ref{Int64}(0)
     check(ctx, ccall((:kgma_get_hits, libkgma), Cint, (Ptr{Cvoid}, Ptr{KgmaHit}, Int64, Ref{Int64}), ctx.h, C_NULL, 0, n))
@@ -187,7 +202,9 @@ function single_engine!(ctx::Context, g::DeviceGenome, ident::Function; refVec, 
             (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int64, Int64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}),
             ctx.h, g.h, KGMA_MODE_SINGLE, buff, 0, scan_flags(do_return_dists, float_chain), cb, pointer_from_objref(st)))
     end
-    for h in fetch_hits(ctx)
+    hits = fetch_hits(ctx)
+    bodies = hit_bodies(g, hits)
+    for (h, body) in zip(hits, bodies)
         seq_UnitRange = Int(h.lo):Int(h.hi)
         # the reference's record format: src/Alignment.jl:69-80 (append_hit!, do_overlap = false);
         # record_KmerGMA! omits GenomePos (src/MultiThread/GenomeMiner.jl:87-93)
@@ -196,7 +213,7 @@ function single_engine!(ctx::Context, g::DeviceGenome, ident::Function; refVec, 
             " | MatchPos = $seq_UnitRange" *
             (with_genome_pos ? " | GenomePos = $(h.genome_pos)" : "") *
             " | Len = " * string(last(seq_UnitRange) - first(seq_UnitRange) + 1)
-        push!(resultVec, FASTA.Record(header, subseq(g, h.contig, h.lo, h.hi)))
+        push!(resultVec, FASTA.Record(header, body))
         get_hit_loci && push!(hit_loci_vec, h.lo + h.genome_pos)
     end
     do_return_dists && fetch_dists!(ctx, 1, dist_vec)
@@ -287,7 +304,9 @@ function Omn_KmerGMA!(; genome_path::String, refVecs::Vector{Vector{Float64}}, w
                 ctx.h, g.h, KGMA_MODE_OMN, buff, genome_pos, scan_flags(do_return_dists, float_chain),
                 cb, pointer_from_objref(st)))
         end
-        for h in fetch_hits(ctx)
+        hits = fetch_hits(ctx)
+        bodies = hit_bodies(g, hits)
+        for (h, body) in zip(hits, bodies)
             seq_UnitRange = Int(h.lo):Int(h.hi)
             # record construction as in src/OmnGenomeMiner.jl:141-149
             push!(resultVec, FASTA.Record(
@@ -297,7 +316,7 @@ function Omn_KmerGMA!(; genome_path::String, refVecs::Vector{Vector{Float64}}, w
                     " | MatchPos = $seq_UnitRange" *
                     " | GenomePos = $(h.genome_pos)" *
                     " | Len = " * string(last(seq_UnitRange) - first(seq_UnitRange) + 1),
-                subseq(g, h.contig, h.lo, h.hi)))
+                body))
             get_hit_loci && push!(hit_loci_vec, first(seq_UnitRange) + h.genome_pos)
         end
         if do_return_dists

@@ -25,7 +25,7 @@ HIT_TIE, HIT_AT_THRESHOLD, HIT_TIE_RESOLVED, HIT_CHAIN = 1, 2, 4, 8
 EXPORTS = [
     "kgma_version", "kgma_status_string", "kgma_last_error", "kgma_create", "kgma_destroy",
     "kgma_set_refs", "kgma_set_thresholds", "kgma_genome_from_host", "kgma_genome_synthetic",
-    "kgma_genome_fetch", "kgma_genome_num_contigs", "kgma_genome_contig_len", "kgma_genome_total_bases",
+    "kgma_genome_fetch", "kgma_genome_fetch_batch", "kgma_genome_num_contigs", "kgma_genome_contig_len", "kgma_genome_total_bases",
     "kgma_genome_free", "kgma_genome_repack", "kgma_genome_poke", "kgma_scan", "kgma_scan_device", "kgma_get_hits",
     "kgma_get_dips", "kgma_get_first_window", "kgma_get_dists", "kgma_get_stats", "kgma_stream",
     "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_header", "kgma_scan_kernel_name",
@@ -115,6 +115,7 @@ def load():
     L.kgma_genome_header.argtypes = [vp, i64, P(C.c_char_p), P(i64)]
     L.kgma_genome_synthetic.argtypes = [vp, P(i64), i64, u64, C.c_char_p, i64, P(i64), P(i64), i64, P(vp)]
     L.kgma_genome_fetch.argtypes = [vp, vp, i64, i64, i64, C.c_char_p]
+    L.kgma_genome_fetch_batch.argtypes = [vp, vp, i64, P(i64), P(i64), P(i64), C.c_char_p, i64]
     L.kgma_genome_num_contigs.argtypes = [vp]
     L.kgma_genome_num_contigs.restype = i64
     L.kgma_genome_contig_len.argtypes = [vp, i64]
@@ -206,6 +207,22 @@ class Genome:
         buf = C.create_string_buffer(max(length, 1))
         self._ctx._check(load().kgma_genome_fetch(self._ctx._h, self._h, contig, pos, length, buf))
         return buf.raw[:length]
+
+    def fetch_batch(self, ranges) -> list:
+        """`ranges`: (contig, pos, length) triples; one device gather + one download for all of them."""
+        ranges = list(ranges)
+        if not ranges:
+            return []
+        c = np.asarray([r[0] for r in ranges], dtype=np.int64)
+        p = np.asarray([r[1] for r in ranges], dtype=np.int64)
+        ln = np.asarray([r[2] for r in ranges], dtype=np.int64)
+        total = int(ln.sum())
+        buf = C.create_string_buffer(max(total, 1))
+        self._ctx._check(load().kgma_genome_fetch_batch(self._ctx._h, self._h, len(ranges), _np_ptr(c, C.c_int64), _np_ptr(p, C.c_int64),
+                                                        _np_ptr(ln, C.c_int64), buf, total))
+        raw = buf.raw
+        offs = np.concatenate(([0], np.cumsum(ln)))
+        return [raw[int(offs[i]):int(offs[i + 1])] for i in range(len(ranges))]
 
     def poke(self, contig: int, pos: int, data: bytes) -> None:
         self._ctx._check(load().kgma_genome_poke(self._ctx._h, self._h, contig, pos, len(data), bytes(data)))

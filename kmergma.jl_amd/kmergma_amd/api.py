@@ -70,6 +70,14 @@ class _GenomeView:
             return self._recs[c].sequence[lo - 1:hi]
         return self.genome.fetch(c, lo, hi - lo + 1)
 
+    def subseqs(self, ranges) -> list:
+        """view(seq, lo:hi) for (record, lo, hi) triples: the bodies of all hit records of a scan in ONE device
+        gather (kgma_genome_fetch_batch) instead of one download per hit."""
+        ranges = list(ranges)
+        if self._recs is not None:
+            return [self._recs[c].sequence[lo - 1:hi] if hi >= lo else b"" for c, lo, hi in ranges]
+        return self.genome.fetch_batch([(c, lo, max(hi - lo + 1, 0)) for c, lo, hi in ranges])
+
     def free(self):
         self.genome.free()
 
@@ -134,10 +142,11 @@ def ac_gma_testing(*, genome_path, refVec, consensus_refseq: bytes = b"", k: int
         else:
             ctx.scan(genome, _lib.MODE_SINGLE, int(buff), 0, flags, cb)
         hits = ctx.hits()
-        for h in hits:
+        bodies = view.subseqs((h["contig"], h["lo"], h["hi"]) for h in hits)
+        for h, body in zip(hits, bodies):
             c = h["contig"]
             hdr = headers.single_header(view.identifier(c), h["dist"], h["lo"], h["hi"], h["genome_pos"], with_genome_pos)
-            resultVec.append(Record(hdr, view.subseq(c, h["lo"], h["hi"])))
+            resultVec.append(Record(hdr, body))
             if get_hit_loci and hit_loci_vec is not None:
                 hit_loci_vec.append(h["lo"] + h["genome_pos"])
         if do_return_dists and dist_vec is not None:
@@ -192,10 +201,12 @@ def Omn_KmerGMA(*, genome_path, refVecs: Sequence, windowsizes: Sequence[int], c
                 cb = _make_align_cb(aligner, view, lambda kfv: consensus_seqs[kfv - 1], lambda kfv: None,
                                     gap_open_score, gap_extend_score, align_vec if get_aligns else None)
             ctx.scan(genome, _lib.MODE_OMN, int(buff), int(genome_pos), flags, cb)
-        for h in ctx.hits():
+        hits = ctx.hits()
+        bodies = view.subseqs((h["contig"], h["lo"], h["hi"]) for h in hits)
+        for h, body in zip(hits, bodies):
             c = h["contig"]
             hdr = headers.omn_header(view.identifier(c), h["dist"], h["kfv"], h["lo"], h["hi"], h["genome_pos"])
-            resultVec.append(Record(hdr, view.subseq(c, h["lo"], h["hi"])))
+            resultVec.append(Record(hdr, body))
             if get_hit_loci and hit_loci_vec is not None:
                 hit_loci_vec.append(h["lo"] + h["genome_pos"])
         if do_return_dists and dist_vec_vec is not None:

@@ -901,3 +901,19 @@ def test_lazy_bit_planes_follow_pokes_and_repacks(ctx, alp_ref, genes, monkeypat
     monkeypatch.delenv("KGMA_KERNEL")
     assert n1 >= 1
     g.free()
+
+
+def test_fetch_batch_matches_single_fetches(ctx):
+    """kgma_genome_fetch_batch: ranges of several records, empty ranges, a whole record, back to back in the output."""
+    rng = np.random.default_rng(5)
+    contigs = [random_dna(rng, 5000), random_dna(rng, 33), random_dna(rng, 70000)]
+    g = ctx.genome_from_host(contigs)
+    ranges = [(2, 1, 70000), (0, 10, 289), (1, 1, 33), (0, 5000, 1), (2, 69990, 0), (0, 1, 5000), (2, 31, 64)]
+    ranges += [(int(c), int(p), int(n)) for c, p, n in zip(rng.integers(0, 3, 300), rng.integers(1, 30, 300), rng.integers(0, 4, 300))]
+    got = g.fetch_batch(ranges)
+    assert got == [contigs[c][p - 1:p - 1 + n] for c, p, n in ranges]
+    assert got == [g.fetch(c, p, n) for c, p, n in ranges]
+    with pytest.raises(_lib.KgmaError):
+        g.fetch_batch([(0, 1, 10), (1, 30, 5)])            # the second range leaves its record
+    assert g.fetch_batch([]) == []
+    g.free()
