@@ -26,6 +26,8 @@ def main():
         KFVs.append(RV); ws.append(w); N.append(n)
     ctx = _lib.Context(0)
     thr = [float(t) for t in refprep.estimate_optimal_threshold(KFVs, ws, buffer=7, num_trials=20)]
+    if os.environ.get("GROUP_AB_THR"):                                 # experiments: one threshold for every KFV
+        thr = [float(os.environ["GROUP_AB_THR"])] * len(ws)
     ctx.set_refs(k, KFVs, ws, thr, N)
     bases = 400_000_000
     gen = ctx.genome_synthetic([bases], 7)
