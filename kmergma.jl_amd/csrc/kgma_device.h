@@ -96,7 +96,8 @@ struct ScanArgs {
 
 // Count-table stream kernel (kgma_stream.hip): one wave per stream of consecutive window starts.
 constexpr int KGMA_STREAM_MIN_WINDOWS = 2048;                  // shorter streams waste their warm-up (n k-mers)
-constexpr int KGMA_STREAM_MAX_WINDOWS = 1 << 20;
+constexpr int KGMA_STREAM_MAX_WINDOWS = 1 << 19;               // longer genomes take more rounds (100 Gb, one KFV: 24 rounds of 509 k windows
+                                                               // 155.1 ms, 12 rounds of 1 M windows 157.3 ms, 48 rounds 154.5 ms)
 constexpr int KGMA_STREAM_MAX_K = 7;                           // 4^k 16-bit counters per wave must fit the LDS
 
 // Aux region of the result block: residues under tied minima, gathered on the device (export_kernel)
