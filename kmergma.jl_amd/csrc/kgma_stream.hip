@@ -633,8 +633,10 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
     };
     prefetch(0);
     const int neg_lane = -lane;
-    uint32_t one = 1u;
-    asm volatile("" : "+v"(one));
+    uint32_t one = 1u, mone = ~0u;
+    asm volatile("" : "+v"(one), "+v"(mone));
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t cbase = (uint32_t)uni((int)(uint32_t)(uintptr_t)(lds_u32 *)C);   // LDS byte offset of this wave's count table
 
     // the stream's first window of KFV j has distance D0: thresholds in E units
     auto set_first_window = [&](const int j, int32_t *st, const int64_t D0) {
@@ -727,8 +729,13 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
                 else { Sr[j] = sTab32[(size_t)j * NB + kp]; Sl[j] = sTab32[(size_t)j * NB + ks]; }
             }
         }
-        const uint8_t *Cb = reinterpret_cast<const uint8_t *>(C);
-        uint32_t cp = Cb[kp], cs = Cb[ks];                            // counts at the start of the step (raw bytes)
+        // LDS byte addresses of the two counters (explicit LDS pointers: the dword address of the atomic is the byte
+        // address with its low bits cleared -- one instruction instead of a second address calculation)
+        const uint32_t ap = cbase + kp, as = cbase + ks;
+        // counts at the start of the step (raw bytes).  Issued in assembly: the compiler masks the result of a byte load it
+        // issues itself (two v_and per step); the LDS returns in order, so the wait for the atomics below covers these.
+        uint32_t cp, cs;
+        asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %3" : "=&v"(cp), "=&v"(cs) : "v"(ap), "v"(as));
         const uint32_t shp = 8u * (kp & 3u), shs = 8u * (ks & 3u);
         // this lane's transition; the old values tell whether another lane touched the k-mer.  Lanes without a
         // transition (left == right: homopolymer / N runs) issue nothing: 64 lanes adding 0 to one address would
@@ -736,8 +743,11 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
         // (lanes that issue nothing keep whatever the registers hold: their bits of the pending masks are cleared by AE / AL)
         uint32_t wop, wos;
         asm volatile("" : "=v"(wop), "=v"(wos));
-        if (actE) wop = atomicAdd(&C[kp >> 2], one << shp);           // (`one` lives in a vector register: v_lshlrev in its short form)
-        if (actL) wos = atomicSub(&C[ks >> 2], one << shs);
+        // (`one` and `mone` = -1 live in vector registers: v_lshlrev in its short form, and the subtraction is an add of
+        //  -(1 << shift) = (-1) << shift without a negation)
+        if (actE) wop = __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)(ap & ~3u), one << shp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (actL) wos = __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)(as & ~3u), mone << shs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cp), "+v"(cs), "+v"(wop), "+v"(wos));   // (the byte loads are not known to the compiler's counters)
 
         // ---- exact counts of the entering / leaving k-mer in THIS lane's window ---------------------
         int32_t cP, cS;
@@ -795,8 +805,20 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
             cP = (int32_t)cp + corrP;
             cS = (int32_t)cs + corrS;
         }
-        // left == right: same k-mer, same count, difference 0; otherwise c[l] - 1 - c[r]
-        const int32_t dd = cS - cP - (differ ? 1 : 0);
+        // left == right: same k-mer, same count, difference 0; otherwise c[l] - 1 - c[r]  (the -1 rides as the borrow of
+        // the subtraction of the two start-of-step counts)
+        int32_t dd;
+        if constexpr (GENERIC) {
+            dd = cS - cP - (differ ? 1 : 0);
+        } else {
+            // (steady steps: AE is the mask of the lanes with a transition, or all ones when every lane acts -- then the
+            //  two counts of a lane without a transition are equal and its difference must stay 0)
+            uint32_t d0;
+            uint64_t borrow_out;
+            const uint64_t DIFF = DERIVE ? __builtin_amdgcn_uicmp(kp, ks, 33 /* ne */) : AE;
+            asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(d0), "=s"(borrow_out) : "v"(cs), "v"(cp), "s"(DIFF));
+            dd = (int32_t)d0 + (cS - (int32_t)cs) - (cP - (int32_t)cp);
+        }
         // ---- per KFV (all of this launch's KFVs have the same window: same k-mers, same counts) ----------------
         // Phase 1: e of every KFV (and, in warm-up steps, the first-window D)
         int32_t sc[NKFV], ev[DERIVE ? NKFV : 1];
@@ -809,7 +831,14 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
             const int32_t Nj = gp.N[j];
             // GenomeMiner.jl:67-68 times 2kN^2 / 2N.  Without a transition the two k-mers are equal (Sl == Sr,
             // dd == 0) except in the warm-up, where there is no leaving k-mer at all.
-            int32_t e = Sl[j] - Sr[j] - __mul24(Nj, dd);
+            int32_t e;
+            if constexpr (NKFV == 1) {
+                int32_t sd = Sl[j] - Sr[j];
+                asm volatile("" : "+v"(sd));                          // (one subtraction on the 16-bit halves, then one multiply-add)
+                e = __mul24(-Nj, dd) + sd;
+            } else {
+                e = Sl[j] - Sr[j] - __mul24(Nj, dd);
+            }
             if constexpr (GENERIC) e = actL ? e : 0;
             sc[j] = e;
             if constexpr (DERIVE) ev[j] = e;
@@ -844,8 +873,16 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
         KGMA_SCAN_STAGE(0x142, 0xA)     // row_bcast:15 -> rows 1,3
         KGMA_SCAN_STAGE(0x143, 0xC)     // row_bcast:31 -> rows 2,3
 #undef KGMA_SCAN_STAGE
+        if constexpr (NKFV == 1) asm volatile("" : "+v"(sc[0]));      // (the last stage stays one DPP add; the carry is one more add)
         // Phase 3: thresholds; one combined test decides whether any KFV has a dip in this step
-        const int q = p - nk + 1;                                     // window start (local) this transition leads to
+        // window start (local) this transition leads to.  Steady steps need it in the cold paths only (distances, records):
+        // there it is formed from an opaque copy of the step number, so that it is not computed in every step
+        int q = 0;
+        if constexpr (GENERIC) q = p - nk + 1;
+        auto q_cold = [&]() {
+            if constexpr (GENERIC) return q;
+            else { int bb = b; asm volatile("" : "+s"(bb)); return (bb << 6) + lane - nk + 1; }
+        };
         bool tested = true, tested_d = true;                           // (tested_d: KFVs with a derived window, index q - 1)
         uint64_t TESTED = ~(uint64_t)0, TESTED_D = ~(uint64_t)0;
         if constexpr (GENERIC) {
@@ -892,7 +929,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
                 const int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
                 const int64_t twoN = 2 * (int64_t)gp.N[j];
                 const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
-                a.dist[j][td.dist_base + q - dj] = (double)(D0 + twoN * (int64_t)E[j]) / gpp->inv_scale[j];
+                a.dist[j][td.dist_base + q_cold() - dj] = (double)(D0 + twoN * (int64_t)E[j]) / gpp->inv_scale[j];
             }
         }
         if (anyU == 0 && inrun_mask == 0 && att_mask == 0) return;    // fast path: nothing near any threshold
@@ -922,8 +959,9 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
             if (att) {
                 DevRecord rec;
                 rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8);
-                rec.start = q - dj; rec.end = q - dj; rec.minE = E;
-                rec.argf = rec.argl = q - dj; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
+                const int qa = q_cold() - dj;
+                rec.start = qa; rec.end = qa; rec.minE = E;
+                rec.argf = rec.argl = qa; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
                 emit_global(a, rec);
                 atomicAdd(a.n_att, 1ull);
             }
