@@ -252,9 +252,10 @@ def main():
                          "pack_kernel": {"kernel_ms": round(avg_pack_ms, 4), "algorithmic_bytes": PACK_BYTES_PER_BASE * my_bases,
                                          "achieved_GBps": round(PACK_BYTES_PER_BASE * my_bases / (avg_pack_ms * 1e-3) / 1e9, 1),
                                          "frac_of_hbm_peak": round(PACK_BYTES_PER_BASE * my_bases / (avg_pack_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                         "binding_note": "the scan moves 0.25 B per base: its binding resources are VALU issue and LDS latency, "
-                                         "not HBM (DESIGN.md section 4; `pmc` holds VALU instructions per cycle per SIMD: "
-                                         "0.21-0.24 is what gfx950 issues of 3-operand forms, 0.38-0.41 of 2-operand ones, "
+                         "binding_note": "the scan moves 0.25 B per base: its binding resources are the LDS pipe (six instructions "
+                                         "per step with 64 random addresses each: `pmc.lds_active_fraction_of_kernel`, most of it bank "
+                                         "conflicts) and VALU issue, not HBM (DESIGN.md section 4; `pmc` holds VALU instructions per cycle "
+                                         "per SIMD: 0.21-0.24 is what gfx950 issues of 3-operand forms, 0.38-0.41 of 2-operand ones, "
                                          "profiles/r01_valu_issue_rates.txt); the pack kernel is the HBM-bound one"},
         }
         if world == 1 and not args.no_secondary:
