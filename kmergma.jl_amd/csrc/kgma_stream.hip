@@ -831,14 +831,9 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
             const int32_t Nj = gp.N[j];
             // GenomeMiner.jl:67-68 times 2kN^2 / 2N.  Without a transition the two k-mers are equal (Sl == Sr,
             // dd == 0) except in the warm-up, where there is no leaving k-mer at all.
-            int32_t e;
-            if constexpr (NKFV == 1) {
-                int32_t sd = Sl[j] - Sr[j];
-                asm volatile("" : "+v"(sd));                          // (one subtraction on the 16-bit halves, then one multiply-add)
-                e = __mul24(-Nj, dd) + sd;
-            } else {
-                e = Sl[j] - Sr[j] - __mul24(Nj, dd);
-            }
+            int32_t sd = Sl[j] - Sr[j];
+            asm volatile("" : "+v"(sd));                              // (one subtraction on the 16-bit halves, then one multiply-add)
+            int32_t e = __mul24(-Nj, dd) + sd;
             if constexpr (GENERIC) e = actL ? e : 0;
             sc[j] = e;
             if constexpr (DERIVE) ev[j] = e;
@@ -873,7 +868,8 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
         KGMA_SCAN_STAGE(0x142, 0xA)     // row_bcast:15 -> rows 1,3
         KGMA_SCAN_STAGE(0x143, 0xC)     // row_bcast:31 -> rows 2,3
 #undef KGMA_SCAN_STAGE
-        if constexpr (NKFV == 1) asm volatile("" : "+v"(sc[0]));      // (the last stage stays one DPP add; the carry is one more add)
+#pragma unroll
+        for (int j = 0; j < NKFV; j++) asm volatile("" : "+v"(sc[j]));   // (the last stage stays one DPP add; the carry is one more add)
         // Phase 3: thresholds; one combined test decides whether any KFV has a dip in this step
         // window start (local) this transition leads to.  Steady steps need it in the cold paths only (distances, records):
         // there it is formed from an opaque copy of the step number, so that it is not computed in every step
