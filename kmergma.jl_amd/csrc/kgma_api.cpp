@@ -1960,6 +1960,8 @@ struct TieResolver {
     }
 
     struct Result { bool ok, sensitive, improved; int64_t pos; };
+    int64_t n_calls = 0, n_fetches = 0, n_windows = 0;          // KGMA_TIE_DEBUG: what the replays cost
+    double fetch_ms = 0;
 
     // Replays windows p_from .. cand_hi of record `contig` for KFV `kfv` (0-based).  The chain value
     // at p_from stands for the running minimum (exact value D_from).  Candidates are the windows in
@@ -1979,7 +1981,10 @@ struct TieResolver {
         const int64_t nbases = (cand_hi - p_from) + W;
         if (p_from - 1 + nbases > (g ? g->cd[(size_t)contig].len : ctx->contig_len[(size_t)contig])) return r;
         const uint8_t *seq = residues;
+        n_calls++; n_windows += cand_hi - p_from;
         if (!seq) {
+            const double tf0 = now_ms();
+            n_fetches++;
             seqbuf.resize((size_t)nbases);
             if (g) {
                 (void)hipSetDevice(ctx->device);
@@ -1989,6 +1994,7 @@ struct TieResolver {
                 return r;                                   // the caller's residue source could not deliver
             }
             seq = seqbuf.data();
+            fetch_ms += now_ms() - tf0;
         }
         if (cnt.empty()) cnt.assign((size_t)NB, 0);
         touched.clear();
@@ -2025,9 +2031,19 @@ struct TieResolver {
                 const double sum = dist + inc;
                 const double bb = sum - dist;                          // TwoSum: exact error of the addition
                 const double err = (dist - (sum - bb)) + (inc - bb);
-                int es;
-                (void)std::frexp(sum, &es);
-                if (std::fabs(err) == std::ldexp(1.0, es - 54) || es != e0) sensitive = true;
+                // exponent of the sum as frexp counts it, and half an ulp of its binade, from the bits (the distance is a
+                // positive normal number; anything else is treated as rounding-sensitive)
+                uint64_t sbits;
+                memcpy(&sbits, &sum, sizeof sbits);
+                const int ef = (int)((sbits >> 52) & 0x7FF);
+                if (ef == 0 || ef == 0x7FF || (sbits >> 63)) sensitive = true;
+                else {
+                    const int es = ef - 1022;
+                    const uint64_t hbits = (uint64_t)(ef - 53) << 52;          // 2^(es - 54)
+                    double half_ulp;
+                    memcpy(&half_ulp, &hbits, sizeof half_ulp);
+                    if (ef <= 53 || std::fabs(err) == half_ulp || es != e0) sensitive = true;
+                }
                 dist = sum;
                 D += 2 * N * N + 2 * N * ((f.S[(size_t)left] - N * cl) - (f.S[(size_t)right] - N * cr));
                 if (cnt[(size_t)right]++ == 0) touched.push_back((uint32_t)right);
@@ -2246,6 +2262,9 @@ static int replay_hits(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_
     for (const kgma_dip &dd : ctx->dips) ctx->stats.n_tie_flagged += (dd.flags & KGMA_HIT_TIE) ? 1 : 0;
     (void)n_resolved; (void)n_ambiguous;
     ctx->stats.replay_ms = now_ms() - t0;
+    if (getenv("KGMA_TIE_DEBUG"))
+        fprintf(stderr, "tie resolver: %lld replays (%lld with their own residue download: %.2f ms), %lld windows walked; replay %.2f ms\n",
+                (long long)tr.n_calls, (long long)tr.n_fetches, tr.fetch_ms, (long long)tr.n_windows, ctx->stats.replay_ms);
     return KGMA_OK;
 }
 
