@@ -736,7 +736,12 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
         // issues itself (two v_and per step); the LDS returns in order, so the wait for the atomics below covers these.
         uint32_t cp, cs;
         asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %3" : "=&v"(cp), "=&v"(cs) : "v"(ap), "v"(as));
-        const uint32_t shp = 8u * (kp & 3u), shs = 8u * (ks & 3u);
+        // shift amounts 8 * (k-mer & 3): the shifter and the bit-field extract read the low five bits of their amount, so
+        // the k-mer times 8 serves unmasked -- in assembly, because C would have the mask back
+        const uint32_t shp = kp << 3, shs = ks << 3;
+        uint32_t addv, subv;
+        asm("v_lshlrev_b32 %0, %1, %2" : "=v"(addv) : "v"(shp), "v"(one));
+        asm("v_lshlrev_b32 %0, %1, %2" : "=v"(subv) : "v"(shs), "v"(mone));
         // this lane's transition; the old values tell whether another lane touched the k-mer.  Lanes without a
         // transition (left == right: homopolymer / N runs) issue nothing: 64 lanes adding 0 to one address would
         // serialise in the LDS for nothing
@@ -745,14 +750,16 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
         asm volatile("" : "=v"(wop), "=v"(wos));
         // (`one` and `mone` = -1 live in vector registers: v_lshlrev in its short form, and the subtraction is an add of
         //  -(1 << shift) = (-1) << shift without a negation)
-        if (actE) wop = __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)(ap & ~3u), one << shp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (actL) wos = __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)(as & ~3u), mone << shs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (actE) wop = __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)(ap & ~3u), addv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (actL) wos = __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)(as & ~3u), subv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cp), "+v"(cs), "+v"(wop), "+v"(wos));   // (the byte loads are not known to the compiler's counters)
 
         // ---- exact counts of the entering / leaving k-mer in THIS lane's window ---------------------
         int32_t cP, cS;
         {
-            const uint32_t oldp = (wop >> shp) & 0xFFu, olds = (wos >> shs) & 0xFFu;
+            uint32_t oldp, olds;
+            asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(oldp) : "v"(wop), "v"(shp));
+            asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(olds) : "v"(wos), "v"(shs));
             uint64_t pendE = __builtin_amdgcn_uicmp(oldp, cp, 33 /* ne */) & AE;
             uint64_t pendL = __builtin_amdgcn_uicmp(olds, cs, 33 /* ne */) & AL;
             const uint64_t cand0 = __builtin_amdgcn_uicmp(cp, 127u, 34 /* ugt */);
