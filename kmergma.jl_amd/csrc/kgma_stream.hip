@@ -637,6 +637,11 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
     asm volatile("" : "+v"(one), "+v"(mone));
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     const uint32_t cbase = (uint32_t)uni((int)(uint32_t)(uintptr_t)(lds_u32 *)C);   // LDS byte offset of this wave's count table
+    constexpr bool KBASED = NKFV == 1 && !SGLOBAL;                    // (per-wave stride = table size, tables in front: aligned)
+    uint32_t kmask = (uint32_t)(NB - 1);
+    asm volatile("" : "+v"(kmask));                                   // (a vector register: the and-or has one scalar operand left for the base)
+    const uint32_t kbase = KBASED ? cbase : 0u;
+    const uint32_t sbase = (uint32_t)uni((int)(uint32_t)(uintptr_t)(lds_u32 *)smem);   // LDS byte offset of the S tables (0: the kernel has no static LDS)
 
     // the stream's first window of KFV j has distance D0: thresholds in E units
     auto set_first_window = [&](const int j, int32_t *st, const int64_t D0) {
@@ -662,8 +667,11 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
     auto step = [&](const int b, auto generic_tag) {
         constexpr bool GENERIC = decltype(generic_tag)::value;
         const int p = (b << 6) + lane;
-        uint32_t kp = __builtin_amdgcn_alignbit(pe.y, pe.x, e_sh) & (uint32_t)(NB - 1);
-        uint32_t ks = __builtin_amdgcn_alignbit(pl.y, pl.x, l_sh) & (uint32_t)(NB - 1);
+        // One KFV, tables in LDS: the wave's count table starts at a multiple of its size, so the k-mer is formed WITH that
+        // base in its high bits (one and-or) and serves as the counter's LDS address as it is; everything that compares
+        // k-mers compares these, the S address takes the base off again inside its shift-add.
+        uint32_t kp = (__builtin_amdgcn_alignbit(pe.y, pe.x, e_sh) & kmask) | kbase;
+        uint32_t ks = (__builtin_amdgcn_alignbit(pl.y, pl.x, l_sh) & kmask) | kbase;
         asm volatile("" : "+v"(kp), "+v"(ks));                        // the k-mers are cut before the loads below overwrite their words
         // (the plane array is padded past the last record; b + 1 >= b_warm makes every leaving word index >= 0)
         if constexpr (GENERIC) { if (4 * (b + 1) + lw_min >= 0) prefetch_steady(b + 1); else prefetch(b + 1); }
@@ -725,13 +733,25 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
             for (int j = 0; j < NKFV; j++) {
                 Sr[j] = Sl[j] = 0;
                 if (j >= n_kfv) continue;
-                if constexpr (S16) { Sr[j] = sTab16[(size_t)j * NB + kp]; Sl[j] = sTab16[(size_t)j * NB + ks]; }
+                if constexpr (KBASED) {
+                    // table address = (k-mer with base) * entry size - base * entry size (the S tables start at LDS offset 0)
+                    typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
+                    typedef __attribute__((address_space(3))) const int32_t lds_ci32;
+                    if constexpr (S16) {
+                        Sr[j] = *(lds_cu16 *)(uintptr_t)((kp << 1) + (sbase - 2u * kbase));
+                        Sl[j] = *(lds_cu16 *)(uintptr_t)((ks << 1) + (sbase - 2u * kbase));
+                    } else {
+                        Sr[j] = *(lds_ci32 *)(uintptr_t)((kp << 2) + (sbase - 4u * kbase));
+                        Sl[j] = *(lds_ci32 *)(uintptr_t)((ks << 2) + (sbase - 4u * kbase));
+                    }
+                }
+                else if constexpr (S16) { Sr[j] = sTab16[(size_t)j * NB + kp]; Sl[j] = sTab16[(size_t)j * NB + ks]; }
                 else { Sr[j] = sTab32[(size_t)j * NB + kp]; Sl[j] = sTab32[(size_t)j * NB + ks]; }
             }
         }
         // LDS byte addresses of the two counters (explicit LDS pointers: the dword address of the atomic is the byte
         // address with its low bits cleared -- one instruction instead of a second address calculation)
-        const uint32_t ap = cbase + kp, as = cbase + ks;
+        const uint32_t ap = KBASED ? kp : cbase + kp, as = KBASED ? ks : cbase + ks;
         // counts at the start of the step (raw bytes).  Issued in assembly: the compiler masks the result of a byte load it
         // issues itself (two v_and per step); the LDS returns in order, so the wait for the atomics below covers these.
         uint32_t cp, cs;
@@ -1183,8 +1203,15 @@ void stream8_geometry(int k, bool s16, int nkfv, int nd, int *nw_out, int *block
             if (blocks * nw > 32) blocks = 32 / nw;
             if (blocks * nw > best_blocks * best_nw) { best_blocks = blocks; best_nw = nw; }
         }
+        {
+            // the one-KFV kernels fold the LDS base of a wave's count table into the k-mers: the dynamic LDS must start at
+            // offset 0 (no static LDS in the kernel), or the tables would not sit at multiples of their size
+            hipFuncAttributes fa;
+            if (hipFuncGetAttributes(&fa, stream8_fn_of(k, s16, nkfv, nd)) == hipSuccess && fa.sharedSizeBytes != 0) best_nw = best_blocks = 0;
+        }
         (void)hipGetLastError();
         c[0] = best_nw > 0 ? best_nw : 4; c[1] = best_blocks > 0 ? best_blocks : 1;
+        if (best_nw == 0) c[0] = -1;                                  // (refused: launch_stream8 reports an error)
     }
     *nw_out = c[0]; *blocks_out = c[1];
 }
@@ -1231,6 +1258,7 @@ static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp_in, hi
     const int nkfv = stream8_variant(gp.n_kfv);
     int nw = 16, blocks = 1;
     stream8_geometry(gp.k, s16, nkfv, derive, &nw, &blocks);
+    if (nw < 1) return hipErrorInvalidConfiguration;                  // (static LDS in the kernel: see stream8_geometry)
     // all launches of a scan share one stream table, sized for the launch that keeps the fewest streams resident:
     // use workgroups that fill exactly that many wave slots per CU, so that every CU gets the same number of streams
     if (gp.stream_slots > 0 && gp.stream_slots < nw * blocks) {
