@@ -917,3 +917,45 @@ def test_fetch_batch_matches_single_fetches(ctx):
         g.fetch_batch([(0, 1, 10), (1, 30, 5)])            # the second range leaves its record
     assert g.fetch_batch([]) == []
     g.free()
+
+
+@pytest.mark.parametrize("k", [5, 6])
+def test_stream8_int32_s_tables(ctx, k):
+    """S entries beyond int16 (many reference sequences with a long homopolymer: S = N x count > 32767): the 8-bit
+    stream kernel keeps such tables as int32 in LDS -- one KFV and two KFVs of one window size, every distance against
+    the integer oracle."""
+    from kmergma_amd.fasta import Record
+    from tests.helpers import mutate
+    rng = np.random.default_rng(600 + k)
+    L = 200
+    base = bytearray(random_dna(rng, L))
+    base[40:140] = b"A" * 100                                        # ~95 copies of the all-A k-mer per sequence
+    base = bytes(base)
+    KFVs, ws, S, N = [], [], [], []
+    for n_seq in (420, 380):
+        refs = [Record(f"r{i}", base) for i in range(n_seq)]
+        RV, w, cons, (s, n) = refprep.gen_ref_ws_cons(refs, k, return_int=True)
+        assert int(np.max(s)) > 32767 and w == L
+        KFVs.append(RV); ws.append(w); S.append(s); N.append(n)
+    g = bytearray(random_dna(rng, 120_000))
+    for pos in (5000, 40_000, 90_000):
+        g[pos:pos + L] = mutate(rng, base, 0.05)[:L]
+    g[60_000:60_400] = b"A" * 400
+    contigs = [bytes(g), random_dna(rng, 3000)]
+    thr1 = float(np.median([orc.kmer_dist_kfv(random_dna(rng, L), KFVs[0], k) for _ in range(10)])) * 0.7
+    ref = dict(RV=KFVs[0], ws=L, S=S[0], N=N[0], k=k)
+    _assert_single_parity(ctx, contigs, ref, thr1)
+    assert ctx.kernel_name().startswith("stream8_kernel")
+    thr = [thr1, thr1]
+    T = [orc.int_threshold(t, k, n) for t, n in zip(thr, N)]
+    ctx.set_refs(k, KFVs, ws, thr, N)
+    gen = ctx.genome_from_host(contigs)
+    ctx.scan(gen, _lib.MODE_OMN, 50, 0, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
+    assert ctx.kernel_name().startswith("stream8_kernel")
+    hits = ctx.hits()
+    dists = [ctx.dists(j + 1) for j in range(2)]
+    gen.free()
+    ohi, oD = orc.omn_scan_int(contigs, S, N, k, ws, T, 50, 0, return_D=True)
+    assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi] and len(ohi) > 0
+    for j in range(2):
+        assert np.array_equal(dists[j], oD[j] / (2.0 * k * N[j] ** 2))
