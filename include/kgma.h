@@ -139,6 +139,12 @@ typedef struct {
     double chain_ms;           /* host time of the Float64 chain replay (KGMA_F_CHAIN_REPLAY), 0 if none ran   */
     int64_t n_chain_pairs;     /* (record, KFV) pairs it re-ran                                                */
     int64_t chain_windows;     /* windows it walked (sum over the pairs)                                       */
+    int64_t chain_device_pairs;/* ... of them walked by the chain kernel on the device (the rest: host threads)         */
+    double chain_device_ms;    /* device time of the chain kernels (hipEvents; part of chain_ms)                      */
+    int64_t chain_raw_steps;   /* 64-window steps whose increments the host added one by one (wanted windows, binade
+                                  changes); every other step reached the host as part of one integer add per chunk    */
+    double chain_max_drift;    /* largest |chain value - exact distance| / exact distance seen at a stream start (the
+                                  device chain is only used while this stays below 2^-31; the guard bands are 2^-29/30) */
 } kgma_stats;
 
 /* Host-side stand-in for `pairalign` + `cigar_to_UnitRange` (src/Alignment.jl:33-52,
@@ -269,6 +275,23 @@ int kgma_host_semiglobal_cigar(const uint8_t *a, int64_t m, const uint8_t *b, in
 int kgma_host_chain_values(const uint8_t *seq, int64_t len, const double *ref, int32_t k, int64_t windowsize,
                            const int64_t *win_lo, const int64_t *win_hi, int64_t n_intervals, double *out, int64_t cap,
                            int64_t *n_out);
+
+/* The reference's running Float64 distance of record `contig` for KFV `kfv` (1-based) at the windows of the given intervals
+ * (1-based window starts, sorted, disjoint) -- kgma_host_chain_values computed by the chain kernel on the resident genome:
+ * what KGMA_F_CHAIN_REPLAY runs for its (record, KFV) pairs.  Window 1's value is the first window's
+ * ScaleFactor * 0.5 * sqeuclidean (summed left to right on the host); every later value is bit for bit what a sequential
+ * IEEE-754 evaluation of src/GenomeMiner.jl:70-72 gives.  KGMA_E_UNSUPPORTED when the chain kernel does not serve the KFV
+ * (k = 5 or 6, at most 383 k-mers per window, KFV bit-identical to S * (1/N)).  Two-call pattern via cap / *n_out. */
+int kgma_chain_values(kgma_ctx *ctx, const kgma_genome *genome, int64_t contig, int32_t kfv, const int64_t *win_lo,
+                      const int64_t *win_hi, int64_t n_intervals, double *out, int64_t cap, int64_t *n_out);
+
+/* HOST half of the device chain, exposed for tests: walks caller-supplied chunk records (the layout of
+ * kgma_device.h's ChainChunk: int64 A0, uint32 info, uint32 raw) and raw increments exactly as the product does with
+ * the kernel's output.  KGMA_E_STATE: the value drifted more than 2^-31 from the exact distance at a stream start. */
+int kgma_host_chain_walk(double first, double scale, int32_t nk, int64_t n_streams, const int64_t *win0, const int32_t *n_valid,
+                         const int64_t *chunk_base, const int64_t *D0, const void *chunks, int64_t n_chunks, const double *raw,
+                         int64_t raw_slots, const int64_t *win_lo, const int64_t *win_hi, int64_t n_intervals, double *out,
+                         int64_t cap, int64_t *n_out, double *max_drift);
 
 /* ---- scans sharded INSIDE a record (one process per GPU; kmergma_amd.parallel.scan_sharded) ----------
  * A rank scans its slice of the records with kgma_scan_device, decides the ties that need its residues

@@ -42,6 +42,9 @@ bool stream8_derive_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_
 bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16);
 int stream8_variant(int n_kfv);
 hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
+bool chain_applies(int k, int nk, int64_t n_ref);
+int chain_slots_per_cu(int k, bool s16);
+hipError_t launch_chain(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 int pos_tables_per_pass(int k);
 int64_t align_trace_bytes(int m, int n);
 hipError_t launch_align(const uint8_t *ascii, const AlignJob *jobs, int n_jobs, const uint8_t *cons, int m, int go, int ge,
@@ -79,6 +82,9 @@ struct KfvInfo {
     int64_t Smax = 0;
     std::vector<int64_t> S;   // natural k-mer order
     std::vector<double> ref;  // the KFV as given (Float64), for the tie resolver
+    int ref_form = -1;        // how the Float64 entries follow from S, bit for bit, so that the device can form them from S (the chain
+                              // kernel does): 0 = RN(S * RN(1/N)) (`answer .* (1/N)`, src/ReferenceGeneration.jl:35,40), 1 = RN(S / N)
+                              // (`KFVs[i] ./= lens[i]`, :118) reproduced by the kernel's own division step, -1 = neither
 };
 
 struct Group {
@@ -138,6 +144,15 @@ struct kgma_ctx {
     char kernel_name[48] = "";
     uint8_t *d_gath = nullptr, *h_gath = nullptr; size_t gath_cap = 0;   // tie-replay residue gather: [desc | residues]
     uint32_t *h_chain = nullptr; size_t chain_cap = 0;                   // chain replay: pinned copy of the records' 2-bit codes (dwords)
+    // chain on the device (stream8_kernel<..., CHAIN>): stream table, chunk records, raw increments, hot-chunk bits,
+    // first-window D per stream, {raw cursor, status}; one pinned mirror for what comes back
+    TileDesc *d_ctiles = nullptr; int64_t ctiles_cap = 0;
+    ChainChunk *d_cchunks = nullptr; int64_t cchunks_cap = 0;
+    double *d_craw = nullptr; int64_t craw_cap = 0;                      // doubles
+    uint32_t *d_chot = nullptr; int64_t chot_cap = 0;
+    int64_t *d_cD0 = nullptr; int64_t cD0_cap = 0;
+    unsigned int *d_cctl = nullptr;
+    uint8_t *h_cpin = nullptr; size_t cpin_cap = 0;
     uint64_t next_uid = 1;
     // key of the tile table currently on the device
     uint64_t tk_uid = 0; int tk_mode = -1, tk_version = 0, tk_k = 0; int64_t tk_maxws = 0;
@@ -464,6 +479,13 @@ void kgma_destroy(kgma_ctx *ctx)
     if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->h_gath) (void)hipHostFree(ctx->h_gath);
     if (ctx->h_chain) (void)hipHostFree(ctx->h_chain);
+    if (ctx->d_ctiles) (void)hipFree(ctx->d_ctiles);
+    if (ctx->d_cchunks) (void)hipFree(ctx->d_cchunks);
+    if (ctx->d_craw) (void)hipFree(ctx->d_craw);
+    if (ctx->d_chot) (void)hipFree(ctx->d_chot);
+    if (ctx->d_cD0) (void)hipFree(ctx->d_cD0);
+    if (ctx->d_cctl) (void)hipFree(ctx->d_cctl);
+    if (ctx->h_cpin) (void)hipHostFree(ctx->h_cpin);
     if (ctx->d_gath) (void)hipFree(ctx->d_gath);
     if (ctx->evp0) (void)hipEventDestroy(ctx->evp0);
     if (ctx->evp1) (void)hipEventDestroy(ctx->evp1);
@@ -745,6 +767,16 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
             return fail(ctx, KGMA_E_UNSUPPORTED, "KFV %d: N = %lld with %lld k-mers per window exceeds the int32 range of the device path", j + 1,
                         (long long)N, (long long)nk);
         f.sumS2 = (int64_t)s2;
+        {
+            const double invN = 1.0 / (double)N, Nd = (double)N;
+            bool mul = true, div = true;
+            for (int64_t x = 0; x < NB && (mul || div); x++) {
+                const double Sd = (double)f.S[(size_t)x], q = Sd * invN;
+                mul = mul && r[x] == q;
+                div = div && r[x] == std::fma(std::fma(-q, Nd, Sd), invN, q) && r[x] == Sd / Nd;
+            }
+            f.ref_form = mul ? 0 : (div ? 1 : -1);
+        }
         f.thr = thr[j];
         threshold_band(thr[j], k, N, &f.T, &f.T_hi);
     }
@@ -2269,6 +2301,284 @@ static int replay_hits(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_
 }
 
 // ------------------------------------------------------------------------------------------
+// The chain on the device.  For the given (record, KFV) pairs the reference's running Float64 value is wanted at the
+// windows of `iv`.  stream8_kernel<..., CHAIN> walks windows 1 .. last of every pair in streams of `T` transitions
+// (same count table, same exact counts as the scan), forms each window's Float64 increment in the reference's
+// operation order and reduces it chunk by chunk to what the host needs (kgma_device.h: ChainChunk); the host then
+// walks each pair's chunks in order (kgma_chain.cpp: run_chain_walks) -- an integer add per regular chunk, hardware
+// additions through the chunks that hold a wanted window or may change binade.  Pairs the kernel does not serve
+// (k, window length, a KFV that is not RN(S * (1/N))) or whose walk fails a check are left to the host chain.
+// ------------------------------------------------------------------------------------------
+static void reset_chain_stats(kgma_ctx *ctx)
+{
+    ctx->stats.chain_ms = 0; ctx->stats.n_chain_pairs = 0; ctx->stats.chain_windows = 0;
+    ctx->stats.chain_device_pairs = 0; ctx->stats.chain_device_ms = 0; ctx->stats.chain_raw_steps = 0; ctx->stats.chain_max_drift = 0;
+}
+
+struct ChainPair {
+    int32_t c, j;
+    size_t d0, d1, a0, a1;                 // its dips / guard-band windows in ctx->dips / ctx->att
+    std::vector<ChainInterval> iv;
+    std::vector<double> val;
+    int64_t last;
+};
+
+struct ChainDevInfo { int64_t pairs = 0, windows = 0, raw_steps = 0, streams = 0; double kernel_ms = 0, walk_ms = 0, max_drift = 0; int attempts = 0; };
+
+static bool chain_device_enabled()
+{
+    const char *e = getenv("KGMA_CHAIN");                  // testing: KGMA_CHAIN=host keeps every pair on the host chain
+    return !(e && !strcmp(e, "host"));
+}
+
+static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<ChainPair> &pairs, std::vector<char> &done, ChainDevInfo &info)
+{
+    const int k = ctx->k;
+    const int64_t NB = (int64_t)1 << (2 * k);
+    std::vector<size_t> el;
+    int64_t total_windows = 0;
+    int min_slots = 1 << 20;
+    for (size_t i = 0; i < pairs.size(); i++) {
+        const ChainPair &p = pairs[i];
+        const KfvInfo &f = ctx->kfv[(size_t)p.j];
+        const int nk = (int)(f.W - k + 1);
+        if (!chain_applies(k, nk, f.N) || f.ref_form < 0 || p.last < 2) continue;
+        const int sl = chain_slots_per_cu(k, f.Smax <= 32767);
+        if (sl < 1) continue;
+        min_slots = std::min(min_slots, sl);
+        el.push_back(i);
+        total_windows += p.last;
+    }
+    if (el.empty()) return KGMA_OK;
+    std::stable_sort(el.begin(), el.end(), [&](size_t a, size_t b) { return pairs[a].j < pairs[b].j; });
+    (void)hipSetDevice(ctx->device);
+
+    // transitions per stream: about three rounds of streams over the chip, 64 | T (streams start on plane words),
+    // at most 2^18 (the drift a stream may add stays far below the guard band)
+    int64_t T;
+    {
+        const int64_t slots = (int64_t)std::max(1, ctx->n_cus) * min_slots;
+        T = (total_windows + slots * 3 - 1) / (slots * 3);
+        if (const char *e = getenv("KGMA_CHAIN_STREAM")) T = atoll(e);                         // experiments / tests
+        T = std::min<int64_t>(std::max<int64_t>(((T + 63) / 64) * 64, 1024), (int64_t)1 << 18);
+    }
+    struct Launch { int j; size_t t0, t1; };
+    struct PairStreams { size_t s0, s1; };
+    std::vector<TileDesc> tiles;
+    std::vector<ChainStream> streams;
+    std::vector<PairStreams> ps(el.size());
+    std::vector<Launch> launches;
+    int64_t n_chunks = 0, total_steps = 0;
+    for (size_t u = 0; u < el.size(); u++) {
+        const ChainPair &p = pairs[el[u]];
+        const KfvInfo &f = ctx->kfv[(size_t)p.j];
+        const int nk = (int)(f.W - k + 1);
+        if (launches.empty() || launches.back().j != p.j) launches.push_back(Launch{p.j, tiles.size(), tiles.size()});
+        ps[u].s0 = streams.size();
+        for (int64_t win0 = 1; win0 < p.last; win0 += T) {
+            TileDesc td;
+            td.word_base = g->cd[(size_t)p.c].word_off + (win0 - 1) / 32;
+            td.win0 = win0;
+            td.dist_base = n_chunks;                                   // (chain launches: the stream's first chunk)
+            td.n_valid = (int32_t)std::min<int64_t>(T + 1, p.last - win0 + 1);
+            td.first_test = 0;
+            td.contig = p.c;
+            td.pad = 0;
+            tiles.push_back(td);
+            streams.push_back(ChainStream{win0, n_chunks, 0, td.n_valid, 0});
+            const int64_t nb = ((int64_t)td.n_valid + nk - 1 + 63) >> 6;
+            n_chunks += (nb + KGMA_CHAIN_STEPS - 1) / KGMA_CHAIN_STEPS;
+            total_steps += nb;
+        }
+        ps[u].s1 = streams.size();
+        launches.back().t1 = tiles.size();
+    }
+    const int64_t n_tiles = (int64_t)tiles.size();
+    if (n_tiles > 0x7FFFFFF0ll || n_chunks > 0x7FFFFFF0ll) return KGMA_OK;   // (left to the host chain)
+
+    // hot chunks: every chunk that holds a transition into a wanted window
+    std::vector<uint32_t> hot((size_t)(n_chunks + 31) / 32 + 1, 0u);
+    int64_t hot_chunks = 0;
+    for (size_t u = 0; u < el.size(); u++) {
+        const ChainPair &p = pairs[el[u]];
+        const int nk = (int)(ctx->kfv[(size_t)p.j].W - k + 1);
+        for (const ChainInterval &x : p.iv)
+            for (int64_t w = std::max<int64_t>(x.lo, 2); w <= x.hi; w++) {
+                const int64_t si = (w - 2) / T;
+                const ChainStream &S = streams[ps[u].s0 + (size_t)si];
+                const int64_t pos = (w - S.win0) + nk - 1;
+                const int64_t cid = S.chunk_base + (pos >> (6 + KGMA_CHAIN_STEPS_LOG2));
+                uint32_t &word = hot[(size_t)(cid >> 5)];
+                if (!((word >> (cid & 31)) & 1u)) { word |= 1u << (cid & 31); hot_chunks++; }
+                // (jump to the chunk's end: the windows of one chunk share the bit)
+                const int64_t chunk_last_pos = ((pos >> (6 + KGMA_CHAIN_STEPS_LOG2)) + 1) * (64 * KGMA_CHAIN_STEPS) - 1;
+                const int64_t w_chunk_last = S.win0 + chunk_last_pos - nk + 1;
+                if (w_chunk_last > w) w = std::min(w_chunk_last, std::min<int64_t>(x.hi, S.win0 + S.n_valid - 1));
+            }
+    }
+
+    int rc = dev_reserve(ctx, ctx->d_ctiles, ctx->ctiles_cap, n_tiles);
+    if (rc) return rc;
+    rc = dev_reserve(ctx, ctx->d_cchunks, ctx->cchunks_cap, n_chunks);
+    if (rc) return rc;
+    rc = dev_reserve(ctx, ctx->d_chot, ctx->chot_cap, (int64_t)hot.size());
+    if (rc) return rc;
+    rc = dev_reserve(ctx, ctx->d_cD0, ctx->cD0_cap, n_tiles);
+    if (rc) return rc;
+    if (!ctx->d_cctl) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_cctl), 16));
+
+    // raw pool: the hot chunks, plus room for the chunks that go raw on a binade change; grown once if that was short
+    int64_t raw_slots = hot_chunks * KGMA_CHAIN_STEPS + std::max<int64_t>(1 << 15, total_steps / 16);
+    if (const char *e = getenv("KGMA_CHAIN_RAW_SLOTS")) raw_slots = std::max<int64_t>(1, atoll(e));   // tests: force the regrowth
+    for (int attempt = 0;; attempt++) {
+        info.attempts = attempt + 1;
+        raw_slots = std::min<int64_t>(raw_slots, total_steps + KGMA_CHAIN_STEPS);
+        if (raw_slots > 0xFFFFFFF0ll) return KGMA_OK;
+        if (ctx->craw_cap < raw_slots * 64) {
+            double *fresh = nullptr;
+            int64_t cap = 0;
+            if (dev_reserve(ctx, fresh, cap, raw_slots * 64) != KGMA_OK) { ctx->err.clear(); return KGMA_OK; }   // no room: host chain
+            if (ctx->d_craw) { (void)hipFree(ctx->d_craw); ctx->device_bytes -= ctx->craw_cap * 8; }
+            ctx->d_craw = fresh; ctx->craw_cap = cap;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ctiles, tiles.data(), (size_t)n_tiles * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chot, hot.data(), hot.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_cctl, 0, 16, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        for (const Launch &L : launches) {
+            const KfvInfo &f = ctx->kfv[(size_t)L.j];
+            GroupParams gp;
+            memset(&gp, 0, sizeof gp);
+            ScanArgs a;
+            memset(&a, 0, sizeof a);
+            gp.n_kfv = 1; gp.k = k;
+            gp.nk = gp.nk_min = (int32_t)(f.W - k + 1);
+            gp.n_sizes = 1; gp.sizes[0] = gp.nk; gp.nk_of[0] = gp.nk;
+            gp.kfv_id[0] = 1;                                       // (table and D0 pointers below are this KFV's)
+            gp.N[0] = (int32_t)f.N;
+            gp.sumS2[0] = f.sumS2;
+            gp.inv_scale[0] = 2.0 * (double)k * (double)f.N * (double)f.N;
+            gp.s_fits_i16 = f.Smax <= 32767 ? 1 : 0;
+            a.inter = g->d_inter;
+            a.tiles = ctx->d_ctiles + L.t0;
+            a.n_tiles = (int32_t)(L.t1 - L.t0);
+            a.Stab = ctx->d_Stab + (size_t)L.j * (size_t)NB;
+            a.D0out = ctx->d_cD0 + L.t0;
+            a.n_chunk_tiles = a.n_tiles;
+            a.chain.chunks = ctx->d_cchunks;
+            a.chain.raw = ctx->d_craw;
+            a.chain.raw_cursor = ctx->d_cctl;
+            a.chain.raw_cap = (unsigned int)raw_slots;
+            a.chain.hot = ctx->d_chot;
+            a.chain.invN = 1.0 / (double)f.N;
+            a.chain.Nd = (double)f.N;
+            a.chain.form = f.ref_form;
+            a.chain.SF = 1.0 / (double)k;                           // src/API.jl:86,204
+            a.chain.guard = 1.862645149230957e-09;                  // 2^-29
+            a.chain.status = ctx->d_cctl + 1;
+            HIP_TRY(ctx, launch_chain(a, gp, ctx->stream));
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        unsigned int ctl[4] = {0, 0, 0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(ctl, ctx->d_cctl, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, sync_spin(ctx->stream));
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+        info.kernel_ms += ms;
+        if (!(ctl[1] & 1u)) { raw_slots = std::min<int64_t>(raw_slots, (int64_t)ctl[0]); break; }
+        if (attempt >= 1 || raw_slots >= total_steps) return KGMA_OK;                 // (cannot happen with a full pool)
+        raw_slots = std::max<int64_t>((int64_t)ctl[0] + KGMA_CHAIN_STEPS, total_steps / 2);
+    }
+
+    // ---- download: D0 per stream, chunk records, the used part of the raw pool; the pairs' first residues ----
+    struct Rec { int32_t c; size_t dw_off, dw; };
+    std::vector<Rec> recs;
+    size_t first_dw = 0;
+    for (size_t u = 0; u < el.size(); u++) {
+        const ChainPair &p = pairs[el[u]];
+        const size_t dw = (size_t)((ctx->kfv[(size_t)p.j].W + 15) / 16);
+        auto it = std::find_if(recs.begin(), recs.end(), [&](const Rec &r) { return r.c == p.c; });
+        if (it == recs.end()) recs.push_back(Rec{p.c, 0, dw});
+        else it->dw = std::max(it->dw, dw);
+    }
+    for (Rec &r : recs) { r.dw_off = first_dw; first_dw += r.dw + 2; }
+    const size_t off_D0 = 0, off_chunks = off_D0 + (size_t)n_tiles * 8, off_raw = off_chunks + (size_t)n_chunks * sizeof(ChainChunk),
+                 off_first = off_raw + (size_t)raw_slots * 512, pin_need = off_first + first_dw * 4 + 64;
+    if (pin_need > ctx->cpin_cap) {
+        if (ctx->h_cpin) (void)hipHostFree(ctx->h_cpin);
+        ctx->h_cpin = nullptr; ctx->cpin_cap = 0;
+        const size_t cap = pin_need + (pin_need >> 2);
+        if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_cpin), cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return KGMA_OK; }
+        ctx->cpin_cap = cap;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_D0, ctx->d_cD0, (size_t)n_tiles * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_chunks, ctx->d_cchunks, (size_t)n_chunks * sizeof(ChainChunk), hipMemcpyDeviceToHost, ctx->stream));
+    if (raw_slots > 0)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_raw, ctx->d_craw, (size_t)raw_slots * 512, hipMemcpyDeviceToHost, ctx->stream));
+    for (const Rec &r : recs)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_first + r.dw_off * 4, g->d_inter + 2 * g->cd[(size_t)r.c].word_off, r.dw * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, sync_spin(ctx->stream));
+    const double tw0 = now_ms();
+    const int64_t *h_D0 = reinterpret_cast<const int64_t *>(ctx->h_cpin + off_D0);
+    for (int64_t t = 0; t < n_tiles; t++) streams[(size_t)t].D0 = h_D0[t];
+
+    // the chain's value at window 1: kmer_count! + sqeuclidean of the first window (GenomeMiner.jl:42-47), on the host
+    std::vector<double> first(el.size(), 0.0);
+    {
+        std::vector<ChainJob> jobs(el.size());
+        static const ChainInterval one{1, 1};
+        for (size_t u = 0; u < el.size(); u++) {
+            const ChainPair &p = pairs[el[u]];
+            const KfvInfo &f = ctx->kfv[(size_t)p.j];
+            size_t off = 0;
+            for (const Rec &r : recs) if (r.c == p.c) off = r.dw_off;
+            ChainJob &J = jobs[u];
+            J.seq = nullptr; J.packed = reinterpret_cast<const uint32_t *>(ctx->h_cpin + off_first) + off; J.n_res = f.W; J.ref = f.ref.data();
+            J.k = k; J.W = f.W; J.last_window = 1; J.iv = &one; J.n_iv = 1; J.out = &first[u]; J.n_out = 0; J.ok = false;
+        }
+        run_chain_jobs(jobs.data(), jobs.size(), 1);
+        for (size_t u = 0; u < el.size(); u++)
+            if (!jobs[u].ok) return fail(ctx, KGMA_E_HIP, "internal: first window of record %d KFV %d", pairs[el[u]].c, pairs[el[u]].j + 1);
+    }
+    int n_threads = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("KGMA_CHAIN_THREADS")) n_threads = atoi(e);
+    n_threads = std::max(1, std::min(n_threads, 64));
+    std::vector<ChainWalkJob> walks(el.size());
+    for (size_t u = 0; u < el.size(); u++) {
+        ChainPair &p = pairs[el[u]];
+        const KfvInfo &f = ctx->kfv[(size_t)p.j];
+        ChainWalkJob &J = walks[u];
+        J = ChainWalkJob{};
+        J.first = first[u];
+        J.scale = 2.0 * (double)k * (double)f.N * (double)f.N;
+        J.nk = (int)(f.W - k + 1);
+        J.streams = streams.data() + ps[u].s0; J.n_streams = ps[u].s1 - ps[u].s0;
+        J.chunks = reinterpret_cast<const ChainChunk *>(ctx->h_cpin + off_chunks);
+        J.raw = reinterpret_cast<const double *>(ctx->h_cpin + off_raw);
+        J.raw_slots = raw_slots;
+        J.iv = p.iv.data(); J.n_iv = p.iv.size(); J.out = p.val.data();
+    }
+    run_chain_walks(walks.data(), walks.size(), n_threads);
+    for (size_t u = 0; u < el.size(); u++) {
+        const ChainWalkJob &J = walks[u];
+        info.max_drift = std::max(info.max_drift, J.max_drift);
+        if (J.status != CHAIN_WALK_OK || J.n_out != (int64_t)pairs[el[u]].val.size()) {
+            if (getenv("KGMA_CHAIN_DEBUG"))
+                fprintf(stderr, "chain on the device: record %d KFV %d left to the host (status %d, %lld of %zu values, drift %.3g)\n", pairs[el[u]].c,
+                        pairs[el[u]].j + 1, J.status, (long long)J.n_out, pairs[el[u]].val.size(), J.max_drift);
+            continue;
+        }
+        done[el[u]] = 1;
+        info.pairs++;
+        info.windows += pairs[el[u]].last;
+        info.raw_steps += J.raw_steps;
+    }
+    info.streams = n_tiles;
+    info.walk_ms = now_ms() - tw0;
+    return KGMA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Float64 chain replay (KGMA_F_CHAIN_REPLAY): for the (record, KFV) pairs in which exact arithmetic leaves a
 // decision to the rounding of the reference's running Float64 value, re-run that value from the record's
 // first window (kgma_chain.cpp, host threads) and rebuild the pair's dips from the chain's values at the
@@ -2284,7 +2594,7 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
     const double t0 = now_ms();
     const int k = ctx->k, m = ctx->m;
     const int64_t nc = (int64_t)ctx->contig_len.size();
-    ctx->stats.chain_ms = 0; ctx->stats.n_chain_pairs = 0; ctx->stats.chain_windows = 0;
+    reset_chain_stats(ctx);
     // (A) ties inside one dip are decided where that is provably independent of the chain's history
     {
         TieResolver tr{ctx, g, {}, {}, {}, nullptr, {}, {}};
@@ -2301,7 +2611,7 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
         }
     }
     // ---- select the pairs ------------------------------------------------------------------
-    struct Pair { int32_t c, j; size_t d0, d1, a0, a1; std::vector<ChainInterval> iv; std::vector<double> val; int64_t last; };
+    typedef ChainPair Pair;
     std::vector<Pair> pairs;
     {
         size_t di = 0, ai = 0;
@@ -2377,7 +2687,25 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
         if (p.iv.front().lo < 1 || p.last > nwin) return fail(ctx, KGMA_E_HIP, "internal: chain replay window outside record %d", p.c);
     }
 
-    // ---- run the chains, records in batches of bounded host memory ---------------------------
+    // ---- the chains: on the device where its kernel applies, the rest (and whatever failed a check there) on the host ----
+    std::vector<char> on_device(pairs.size(), 0);
+    ChainDevInfo dev;
+    if (chain_device_enabled()) {
+        const int drc = chain_on_device(ctx, g, pairs, on_device, dev);
+        if (drc) return drc;
+    }
+    ctx->stats.chain_device_pairs = dev.pairs;
+    ctx->stats.chain_device_ms = dev.kernel_ms;
+    ctx->stats.chain_raw_steps = dev.raw_steps;
+    ctx->stats.chain_max_drift = dev.max_drift;
+    if (getenv("KGMA_CHAIN_DEBUG"))
+        fprintf(stderr, "chain on the device: %lld of %zu pairs, %lld windows in %lld streams, kernels %.2f ms (%d attempt(s)), host walk %.2f ms, %lld raw steps, drift <= %.3g\n",
+                (long long)dev.pairs, pairs.size(), (long long)dev.windows, (long long)dev.streams, dev.kernel_ms, dev.attempts, dev.walk_ms,
+                (long long)dev.raw_steps, dev.max_drift);
+    std::vector<Pair *> hostp;
+    for (size_t i = 0; i < pairs.size(); i++)
+        if (!on_device[i]) hostp.push_back(&pairs[i]);
+    // ---- host chains, records in batches of bounded host memory ---------------------------
     int n_threads = (int)std::thread::hardware_concurrency();
     if (const char *e = getenv("KGMA_CHAIN_THREADS")) n_threads = atoi(e);
     n_threads = std::max(1, std::min(n_threads, 64));
@@ -2385,9 +2713,9 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
     int64_t BATCH_BYTES = (int64_t)2 << 30;         // of 2-bit codes: 8 G residues per batch (one batch for a GRCh38-size genome)
     if (const char *e = getenv("KGMA_CHAIN_BATCH_MB")) BATCH_BYTES = std::max<int64_t>(1, atoll(e)) << 20;   // experiments
     size_t pi = 0;
-    int64_t windows = 0;
+    int64_t windows = dev.windows;
     double copy_ms = 0, jobs_ms = 0;
-    while (pi < pairs.size()) {
+    while (pi < hostp.size()) {
         // the records of this batch: their 2-bit codes (the device's interleaved copy: a quarter of the residue text)
         // are copied into one pinned buffer, kept by the context; all pairs of one record share its copy
         struct Rec { int32_t c; size_t p0, p1; int64_t need; size_t dw_off, dw; };
@@ -2395,12 +2723,12 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
         std::vector<ChainJob> jobs;
         int64_t bytes = 0;
         size_t pj = pi, total_dw = 0;
-        while (pj < pairs.size() && (pj == pi || bytes < BATCH_BYTES)) {
-            const int32_t c = pairs[pj].c;
+        while (pj < hostp.size() && (pj == pi || bytes < BATCH_BYTES)) {
+            const int32_t c = hostp[pj]->c;
             size_t pe = pj;
             int64_t need = 0;
-            while (pe < pairs.size() && pairs[pe].c == c) {
-                need = std::max(need, ctx->kfv[(size_t)pairs[pe].j].W + pairs[pe].last - 1);
+            while (pe < hostp.size() && hostp[pe]->c == c) {
+                need = std::max(need, ctx->kfv[(size_t)hostp[pe]->j].W + hostp[pe]->last - 1);
                 pe++;
             }
             need = std::min(need, g->cd[(size_t)c].len);
@@ -2426,7 +2754,7 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
         copy_ms += now_ms() - tc0;
         for (const Rec &r : recs)
             for (size_t u = r.p0; u < r.p1; u++) {
-                Pair &p = pairs[u];
+                Pair &p = *hostp[u];
                 ChainJob J;
                 J.seq = nullptr; J.packed = ctx->h_chain + r.dw_off; J.n_res = r.need; J.ref = ctx->kfv[(size_t)p.j].ref.data(); J.k = k;
                 J.W = ctx->kfv[(size_t)p.j].W; J.last_window = p.last; J.iv = p.iv.data(); J.n_iv = p.iv.size();
@@ -2438,8 +2766,8 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
         run_chain_jobs(jobs.data(), jobs.size(), n_threads);
         jobs_ms += now_ms() - tj0;
         for (size_t u = 0; u < jobs.size(); u++)
-            if (!jobs[u].ok || jobs[u].n_out != (int64_t)pairs[pi + u].val.size())
-                return fail(ctx, KGMA_E_HIP, "internal: chain replay of record %d KFV %d failed", pairs[pi + u].c, pairs[pi + u].j + 1);
+            if (!jobs[u].ok || jobs[u].n_out != (int64_t)hostp[pi + u]->val.size())
+                return fail(ctx, KGMA_E_HIP, "internal: chain replay of record %d KFV %d failed", hostp[pi + u]->c, hostp[pi + u]->j + 1);
         pi = pj;
     }
 
@@ -2524,12 +2852,55 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
 {
     int rc = kgma_scan_device(ctx, g, mode, flags);
     if (rc) return rc;
-    ctx->stats.chain_ms = 0; ctx->stats.n_chain_pairs = 0; ctx->stats.chain_windows = 0;
+    reset_chain_stats(ctx);
     if ((flags & KGMA_F_CHAIN_REPLAY) && !(flags & KGMA_F_NO_TIE_RESOLVE)) {
         rc = chain_decide(ctx, g, mode);
         if (rc) return rc;
     }
     return replay_hits(ctx, g, mode, buff, genome_pos0, flags, align, align_user);
+}
+
+int kgma_chain_values(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int32_t kfv, const int64_t *win_lo, const int64_t *win_hi,
+                      int64_t n_intervals, double *out, int64_t cap, int64_t *n_out)
+{
+    if (!ctx || !g || !win_lo || !win_hi || !n_out || n_intervals < 1) return KGMA_E_ARG;
+    if (ctx->m == 0) return fail(ctx, KGMA_E_STATE, "kgma_set_refs has not been called");
+    if (kfv < 1 || kfv > ctx->m || contig < 0 || contig >= g->n_contigs) return fail(ctx, KGMA_E_ARG, "no such record / KFV");
+    const KfvInfo &f = ctx->kfv[(size_t)(kfv - 1)];
+    const int64_t L = g->cd[(size_t)contig].len, nwin = L - f.W + 1;
+    std::vector<ChainPair> pairs(1);
+    ChainPair &p = pairs[0];
+    p.c = (int32_t)contig; p.j = kfv - 1; p.d0 = p.d1 = p.a0 = p.a1 = 0;
+    int64_t total = 0, prev = 0;
+    for (int64_t i = 0; i < n_intervals; i++) {
+        if (win_lo[i] < 1 || win_hi[i] < win_lo[i] || win_lo[i] <= prev || win_hi[i] > nwin) return fail(ctx, KGMA_E_ARG, "window intervals must be sorted, disjoint and inside the record");
+        p.iv.push_back(ChainInterval{win_lo[i], win_hi[i]});
+        total += win_hi[i] - win_lo[i] + 1;
+        prev = win_hi[i];
+    }
+    *n_out = total;
+    if (!out) return KGMA_OK;
+    if (cap < total) return KGMA_E_ARG;
+    {
+        kgma_genome *gm = const_cast<kgma_genome *>(g);
+        const int src = genome_sync(ctx, gm);
+        if (src) return src;
+        const unsigned long long fb = g->first_bad[(size_t)contig];
+        if (fb != NO_BAD && (int64_t)fb <= f.W + prev - 1)
+            return fail(ctx, KGMA_E_BADBASE, "record %lld position %llu: residue is not one of A/C/G/T/N (KeyError, Consts.jl:22-28)", (long long)contig, fb);
+    }
+    p.last = prev;
+    p.val.assign((size_t)total, 0.0);
+    std::vector<char> done(1, 0);
+    ChainDevInfo info;
+    const int rc = chain_on_device(ctx, g, pairs, done, info);
+    if (rc) return rc;
+    if (!done[0])
+        return fail(ctx, KGMA_E_UNSUPPORTED, "the chain kernel does not serve this KFV (k = 5 or 6, at most 383 k-mers per window, KFV = S * (1/N), last window >= 2) or a check failed");
+    memcpy(out, p.val.data(), (size_t)total * sizeof(double));
+    ctx->stats.chain_device_pairs = info.pairs; ctx->stats.chain_device_ms = info.kernel_ms;
+    ctx->stats.chain_raw_steps = info.raw_steps; ctx->stats.chain_max_drift = info.max_drift;
+    return KGMA_OK;
 }
 
 // windows a record of L residues contributes (GenomeMiner.jl:37-39,60 / OmnGenomeMiner.jl:89)
@@ -2656,7 +3027,7 @@ int kgma_scan_aligned(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t
     ctx->n_align_device = ctx->n_align_host = 0;
     int rc = kgma_scan_device(ctx, g, mode, flags);
     if (rc) return rc;
-    ctx->stats.chain_ms = 0; ctx->stats.n_chain_pairs = 0; ctx->stats.chain_windows = 0;
+    reset_chain_stats(ctx);
     if ((flags & KGMA_F_CHAIN_REPLAY) && !(flags & KGMA_F_NO_TIE_RESOLVE)) {
         rc = chain_decide(ctx, g, mode);
         if (rc) return rc;

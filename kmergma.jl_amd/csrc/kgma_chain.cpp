@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -174,7 +175,152 @@ void run_chain_jobs(ChainJob *jobs, size_t n_jobs, int n_threads)
     for (std::thread &th : pool) th.join();
 }
 
+// ---- host half of the device chain ---------------------------------------------------------------------------
+// Inside a binade a double's bit pattern IS its count of ulps, so a regular chunk is one integer add to the pattern
+// (A0 or A0 + dA by the pattern's low bit); raw steps are hardware additions of the increments the device formed.
+// At every stream start the value is compared with the exact distance of that window: the device decided which
+// windows may leave a binade on exact values with a 2^-29 guard band, which is sound while the chain has drifted
+// less than that from the exact value -- 2^-31 is demanded here, a stream adds at most 2^-35.
+namespace {
+
+constexpr double CHAIN_MAX_DRIFT = 4.656612873077393e-10;   // 2^-31
+
+void chain_walk_one(ChainWalkJob &J)
+{
+    J.status = CHAIN_WALK_INTERNAL;
+    J.n_out = 0; J.max_drift = 0; J.raw_steps = 0;
+    if (J.n_iv == 0 || J.nk < 1) return;
+    double v = J.first;
+    const ChainInterval *iv = J.iv;
+    size_t ii = 0;
+    double *o = J.out;
+    int64_t cur_lo = iv[0].lo, cur_hi = iv[0].hi;
+    auto sample = [&](int64_t w, double x) {
+        if (w < cur_lo) return;
+        *o++ = x;
+        if (w == cur_hi) {
+            ii++;
+            if (ii < J.n_iv) { cur_lo = iv[ii].lo; cur_hi = iv[ii].hi; }
+            else { cur_lo = INT64_MAX; cur_hi = INT64_MAX; }
+        }
+    };
+    sample(1, v);
+    const int nk = J.nk;
+    for (size_t s = 0; s < J.n_streams; s++) {
+        const ChainStream &S = J.streams[s];
+        {
+            const double exact = (double)S.D0 / J.scale;
+            const double drift = exact > 0 ? std::fabs(v - exact) / exact : (v == 0.0 ? 0.0 : 1.0);
+            if (drift > J.max_drift) J.max_drift = drift;
+            if (!(drift <= CHAIN_MAX_DRIFT)) { J.status = CHAIN_WALK_DRIFT; return; }
+        }
+        const int64_t n_pos = (int64_t)S.n_valid + nk - 1;
+        const int64_t n_blocks = (n_pos + 63) >> 6;
+        const int64_t n_chunks = (n_blocks + KGMA_CHAIN_STEPS - 1) / KGMA_CHAIN_STEPS;
+        for (int64_t c = 0; c < n_chunks; c++) {
+            const ChainChunk cc = J.chunks[S.chunk_base + c];
+            const int64_t steps = std::min<int64_t>(KGMA_CHAIN_STEPS, n_blocks - c * KGMA_CHAIN_STEPS);
+            const int64_t nlead = (cc.info >> 2) & 63;
+            if (nlead > steps) return;
+            if (nlead > 0) {
+                uint64_t bits;
+                memcpy(&bits, &v, 8);
+                const int64_t dA = (int64_t)(cc.info & 3u) - 1;
+                bits += (uint64_t)((bits & 1u) ? cc.A0 + dA : cc.A0);
+                memcpy(&v, &bits, 8);
+            }
+            if (nlead == steps) continue;
+            if (cc.info & (1u << 16)) { J.status = CHAIN_WALK_OVERFLOW; return; }
+            if ((int64_t)cc.raw + (steps - nlead) > J.raw_slots) return;
+            const double *r = J.raw + (size_t)cc.raw * 64;
+            int64_t p = (c * KGMA_CHAIN_STEPS + nlead) * 64;
+            const int64_t p_end = (c * KGMA_CHAIN_STEPS + steps) * 64;
+            J.raw_steps += steps - nlead;
+            const int64_t w_first = S.win0 + (p - nk + 1), w_last = S.win0 + (p_end - 1 - nk + 1);
+            if (w_last < cur_lo || cur_lo == INT64_MAX) {
+                for (; p < p_end; p++) v += *r++;                        // (positions outside the stream hold 0.0)
+            } else {
+                (void)w_first;
+                for (; p < p_end; p++) {
+                    v += *r++;
+                    const int64_t q = p - nk + 1;
+                    if (q >= 1 && q < S.n_valid) sample(S.win0 + q, v);
+                }
+            }
+        }
+    }
+    J.n_out = (int64_t)(o - J.out);
+    J.status = CHAIN_WALK_OK;
+}
+
+}  // namespace
+
+void run_chain_walks(ChainWalkJob *jobs, size_t n_jobs, int n_threads)
+{
+    if (n_jobs == 0) return;
+    if (n_threads < 1) n_threads = 1;
+    if ((size_t)n_threads > n_jobs) n_threads = (int)n_jobs;
+    if (n_threads == 1) {
+        for (size_t i = 0; i < n_jobs; i++) chain_walk_one(jobs[i]);
+        return;
+    }
+    std::vector<size_t> order(n_jobs);
+    for (size_t i = 0; i < n_jobs; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return jobs[a].n_streams > jobs[b].n_streams; });
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_jobs) return;
+            chain_walk_one(jobs[order[i]]);
+        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)n_threads - 1);
+    for (int t = 1; t < n_threads; t++) pool.emplace_back(worker);
+    worker();
+    for (std::thread &th : pool) th.join();
+}
+
 }  // namespace kgma
+
+// C ABI: the host half of the device chain on caller-supplied chunk records (tests: the records come from a numpy
+// restatement of the kernel's arithmetic; the product path feeds it what stream8_kernel<..., CHAIN> wrote)
+extern "C" int kgma_host_chain_walk(double first, double scale, int32_t nk, int64_t n_streams, const int64_t *win0,
+                                    const int32_t *n_valid, const int64_t *chunk_base, const int64_t *D0, const void *chunks,
+                                    int64_t n_chunks, const double *raw, int64_t raw_slots, const int64_t *win_lo,
+                                    const int64_t *win_hi, int64_t n_intervals, double *out, int64_t cap, int64_t *n_out,
+                                    double *max_drift)
+{
+    if (!win0 || !n_valid || !chunk_base || !D0 || !chunks || !win_lo || !win_hi || !out || !n_out || n_streams < 1 || n_intervals < 1 ||
+        nk < 1)
+        return KGMA_E_ARG;
+    std::vector<kgma::ChainStream> st((size_t)n_streams);
+    for (int64_t i = 0; i < n_streams; i++) {
+        st[(size_t)i] = kgma::ChainStream{win0[i], chunk_base[i], D0[i], n_valid[i], 0};
+        const int64_t n_pos = (int64_t)n_valid[i] + nk - 1, nb = (n_pos + 63) >> 6;
+        if (chunk_base[i] < 0 || chunk_base[i] + (nb + kgma::KGMA_CHAIN_STEPS - 1) / kgma::KGMA_CHAIN_STEPS > n_chunks) return KGMA_E_ARG;
+    }
+    std::vector<kgma::ChainInterval> iv((size_t)n_intervals);
+    int64_t total = 0, prev = 0;
+    for (int64_t i = 0; i < n_intervals; i++) {
+        if (win_lo[i] < 1 || win_hi[i] < win_lo[i] || win_lo[i] <= prev) return KGMA_E_ARG;
+        iv[(size_t)i] = kgma::ChainInterval{win_lo[i], win_hi[i]};
+        total += win_hi[i] - win_lo[i] + 1;
+        prev = win_hi[i];
+    }
+    *n_out = total;
+    if (cap < total) return KGMA_E_ARG;
+    kgma::ChainWalkJob J{};
+    J.first = first; J.scale = scale; J.nk = nk; J.streams = st.data(); J.n_streams = st.size();
+    J.chunks = static_cast<const kgma::ChainChunk *>(chunks); J.raw = raw; J.raw_slots = raw_slots;
+    J.iv = iv.data(); J.n_iv = iv.size(); J.out = out;
+    kgma::run_chain_walks(&J, 1, 1);
+    if (max_drift) *max_drift = J.max_drift;
+    if (J.status == kgma::CHAIN_WALK_DRIFT) return KGMA_E_STATE;
+    if (J.status == kgma::CHAIN_WALK_OVERFLOW) return KGMA_E_OVERFLOW;
+    return J.status == kgma::CHAIN_WALK_OK && J.n_out == total ? KGMA_OK : KGMA_E_ARG;
+}
 
 // C ABI: the chain on one sequence, for hosts and tests (no device involved)
 extern "C" int kgma_host_chain_values(const uint8_t *seq, int64_t len, const double *ref, int32_t k, int64_t windowsize,

@@ -73,6 +73,45 @@ struct DevRecord {
                           // bits 1.. = 1 + 16-byte slot of the residues under the tied minimum in the aux region (0: none)
 };
 
+// ---- Float64 chain on the device (stream8_kernel<..., CHAIN>; KGMA_F_CHAIN_REPLAY) --------------------------
+// The reference's running distance is ONE sequential Float64 value per record and KFV: v' = RN(v + inc)
+// (src/GenomeMiner.jl:70-72, src/OmnGenomeMiner.jl:101-108).  The increment of a window is a function of that
+// window's exact counts alone, so every lane can form it; what is sequential is the rounding.  Inside one binade
+// v is an integer number of ulps, RN(v + inc) = v + a when v is even and v + b when it is odd, with a == b unless
+// the sum lands exactly half way between two doubles (then the even neighbour wins and the result is EVEN whatever
+// v was).  So a run of windows inside one binade is a translation by the sum of its a's, corrected at the ties by
+// the parity the value has there -- a parity that only the run's FIRST tie can inherit from the incoming value.
+// A chain stream cuts its positions into chunks of KGMA_CHAIN_STEPS steps; per chunk it emits the translation for
+// both parities of the incoming value (A0, A1 = A0 + dA) over the chunk's leading steps, and the raw Float64
+// increments of the remaining steps -- from the first step in which some window may leave the binade (decided on the
+// exact integer D with a guard band) and for every step of a chunk the host marked hot (it holds a window whose
+// value the host wants).  The host walks the chunks of a record in order: one integer add per regular chunk, one
+// hardware add per raw increment.
+constexpr int KGMA_CHAIN_STEPS = 16;                           // 64-position steps per chunk (1024 positions)
+constexpr int KGMA_CHAIN_STEPS_LOG2 = 4;
+struct ChainChunk {
+    int64_t A0;           // ulps the leading steps add when the incoming value's mantissa is even
+    uint32_t info;        // bits 0-1: dA + 1 (A1 = A0 + dA);  bits 2-7: leading steps (0 ... KGMA_CHAIN_STEPS);
+                          // bit 16: the raw pool overflowed (the increments of this chunk's raw steps are missing)
+    uint32_t raw;         // raw steps: first 64-double slot of the raw pool (the steps follow each other)
+};
+struct ChainArgs {
+    ChainChunk *chunks;           // [all chunks of the launch] (a stream's first chunk: TileDesc::dist_base)
+    double *raw;                  // raw pool: 64 doubles per step
+    unsigned int *raw_cursor;     // slots handed out
+    unsigned int raw_cap;         // slots available
+    const uint32_t *hot;          // one bit per chunk: emit every step raw
+    double invN;                  // RN(1 / N)
+    double Nd;                    // N
+    int32_t form;                 // how the KFV's Float64 entries follow from S (checked entry by entry on the host):
+                                  // 0: RN(S * invN) -- `answer .* (1/N)`, src/ReferenceGeneration.jl:35,40;
+                                  // 1: RN(S / N) -- `KFVs[i] ./= lens[i]`, src/ReferenceGeneration.jl:118
+    int32_t pad;
+    double SF;                    // ScaleFactor = 1 / k (src/API.jl:86,204)
+    double guard;                 // relative guard band around the powers of two (2^-29)
+    unsigned int *status;         // bit 0: raw pool overflow
+};
+
 // Arguments of one scan launch (either kernel).
 struct ScanArgs {
     const uint32_t *planes;
@@ -92,6 +131,7 @@ struct ScanArgs {
     int32_t tile0, n_chunk_tiles;
     int64_t tile_windows;
     int16_t *diff[KGMA_MAX_SIZES];
+    ChainArgs chain;                // chain launches only (no other kernel reads it)
 };
 
 // Count-table stream kernel (kgma_stream.hip): one wave per stream of consecutive window starts.

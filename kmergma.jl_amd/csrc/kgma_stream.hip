@@ -30,9 +30,15 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 #include "kgma_device.h"
+
+// The chain variant of stream8_kernel forms the reference's Float64 increments rounding by rounding: no fused
+// multiply-add may replace a multiply and an add anywhere in this file (nothing else here is floating point).
+#pragma clang fp contract(off)
 
 namespace kgma {
 
@@ -519,10 +525,16 @@ __global__ __launch_bounds__(1024) void stream_kernel(ScanArgs a, GroupParams gp
 // every entry fits (8 KiB instead of 16 KiB at k = 6), 24-bit multiply for N * diff.
 // ------------------------------------------------------------------------------------------
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+#ifndef KGMA_CHAIN_WAVES
+#define KGMA_CHAIN_WAVES 6
+#endif
 
-template <int K, bool S16, int NKFV, int ND = 0>
-__global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 : 4))) void stream8_kernel(ScanArgs a, GroupParams gp)
+template <int K, bool S16, int NKFV, int ND = 0, bool CHAIN = false>
+__global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN_WAVES : 8) : (NKFV <= 4 ? 6 : 4))) void stream8_kernel(ScanArgs a, GroupParams gp)
 {
+    // CHAIN: the same walk, but instead of testing thresholds the wave reproduces the reference's running Float64
+    // value (kgma_device.h, ChainArgs): one KFV, no dips, no records -- chunk translations and raw increments.
+    static_assert(!CHAIN || (NKFV == 1 && ND == 0), "the chain variant walks one KFV");
     constexpr bool DERIVE = ND > 0;                                   // the LAST ND KFVs of the launch have a window one k-mer longer
     static_assert(!DERIVE || (NKFV >= 2 && NKFV <= 4 && ND < NKFV && S16), "derived windows: 2-4 KFVs with int16 S tables");
     // k = 7: a wave's table is 16 KiB, so the LDS holds 10 of them and nothing else; the S tables stay in global memory,
@@ -643,11 +655,87 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
     const uint32_t kbase = KBASED ? cbase : 0u;
     const uint32_t sbase = (uint32_t)uni((int)(uint32_t)(uintptr_t)(lds_u32 *)smem);   // LDS byte offset of the S tables (0: the kernel has no static LDS)
 
+    // ---- CHAIN state (wave-uniform except c_acc) ---------------------------------------------------------------
+    int64_t c_acc = 0;                                                // per lane: ulps its windows added in this chunk (even-parity a's)
+    int32_t c_corr = 0, c_dA = 0;                                     // tie corrections for an even incoming value; A1 - A0
+    uint32_t c_P = 0;                                                 // parity of the running value (for an even incoming value)
+    bool c_split = true;                                              // no tie yet in this chunk: an odd incoming value has the other parity
+    bool c_raw = false, c_raw_ok = false;                             // this chunk emits raw increments from step c_raw_b0 on
+    uint32_t c_raw_base = 0;
+    int c_raw_b0 = 0, c_chunk_b0 = 0;
+    int64_t c_gid = 0;
+    bool c_bvalid = false;                                            // the binade below holds for the running value
+    int32_t c_Elo = 0, c_Ehi = -1;                                    // E range (stream-relative) that stays inside it, guard band off
+    uint32_t c_XLhi = 0;                                              // high dword of 2^e
+    // binade of the exact distance D / (2kN^2), with the E range in which the reference's value provably shares it
+    auto chain_binade = [&](const int64_t D) {
+        c_bvalid = false;
+        if (D <= 0) return;
+        const double scale = gpp->inv_scale[0];                       // 2kN^2 (an integer)
+        const double Dd = (double)D;
+        const int e = ilogb(Dd / scale);
+        const double g = a.chain.guard;
+        const double lo = ldexp(scale, e) * (1.0 + g), hi = ldexp(scale, e + 1) * (1.0 - g);
+        if (!(Dd > lo && Dd < hi) || e < -900 || e > 900) return;
+        const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st_reg[ST_D0HI]) << 32) | (uint32_t)uni(st_reg[ST_D0LO]));
+        const double twoN = 2.0 * (double)gpp->N[0];
+        double el = ceil((lo - (double)D0) / twoN), eh = floor((hi - (double)D0) / twoN);
+        el = el < -1073741824.0 ? -1073741824.0 : el;
+        eh = eh > 1073741824.0 ? 1073741824.0 : eh;
+        if (!(el <= eh)) return;
+        c_Elo = uni((int32_t)el); c_Ehi = uni((int32_t)eh);
+        c_XLhi = (uint32_t)uni((int32_t)((uint32_t)(e + 1023) << 20));
+        c_bvalid = true;
+    };
+    // the rest of this chunk goes out as raw increments, from step b on; its leading steps as one translation
+    auto chain_switch_raw = [&](const int b) {
+        const int nlead = b - c_chunk_b0;
+        const int64_t total = wave_sum_i64(c_acc) + (int64_t)c_corr;
+        int left = n_blocks - c_chunk_b0;
+        left = (left > KGMA_CHAIN_STEPS ? KGMA_CHAIN_STEPS : left) - nlead;
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(a.chain.raw_cursor, (unsigned int)left);
+        base = (unsigned int)uni((int)base);
+        const bool ok = (uint64_t)base + (uint64_t)left <= (uint64_t)a.chain.raw_cap;
+        if (lane == 0) {
+            if (!ok) atomicOr(a.chain.status, 1u);
+            ChainChunk cc;
+            cc.A0 = total;
+            cc.info = (uint32_t)(c_dA + 1) | ((uint32_t)nlead << 2) | (ok ? 0u : 1u << 16);
+            cc.raw = base;
+            a.chain.chunks[c_gid] = cc;
+        }
+        c_raw = true; c_raw_ok = ok; c_raw_base = base; c_raw_b0 = b;
+        c_bvalid = false;                                             // nothing watches the binade while the chunk is raw
+    };
+    auto chain_begin = [&](const int b) {
+        c_chunk_b0 = b; c_acc = 0; c_corr = 0; c_dA = 0; c_P = 0; c_split = true; c_raw = false;
+        c_gid = td.dist_base + (b >> KGMA_CHAIN_STEPS_LOG2);
+        const uint32_t hw = a.chain.hot[c_gid >> 5];
+        if (!c_bvalid && (b << 6) >= nk) {                            // (the first window's D is known)
+            const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st_reg[ST_D0HI]) << 32) | (uint32_t)uni(st_reg[ST_D0LO]));
+            chain_binade(D0 + 2 * (int64_t)gpp->N[0] * (int64_t)h_carry[0]);
+        }
+        if ((uni((int)hw) >> (c_gid & 31)) & 1) chain_switch_raw(b);
+    };
+    auto chain_end = [&](const int b) {
+        if (c_raw) return;
+        const int64_t total = wave_sum_i64(c_acc) + (int64_t)c_corr;
+        if (lane == 0) {
+            ChainChunk cc;
+            cc.A0 = total;
+            cc.info = (uint32_t)(c_dA + 1) | ((uint32_t)(b - c_chunk_b0 + 1) << 2);
+            cc.raw = 0;
+            a.chain.chunks[c_gid] = cc;
+        }
+    };
+
     // the stream's first window of KFV j has distance D0: thresholds in E units
     auto set_first_window = [&](const int j, int32_t *st, const int64_t D0) {
         const int64_t twoN = 2 * (int64_t)gpp->N[j];
         st[ST_D0LO] = (int32_t)(uint32_t)D0;
         st[ST_D0HI] = (int32_t)(uint32_t)((uint64_t)D0 >> 32);
+        if constexpr (CHAIN) { chain_binade(D0); return; }
         // E_q < TE  <=>  D0 + 2N E_q < T; windows with TE <= E_q < TE + natt are at threshold
         const int64_t Tj = gpp->T[j], Thj = gpp->T_hi[j];
         const int64_t num = Tj - D0;
@@ -897,6 +985,82 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
 #undef KGMA_SCAN_STAGE
 #pragma unroll
         for (int j = 0; j < NKFV; j++) asm volatile("" : "+v"(sc[j]));   // (the last stage stays one DPP add; the carry is one more add)
+        if constexpr (CHAIN) {
+            // ---- the reference's Float64 update of this lane's window (GenomeMiner.jl:70-72, same operation order) ----
+            const int32_t Ecur = sc[0] + h_carry[0];                  // (D - D0) / 2N after this lane's transition
+            h_carry[0] = __builtin_amdgcn_readlane(Ecur, 63);
+            uint64_t ACT = AE;                                        // lanes whose transition belongs to this stream
+            bool act = differ;
+            if constexpr (GENERIC) { act = actL && p - nk + 1 < n_valid; ACT = __ballot(act); }
+            double inc = 0.0;
+            if (ACT != 0) {
+                // (plain operators: this file is compiled with fp contract off, see the pragma at its top -- the __dmul_rn /
+                //  __dadd_rn helpers of the HIP headers carry their own contraction flags and DO fuse)
+                double rl = (double)(uint32_t)Sl[0] * a.chain.invN;   // refVec[left] as RN(S * (1/N))
+                double rr = (double)(uint32_t)Sr[0] * a.chain.invN;   // refVec[right]
+                if (a.chain.form != 0) {
+                    // ... as RN(S / N): the product above is within an ulp of the quotient, its residual S - q N is exact
+                    // in one fused multiply-add, and q + residual * RN(1/N) then rounds to the correctly rounded quotient
+                    // (Markstein's division step; the host has checked the KFV's entries against exactly this sequence)
+                    const double el = __builtin_fma(-rl, a.chain.Nd, (double)(uint32_t)Sl[0]);
+                    const double er = __builtin_fma(-rr, a.chain.Nd, (double)(uint32_t)Sr[0]);
+                    rl = __builtin_fma(el, a.chain.invN, rl);
+                    rr = __builtin_fma(er, a.chain.invN, rr);
+                }
+                double t = (double)(1 + cP);                          // 1 + curr_kmer_freq[right]: integer
+                t = t + rl;
+                t = t - rr;
+                t = t - (double)cS;                                   // - curr_kmer_freq[left]
+                inc = a.chain.SF * t;
+                inc = act ? inc : 0.0;
+            }
+            if (!c_raw && ACT != 0) {
+                // every value of the step inside the binade?  (E of a lane without a transition is its lower neighbour's)
+                bool ok = c_bvalid;
+                if (ok) {
+                    const uint64_t inl = __builtin_amdgcn_sicmp(Ecur, c_Elo, 39 /* sge */) & __builtin_amdgcn_sicmp(Ecur, c_Ehi, 41 /* sle */);
+                    ok = (inl | ~ACT) == ~(uint64_t)0;
+                }
+                if (!ok) chain_switch_raw(b);
+            }
+            if (c_raw) {
+                if (c_raw_ok) a.chain.raw[((size_t)c_raw_base + (size_t)(b - c_raw_b0)) * 64 + (size_t)lane] = inc;
+            } else if (ACT != 0) {
+                // RN(v + inc) for an even and an odd v of this binade, as hardware additions: anchors at the end of the
+                // binade the increment moves away from (2^e, or 2^(e+1) - 2 ulp), so that the sums stay inside
+                const uint64_t ib = (uint64_t)__double_as_longlong(inc);
+                const bool neg = (int32_t)(uint32_t)(ib >> 32) < 0;
+                const uint32_t x0hi = neg ? (c_XLhi | 0xFFFFFu) : c_XLhi;
+                const uint32_t x0lo = neg ? 0xFFFFFFFEu : 0u;
+                const uint64_t x0b = ((uint64_t)x0hi << 32) | x0lo;
+                const double R0 = __longlong_as_double((long long)x0b) + inc;
+                const double R1 = __longlong_as_double((long long)(x0b | 1u)) + inc;
+                const uint64_t r0b = (uint64_t)__double_as_longlong(R0), r1b = (uint64_t)__double_as_longlong(R1);
+                const int64_t av = (int64_t)(r0b - x0b);              // ulps added to an even value
+                const int32_t delta = (int32_t)((uint32_t)r1b - (uint32_t)r0b) - 1;   // ... to an odd value: av + delta (a tie: +-1)
+                c_acc += av;
+                const uint64_t T = __builtin_amdgcn_uicmp((uint32_t)delta, 0u, 33 /* ne */);
+                uint64_t O = __builtin_amdgcn_uicmp((uint32_t)av & 1u, 0u, 33 /* ne */) & ~T;
+                // parity of the running value, lane by lane: it flips at odd a's and is EVEN after a tie
+                if (__builtin_expect(T != 0, 0)) {
+                    uint64_t Trem = T;
+                    while (Trem != 0) {
+                        const int u = __builtin_ctzll(Trem);
+                        const uint64_t below = ((uint64_t)1 << u) - 1;
+                        c_P ^= (uint32_t)__builtin_popcountll(O & below) & 1u;
+                        const int32_t du = __builtin_amdgcn_readlane(delta, u);
+                        const int32_t c0 = c_P ? du : 0;
+                        if (c_split) { c_dA = (c_P ? 0 : du) - c0; c_split = false; }
+                        c_corr += c0;
+                        c_P = 0;
+                        O &= ~below;
+                        Trem &= Trem - 1;
+                    }
+                }
+                c_P ^= (uint32_t)__builtin_popcountll(O) & 1u;
+            }
+            return;
+        }
         // Phase 3: thresholds; one combined test decides whether any KFV has a dip in this step
         // window start (local) this transition leads to.  Steady steps need it in the cold paths only (distances, records):
         // there it is formed from an opaque copy of the step number, so that it is not computed in every step
@@ -1039,6 +1203,17 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? 8 : (NKFV <= 4 ? 6 
     if (b_tail < b_warm) b_tail = b_warm;
     if (b_tail > n_blocks) b_tail = n_blocks;
     int b = 0;
+    if constexpr (CHAIN) {
+        auto cstep = [&](const int bb, auto tag) {
+            if ((bb & (KGMA_CHAIN_STEPS - 1)) == 0) chain_begin(bb);
+            step(bb, tag);
+            if ((bb & (KGMA_CHAIN_STEPS - 1)) == KGMA_CHAIN_STEPS - 1 || bb == n_blocks - 1) chain_end(bb);
+        };
+        for (; b < b_warm; b++) cstep(b, std::true_type{});
+        for (; b < b_tail; b++) cstep(b, std::false_type{});
+        for (; b < n_blocks; b++) cstep(b, std::true_type{});
+        return;
+    }
     for (; b < b_warm; b++) step(b, std::true_type{});
     for (; b < b_tail; b++) step(b, std::false_type{});
     for (; b < n_blocks; b++) step(b, std::true_type{});
@@ -1186,34 +1361,99 @@ static const void *stream8_fn_of(int k, bool s16, int nkfv, int nd = 0)       //
 
 // waves per workgroup and workgroups per CU that keep the most streams resident (asked of the runtime, which knows
 // the LDS allocation granule and the kernel's registers); one KFV: two 16-wave workgroups = 32 waves per CU
+static const void *chain_fn_of(int k, bool s16)
+{
+    if (k == 5) return s16 ? reinterpret_cast<const void *>(&stream8_kernel<5, true, 1, 0, true>) : reinterpret_cast<const void *>(&stream8_kernel<5, false, 1, 0, true>);
+    return s16 ? reinterpret_cast<const void *>(&stream8_kernel<6, true, 1, 0, true>) : reinterpret_cast<const void *>(&stream8_kernel<6, false, 1, 0, true>);
+}
+
+// Residency of one kernel variant on one device, asked of the runtime once: guarded (one context per host thread is the
+// documented use) and keyed by the device too (partitioned modes expose different CUs).
+struct GeomKey {
+    int device, k, s16, nkfv, nd, chain;
+    bool operator<(const GeomKey &o) const
+    {
+        if (device != o.device) return device < o.device;
+        if (k != o.k) return k < o.k;
+        if (s16 != o.s16) return s16 < o.s16;
+        if (nkfv != o.nkfv) return nkfv < o.nkfv;
+        if (nd != o.nd) return nd < o.nd;
+        return chain < o.chain;
+    }
+};
+struct GeomVal { int nw, blocks; };
+
+static GeomVal stream8_geometry_of(int k, bool s16, int nkfv, int nd, bool chain)
+{
+    static std::mutex mu;
+    static std::map<GeomKey, GeomVal> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const GeomKey key{dev, k, s16 ? 1 : 0, nkfv, nd, chain ? 1 : 0};
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    const void *fn = chain ? chain_fn_of(k, s16) : stream8_fn_of(k, s16, nkfv, nd);
+    int best_nw = 0, best_blocks = 0;
+    for (int nw = 16; nw >= 4; nw--) {
+        const size_t lds = stream8_lds(k, s16, nkfv, nw);
+        if (lds > ((size_t)160 << 10)) continue;
+        int blocks = 0;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64 * nw, lds) != hipSuccess) continue;
+        if (blocks * nw > 32) blocks = 32 / nw;
+        if (blocks * nw > best_blocks * best_nw) { best_blocks = blocks; best_nw = nw; }
+    }
+    {
+        // the one-KFV kernels fold the LDS base of a wave's count table into the k-mers: the dynamic LDS must start at
+        // offset 0 (no static LDS in the kernel), or the tables would not sit at multiples of their size
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.sharedSizeBytes != 0) best_nw = best_blocks = 0;
+    }
+    (void)hipGetLastError();
+    GeomVal v{best_nw > 0 ? best_nw : -1, best_blocks > 0 ? best_blocks : 1};   // (nw = -1: refused, the launch reports an error)
+    cache.emplace(key, v);
+    return v;
+}
+
+// waves per workgroup and workgroups per CU that keep the most streams resident (asked of the runtime, which knows
+// the LDS allocation granule and the kernel's registers); one KFV: two 16-wave workgroups = 32 waves per CU
 void stream8_geometry(int k, bool s16, int nkfv, int nd, int *nw_out, int *blocks_out)
 {
-    static int cache[3][2][9][4][2];
-    static bool init = false;
-    if (!init) { memset(cache, 0, sizeof cache); init = true; }
-    int *c = cache[k - 5][s16 ? 1 : 0][nkfv][nd];
-    if (c[0] == 0) {
-        int best_nw = 0, best_blocks = 0;
-        for (int nw = 16; nw >= 4; nw--) {
-            const size_t lds = stream8_lds(k, s16, nkfv, nw);
-            if (lds > ((size_t)160 << 10)) continue;
-            int blocks = 0;
-            if (hipFuncSetAttribute(stream8_fn_of(k, s16, nkfv, nd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, stream8_fn_of(k, s16, nkfv, nd), 64 * nw, lds) != hipSuccess) continue;
-            if (blocks * nw > 32) blocks = 32 / nw;
-            if (blocks * nw > best_blocks * best_nw) { best_blocks = blocks; best_nw = nw; }
-        }
-        {
-            // the one-KFV kernels fold the LDS base of a wave's count table into the k-mers: the dynamic LDS must start at
-            // offset 0 (no static LDS in the kernel), or the tables would not sit at multiples of their size
-            hipFuncAttributes fa;
-            if (hipFuncGetAttributes(&fa, stream8_fn_of(k, s16, nkfv, nd)) == hipSuccess && fa.sharedSizeBytes != 0) best_nw = best_blocks = 0;
-        }
-        (void)hipGetLastError();
-        c[0] = best_nw > 0 ? best_nw : 4; c[1] = best_blocks > 0 ? best_blocks : 1;
-        if (best_nw == 0) c[0] = -1;                                  // (refused: launch_stream8 reports an error)
+    const GeomVal v = stream8_geometry_of(k, s16, nkfv, nd, false);
+    *nw_out = v.nw; *blocks_out = v.blocks;
+}
+
+// ---- chain variant (one KFV, k = 5 or 6): streams resident per CU, launch
+bool chain_applies(int k, int nk, int64_t n_ref)
+{
+    return (k == 5 || k == 6) && nk <= KGMA_STREAM8_MAX_NK && n_ref < ((int64_t)1 << 22);
+}
+
+int chain_slots_per_cu(int k, bool s16)
+{
+    const GeomVal v = stream8_geometry_of(k, s16, 1, 0, true);
+    return v.nw < 1 ? 0 : v.nw * v.blocks;
+}
+
+hipError_t launch_chain(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
+{
+    const bool s16 = gp.s_fits_i16 != 0;
+    const GeomVal v = stream8_geometry_of(gp.k, s16, 1, 0, true);
+    if (v.nw < 1 || gp.n_kfv != 1 || !chain_applies(gp.k, gp.nk, gp.N[0])) return hipErrorInvalidConfiguration;
+    const int nw = v.nw;
+    const size_t lds = stream8_lds(gp.k, s16, 1, nw);
+    const unsigned grid = (unsigned)((a.n_tiles + nw - 1) / nw);
+    hipError_t e = hipFuncSetAttribute(chain_fn_of(gp.k, s16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (gp.k == 5) {
+        if (s16) hipLaunchKernelGGL((stream8_kernel<5, true, 1, 0, true>), dim3(grid), dim3(64u * nw), lds, st, a, gp);
+        else hipLaunchKernelGGL((stream8_kernel<5, false, 1, 0, true>), dim3(grid), dim3(64u * nw), lds, st, a, gp);
+    } else {
+        if (s16) hipLaunchKernelGGL((stream8_kernel<6, true, 1, 0, true>), dim3(grid), dim3(64u * nw), lds, st, a, gp);
+        else hipLaunchKernelGGL((stream8_kernel<6, false, 1, 0, true>), dim3(grid), dim3(64u * nw), lds, st, a, gp);
     }
-    *nw_out = c[0]; *blocks_out = c[1];
+    return hipGetLastError();
 }
 
 template <int K, bool S16>

@@ -32,6 +32,7 @@ EXPORTS = [
     "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips", "kgma_align_hits_device", "kgma_repack_scan_hits",
     "kgma_kmer_count_batch", "kgma_kmer_dist_batch", "kgma_step_begin", "kgma_step_end", "kgma_set_reserved_cus",
     "kgma_scan_aligned", "kgma_get_alignments", "kgma_set_residue_source", "kgma_host_chain_values",
+    "kgma_chain_values", "kgma_host_chain_walk",
 ]
 
 
@@ -57,7 +58,9 @@ class KgmaStats(C.Structure):
                 ("n_hits", C.c_int64), ("n_tie_flagged", C.c_int64), ("n_at_threshold", C.c_int64),
                 ("pack_ms", C.c_double), ("scan_ms", C.c_double), ("replay_ms", C.c_double),
                 ("device_bytes", C.c_int64), ("n_tiles", C.c_int32), ("n_launches", C.c_int32),
-                ("chain_ms", C.c_double), ("n_chain_pairs", C.c_int64), ("chain_windows", C.c_int64)]
+                ("chain_ms", C.c_double), ("n_chain_pairs", C.c_int64), ("chain_windows", C.c_int64),
+                ("chain_device_pairs", C.c_int64), ("chain_device_ms", C.c_double), ("chain_raw_steps", C.c_int64),
+                ("chain_max_drift", C.c_double)]
 
 
 HIT_DTYPE = np.dtype([("contig", "<i4"), ("kfv", "<i4"), ("cmi", "<i8"), ("lo", "<i8"), ("hi", "<i8"),
@@ -148,6 +151,9 @@ def load():
     L.kgma_get_alignments.argtypes = [vp, P(KgmaAlignment), i64, P(i64), P(i64), P(i64)]
     L.kgma_set_residue_source.argtypes = [vp, FETCH_FN, vp]
     L.kgma_host_chain_values.argtypes = [C.c_char_p, i64, P(dbl), i32, i64, P(i64), P(i64), i64, P(dbl), i64, P(i64)]
+    L.kgma_chain_values.argtypes = [vp, vp, i64, i32, P(i64), P(i64), i64, P(dbl), i64, P(i64)]
+    L.kgma_host_chain_walk.argtypes = [dbl, dbl, i32, i64, P(i64), P(i32), P(i64), P(i64), vp, i64, P(dbl), i64, P(i64), P(i64), i64,
+                                       P(dbl), i64, P(i64), P(dbl)]
     L.kgma_stream.argtypes = [vp]
     L.kgma_stream.restype = vp
     L.kgma_scan_kernel_name.argtypes = [vp]
@@ -171,6 +177,34 @@ def host_chain_values(seq: bytes, ref, k: int, windowsize: int, intervals) -> np
     if st != KGMA_OK:
         raise KgmaError(st, "kgma_host_chain_values failed")
     return out[:nn.value]
+
+
+CHAIN_STEPS = 16                 # kgma_device.h: KGMA_CHAIN_STEPS (64-position steps per chunk)
+CHAIN_CHUNK_DTYPE = np.dtype([("A0", "<i8"), ("info", "<u4"), ("raw", "<u4")])   # kgma_device.h: ChainChunk
+
+
+def host_chain_walk(first: float, scale: float, nk: int, win0, n_valid, chunk_base, D0, chunks, raw, intervals):
+    """kgma_host_chain_walk: the host half of the device chain on caller-supplied chunk records (tests).  Returns
+    (values at the windows of `intervals`, largest drift seen at a stream start)."""
+    win0 = np.ascontiguousarray(win0, dtype=np.int64)
+    n_valid = np.ascontiguousarray(n_valid, dtype=np.int32)
+    chunk_base = np.ascontiguousarray(chunk_base, dtype=np.int64)
+    D0 = np.ascontiguousarray(D0, dtype=np.int64)
+    chunks = np.ascontiguousarray(chunks, dtype=CHAIN_CHUNK_DTYPE)
+    raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1)
+    lo = np.asarray([a for a, _ in intervals], dtype=np.int64)
+    hi = np.asarray([b for _, b in intervals], dtype=np.int64)
+    n = int((hi - lo + 1).sum())
+    out = np.zeros(max(n, 1), dtype=np.float64)
+    nn = C.c_int64(0)
+    drift = C.c_double(0)
+    st = load().kgma_host_chain_walk(float(first), float(scale), int(nk), win0.size, _np_ptr(win0, C.c_int64), _np_ptr(n_valid, C.c_int32),
+                                     _np_ptr(chunk_base, C.c_int64), _np_ptr(D0, C.c_int64), chunks.ctypes.data_as(C.c_void_p), chunks.size,
+                                     _np_ptr(raw, C.c_double) if raw.size else None, raw.size // 64, _np_ptr(lo, C.c_int64),
+                                     _np_ptr(hi, C.c_int64), lo.size, _np_ptr(out, C.c_double), out.size, C.byref(nn), C.byref(drift))
+    if st != KGMA_OK:
+        raise KgmaError(st, "kgma_host_chain_walk failed")
+    return out[:nn.value], drift.value
 
 
 def _np_ptr(a, t):
@@ -202,6 +236,18 @@ class Genome:
         if st != KGMA_OK:
             raise KgmaError(st, "genome has no FASTA headers (it was not built from FASTA text)")
         return C.string_at(txt, n.value).decode("utf-8", "replace")
+
+    def chain_values(self, contig: int, kfv: int, intervals) -> np.ndarray:
+        """kgma_chain_values: the reference's running Float64 distance of record `contig` for KFV `kfv` (1-based) at the
+        windows of `intervals` ((lo, hi) pairs, 1-based window starts), computed by the chain kernel on the device."""
+        lo = np.asarray([a for a, _ in intervals], dtype=np.int64)
+        hi = np.asarray([b for _, b in intervals], dtype=np.int64)
+        n = int((hi - lo + 1).sum())
+        out = np.zeros(max(n, 1), dtype=np.float64)
+        nn = C.c_int64(0)
+        self._ctx._check(load().kgma_chain_values(self._ctx._h, self._h, int(contig), int(kfv), _np_ptr(lo, C.c_int64), _np_ptr(hi, C.c_int64),
+                                                  lo.size, _np_ptr(out, C.c_double), out.size, C.byref(nn)))
+        return out[:nn.value]
 
     def fetch(self, contig: int, pos: int, length: int) -> bytes:
         buf = C.create_string_buffer(max(length, 1))

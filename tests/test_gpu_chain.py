@@ -1,0 +1,153 @@
+"""The reference's running Float64 distance computed by the chain kernel (stream8_kernel<..., CHAIN> + the host walk,
+kgma_chain_values / KGMA_F_CHAIN_REPLAY) against the oracle's reference-order values: bit for bit at every window,
+through regular chunks, binade changes, half-ulp ties, heavy k-mers (N / homopolymer runs), several records and KFVs."""
+import os
+
+import numpy as np
+import pytest
+
+from kmergma_amd import _lib, workloads
+from oracle import oracle as orc
+from tests.helpers import hit_key, make_genome, mutate, random_dna
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def genes(data_dir):
+    from kmergma_amd import fasta
+    return [r.sequence.upper() for r in fasta.read_fasta(os.path.join(data_dir, "Alp_V_ref.fasta"))]
+
+
+def _rich_seq(rng, n, genes):
+    a = bytearray(random_dna(rng, n))
+    a[3000:3700] = b"A" * 700
+    a[9000:9400] = b"n" * 400
+    a[15000:15600] = b"ACGT" * 150
+    a[16000:16300] = b"AC" * 150
+    for pos in range(5000, n - 1000, 7919):
+        g = mutate(rng, genes[int(rng.integers(0, len(genes)))], float(rng.random()) * 0.1)
+        a[pos:pos + len(g)] = g
+    return bytes(a)
+
+
+def _oracle_chain(seq, RV, k, W):
+    _, od = orc.single_scan([seq], RV, k, W, 30.0, 50, return_dists=True)
+    return np.concatenate([[orc.kmer_dist_kfv(seq[:W], RV, k)], od])
+
+
+@pytest.mark.parametrize("stream", [None, "1024", "4096"])
+def test_chain_values_every_window(ctx, alp_ref, genes, stream, monkeypatch):
+    if stream:
+        monkeypatch.setenv("KGMA_CHAIN_STREAM", stream)
+    rng = np.random.default_rng(21)
+    k, W, RV = 6, alp_ref["ws"], alp_ref["RV"]
+    seqs = [_rich_seq(rng, 70_000, genes), random_dna(rng, 5000), b"A" * 1000 + random_dna(rng, 400)]
+    ctx.set_refs(k, [RV], [W], [30.0], [alp_ref["N"]])
+    g = ctx.genome_from_host(seqs)
+    try:
+        for c, seq in enumerate(seqs):
+            chain = _oracle_chain(seq, RV, k, W)
+            nwin = len(seq) - W + 1
+            v = g.chain_values(c, 1, [(1, nwin)])
+            assert np.array_equal(v, chain), f"record {c}: first mismatch at window {int(np.argmax(v != chain)) + 1}"
+    finally:
+        g.free()
+
+
+def test_chain_values_sparse_windows_go_through_regular_chunks(ctx, alp_ref, genes):
+    rng = np.random.default_rng(22)
+    k, W, RV = 6, alp_ref["ws"], alp_ref["RV"]
+    seq = _rich_seq(rng, 600_000, genes)
+    chain = _oracle_chain(seq, RV, k, W)
+    nwin = len(seq) - W + 1
+    ctx.set_refs(k, [RV], [W], [30.0], [alp_ref["N"]])
+    g = ctx.genome_from_host([seq])
+    try:
+        iv = [(1, 1), (2, 2), (100_000, 100_003), (333_333, 333_400), (nwin - 1, nwin)]
+        v = g.chain_values(0, 1, iv)
+        want = np.concatenate([chain[lo - 1:hi] for lo, hi in iv])
+        assert np.array_equal(v, want)
+        st = ctx.stats()
+        total_steps = (nwin + 63) // 64
+        assert st["chain_device_pairs"] == 1 and 0 < st["chain_raw_steps"] < total_steps // 4
+        assert st["chain_max_drift"] < 2.0 ** -40
+        only_last = g.chain_values(0, 1, [(nwin, nwin)])
+        assert only_last[0] == chain[-1]
+    finally:
+        g.free()
+
+
+def test_chain_values_raw_pool_regrowth(ctx, alp_ref, genes, monkeypatch):
+    rng = np.random.default_rng(23)
+    k, W, RV = 6, alp_ref["ws"], alp_ref["RV"]
+    seq = _rich_seq(rng, 50_000, genes)
+    chain = _oracle_chain(seq, RV, k, W)
+    ctx.set_refs(k, [RV], [W], [30.0], [alp_ref["N"]])
+    g = ctx.genome_from_host([seq])
+    try:
+        monkeypatch.setenv("KGMA_CHAIN_RAW_SLOTS", "3")                 # far too small: the second attempt has room
+        v = g.chain_values(0, 1, [(1, len(chain))])
+        assert np.array_equal(v, chain)
+    finally:
+        g.free()
+
+
+def test_chain_values_cluster_kfvs_and_k5(ctx, alp_clusters, genes, data_dir):
+    from kmergma_amd import refprep
+    rng = np.random.default_rng(24)
+    seq = _rich_seq(rng, 40_000, genes)
+    c = alp_clusters
+    thr = [37, 33, 38, 34, 28]
+    _, od = orc.omn_scan([seq], c["KFVs"], 6, c["ws"], thr, 50, 0, return_dists=True)
+    ctx.set_refs(6, c["KFVs"], c["ws"], thr, c["N"])
+    g = ctx.genome_from_host([seq])
+    try:
+        for j, w in enumerate(c["ws"]):
+            n = len(od[j])
+            v = g.chain_values(0, j + 1, [(2, n + 1)])
+            assert np.array_equal(v, od[j]), f"KFV {j + 1}"
+    finally:
+        g.free()
+    RV, ws, cons, (S, N) = refprep.gen_ref_ws_cons(os.path.join(data_dir, "Alp_V_ref.fasta"), 5, return_int=True)
+    _, od1 = orc.single_scan([seq], RV, 5, ws, 30.0, 50, return_dists=True)
+    ctx.set_refs(5, [RV], [ws], [30.0], [N])
+    g = ctx.genome_from_host([seq])
+    try:
+        assert np.array_equal(g.chain_values(0, 1, [(2, len(seq) - ws + 1)]), od1)
+    finally:
+        g.free()
+
+
+def test_chain_replay_runs_on_the_device_and_agrees_with_the_host_chain(ctx, alp_ref, genes, monkeypatch):
+    """A tie-dense scan (threshold at the random mean): KGMA_F_CHAIN_REPLAY decides on the device chain's values; the
+    host chain (KGMA_CHAIN=host) gives the same hits, both identical to the Float64 oracle."""
+    rng = np.random.default_rng(25)
+    contigs, _ = make_genome(rng, [2_000_000, 900_000, 3000], genes, n_plants_per_mb=20)
+    k, W, RV, N = 6, alp_ref["ws"], alp_ref["RV"], alp_ref["N"]
+    thr = 37.0
+    ohits, _ = orc.single_scan(contigs, RV, k, W, thr, 50)
+    ctx.set_refs(k, [RV], [W], [thr], [N])
+    g = ctx.genome_from_host(contigs)
+    try:
+        ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_CHAIN_REPLAY, None)
+        hits, st = ctx.hits(), ctx.stats()
+        assert st["n_chain_pairs"] > 0 and st["chain_device_pairs"] == st["n_chain_pairs"]
+        assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohits]
+        for a, b in zip(hits, ohits):
+            if a["flags"] & _lib.HIT_CHAIN:
+                assert a["dist"] == b["dist"]
+        monkeypatch.setenv("KGMA_CHAIN", "host")
+        ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_CHAIN_REPLAY, None)
+        hits2, st2 = ctx.hits(), ctx.stats()
+        assert st2["chain_device_pairs"] == 0 and st2["n_chain_pairs"] == st["n_chain_pairs"]
+        assert [(hit_key(h), h["dist"]) for h in hits2] == [(hit_key(h), h["dist"]) for h in hits]
+    finally:
+        g.free()
