@@ -288,6 +288,7 @@ int kgma_chain_values(kgma_ctx *ctx, const kgma_genome *genome, int64_t contig, 
 /* HOST half of the device chain, exposed for tests: walks caller-supplied chunk records (the layout of
  * kgma_device.h's ChainChunk: int64 A0, uint32 info, uint32 raw) and raw increments exactly as the product does with
  * the kernel's output.  KGMA_E_STATE: the value drifted more than 2^-31 from the exact distance at a stream start. */
+int kgma_chain_chunk_steps(void);   /* 64-position steps per chunk (kgma_device.h: KGMA_CHAIN_STEPS) */
 int kgma_host_chain_walk(double first, double scale, int32_t nk, int64_t n_streams, const int64_t *win0, const int32_t *n_valid,
                          const int64_t *chunk_base, const int64_t *D0, const void *chunks, int64_t n_chunks, const double *raw,
                          int64_t raw_slots, const int64_t *win_lo, const int64_t *win_hi, int64_t n_intervals, double *out,

@@ -2323,7 +2323,7 @@ struct ChainPair {
     int64_t last;
 };
 
-struct ChainDevInfo { int64_t pairs = 0, windows = 0, raw_steps = 0, streams = 0; double kernel_ms = 0, walk_ms = 0, max_drift = 0; int attempts = 0; };
+struct ChainDevInfo { int64_t pairs = 0, windows = 0, raw_steps = 0, streams = 0, chunks = 0; double kernel_ms = 0, walk_ms = 0, setup_ms = 0, copy_ms = 0, max_drift = 0; int attempts = 0; };
 
 static bool chain_device_enabled()
 {
@@ -2336,62 +2336,66 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
     const int k = ctx->k;
     const int64_t NB = (int64_t)1 << (2 * k);
     std::vector<size_t> el;
-    int64_t total_windows = 0;
-    int min_slots = 1 << 20;
+    const double ts0 = now_ms();
     for (size_t i = 0; i < pairs.size(); i++) {
         const ChainPair &p = pairs[i];
         const KfvInfo &f = ctx->kfv[(size_t)p.j];
         const int nk = (int)(f.W - k + 1);
         if (!chain_applies(k, nk, f.N) || f.ref_form < 0 || p.last < 2) continue;
-        const int sl = chain_slots_per_cu(k, f.Smax <= 32767);
-        if (sl < 1) continue;
-        min_slots = std::min(min_slots, sl);
+        if (chain_slots_per_cu(k, f.Smax <= 32767) < 1) continue;
         el.push_back(i);
-        total_windows += p.last;
     }
     if (el.empty()) return KGMA_OK;
     std::stable_sort(el.begin(), el.end(), [&](size_t a, size_t b) { return pairs[a].j < pairs[b].j; });
     (void)hipSetDevice(ctx->device);
 
-    // transitions per stream: about three rounds of streams over the chip, 64 | T (streams start on plane words),
-    // at most 2^18 (the drift a stream may add stays far below the guard band)
-    int64_t T;
-    {
-        const int64_t slots = (int64_t)std::max(1, ctx->n_cus) * min_slots;
-        T = (total_windows + slots * 3 - 1) / (slots * 3);
-        if (const char *e = getenv("KGMA_CHAIN_STREAM")) T = atoll(e);                         // experiments / tests
-        T = std::min<int64_t>(std::max<int64_t>(((T + 63) / 64) * 64, 1024), (int64_t)1 << 18);
-    }
-    struct Launch { int j; size_t t0, t1; };
-    struct PairStreams { size_t s0, s1; };
+    // transitions per stream, per launch (= per KFV): about three rounds of streams over the chip, 64 | T (streams start
+    // on plane words), at most 2^18 (the drift a stream may add stays far below the guard band)
+    struct Launch { int j; size_t t0, t1; int64_t T; };
+    struct PairStreams { size_t s0, s1; int64_t T; };
     std::vector<TileDesc> tiles;
     std::vector<ChainStream> streams;
     std::vector<PairStreams> ps(el.size());
     std::vector<Launch> launches;
     int64_t n_chunks = 0, total_steps = 0;
-    for (size_t u = 0; u < el.size(); u++) {
-        const ChainPair &p = pairs[el[u]];
-        const KfvInfo &f = ctx->kfv[(size_t)p.j];
+    for (size_t u0 = 0; u0 < el.size();) {
+        const int j = pairs[el[u0]].j;
+        size_t u1 = u0;
+        int64_t windows_j = 0;
+        while (u1 < el.size() && pairs[el[u1]].j == j) windows_j += pairs[el[u1++]].last;
+        const KfvInfo &f = ctx->kfv[(size_t)j];
         const int nk = (int)(f.W - k + 1);
-        if (launches.empty() || launches.back().j != p.j) launches.push_back(Launch{p.j, tiles.size(), tiles.size()});
-        ps[u].s0 = streams.size();
-        for (int64_t win0 = 1; win0 < p.last; win0 += T) {
-            TileDesc td;
-            td.word_base = g->cd[(size_t)p.c].word_off + (win0 - 1) / 32;
-            td.win0 = win0;
-            td.dist_base = n_chunks;                                   // (chain launches: the stream's first chunk)
-            td.n_valid = (int32_t)std::min<int64_t>(T + 1, p.last - win0 + 1);
-            td.first_test = 0;
-            td.contig = p.c;
-            td.pad = 0;
-            tiles.push_back(td);
-            streams.push_back(ChainStream{win0, n_chunks, 0, td.n_valid, 0});
-            const int64_t nb = ((int64_t)td.n_valid + nk - 1 + 63) >> 6;
-            n_chunks += (nb + KGMA_CHAIN_STEPS - 1) / KGMA_CHAIN_STEPS;
-            total_steps += nb;
+        int64_t T;
+        {
+            const int64_t slots = (int64_t)std::max(1, ctx->n_cus) * chain_slots_per_cu(k, f.Smax <= 32767);
+            T = (windows_j + slots * 3 - 1) / (slots * 3);
+            if (const char *e = getenv("KGMA_CHAIN_STREAM")) T = atoll(e);                     // experiments / tests
+            T = std::min<int64_t>(std::max<int64_t>(((T + 63) / 64) * 64, 1024), (int64_t)1 << 18);
         }
-        ps[u].s1 = streams.size();
+        launches.push_back(Launch{j, tiles.size(), tiles.size(), T});
+        for (size_t u = u0; u < u1; u++) {
+            const ChainPair &p = pairs[el[u]];
+            ps[u].s0 = streams.size();
+            ps[u].T = T;
+            for (int64_t win0 = 1; win0 < p.last; win0 += T) {
+                TileDesc td;
+                td.word_base = g->cd[(size_t)p.c].word_off + (win0 - 1) / 32;
+                td.win0 = win0;
+                td.dist_base = n_chunks;                               // (chain launches: the stream's first chunk)
+                td.n_valid = (int32_t)std::min<int64_t>(T + 1, p.last - win0 + 1);
+                td.first_test = 0;
+                td.contig = p.c;
+                td.pad = 0;
+                tiles.push_back(td);
+                streams.push_back(ChainStream{win0, n_chunks, 0, td.n_valid, 0});
+                const int64_t nb = ((int64_t)td.n_valid + nk - 1 + 63) >> 6;
+                n_chunks += (nb + KGMA_CHAIN_STEPS - 1) / KGMA_CHAIN_STEPS;
+                total_steps += nb;
+            }
+            ps[u].s1 = streams.size();
+        }
         launches.back().t1 = tiles.size();
+        u0 = u1;
     }
     const int64_t n_tiles = (int64_t)tiles.size();
     if (n_tiles > 0x7FFFFFF0ll || n_chunks > 0x7FFFFFF0ll) return KGMA_OK;   // (left to the host chain)
@@ -2404,7 +2408,7 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
         const int nk = (int)(ctx->kfv[(size_t)p.j].W - k + 1);
         for (const ChainInterval &x : p.iv)
             for (int64_t w = std::max<int64_t>(x.lo, 2); w <= x.hi; w++) {
-                const int64_t si = (w - 2) / T;
+                const int64_t si = (w - 2) / ps[u].T;
                 const ChainStream &S = streams[ps[u].s0 + (size_t)si];
                 const int64_t pos = (w - S.win0) + nk - 1;
                 const int64_t cid = S.chunk_base + (pos >> (6 + KGMA_CHAIN_STEPS_LOG2));
@@ -2430,6 +2434,8 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
     // raw pool: the hot chunks, plus room for the chunks that go raw on a binade change; grown once if that was short
     int64_t raw_slots = hot_chunks * KGMA_CHAIN_STEPS + std::max<int64_t>(1 << 15, total_steps / 16);
     if (const char *e = getenv("KGMA_CHAIN_RAW_SLOTS")) raw_slots = std::max<int64_t>(1, atoll(e));   // tests: force the regrowth
+    info.setup_ms = now_ms() - ts0;
+    info.chunks = n_chunks;
     for (int attempt = 0;; attempt++) {
         info.attempts = attempt + 1;
         raw_slots = std::min<int64_t>(raw_slots, total_steps + KGMA_CHAIN_STEPS);
@@ -2491,6 +2497,7 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
     }
 
     // ---- download: D0 per stream, chunk records, the used part of the raw pool; the pairs' first residues ----
+    const double tc0 = now_ms();
     struct Rec { int32_t c; size_t dw_off, dw; };
     std::vector<Rec> recs;
     size_t first_dw = 0;
@@ -2519,6 +2526,7 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_first + r.dw_off * 4, g->d_inter + 2 * g->cd[(size_t)r.c].word_off, r.dw * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, sync_spin(ctx->stream));
     const double tw0 = now_ms();
+    info.copy_ms = tw0 - tc0;
     const int64_t *h_D0 = reinterpret_cast<const int64_t *>(ctx->h_cpin + off_D0);
     for (int64_t t = 0; t < n_tiles; t++) streams[(size_t)t].D0 = h_D0[t];
 
@@ -2699,9 +2707,9 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
     ctx->stats.chain_raw_steps = dev.raw_steps;
     ctx->stats.chain_max_drift = dev.max_drift;
     if (getenv("KGMA_CHAIN_DEBUG"))
-        fprintf(stderr, "chain on the device: %lld of %zu pairs, %lld windows in %lld streams, kernels %.2f ms (%d attempt(s)), host walk %.2f ms, %lld raw steps, drift <= %.3g\n",
-                (long long)dev.pairs, pairs.size(), (long long)dev.windows, (long long)dev.streams, dev.kernel_ms, dev.attempts, dev.walk_ms,
-                (long long)dev.raw_steps, dev.max_drift);
+        fprintf(stderr, "chain on the device: %lld of %zu pairs, %lld windows in %lld streams / %lld chunks, setup %.2f ms, kernels %.2f ms (%d attempt(s)), download %.2f ms, host walk %.2f ms, %lld raw steps, drift <= %.3g\n",
+                (long long)dev.pairs, pairs.size(), (long long)dev.windows, (long long)dev.streams, (long long)dev.chunks, dev.setup_ms, dev.kernel_ms, dev.attempts,
+                dev.copy_ms, dev.walk_ms, (long long)dev.raw_steps, dev.max_drift);
     std::vector<Pair *> hostp;
     for (size_t i = 0; i < pairs.size(); i++)
         if (!on_device[i]) hostp.push_back(&pairs[i]);

@@ -220,7 +220,7 @@ void chain_walk_one(ChainWalkJob &J)
         for (int64_t c = 0; c < n_chunks; c++) {
             const ChainChunk cc = J.chunks[S.chunk_base + c];
             const int64_t steps = std::min<int64_t>(KGMA_CHAIN_STEPS, n_blocks - c * KGMA_CHAIN_STEPS);
-            const int64_t nlead = (cc.info >> 2) & 63;
+            const int64_t nlead = (cc.info >> 2) & 255;
             if (nlead > steps) return;
             if (nlead > 0) {
                 uint64_t bits;
@@ -283,6 +283,8 @@ void run_chain_walks(ChainWalkJob *jobs, size_t n_jobs, int n_threads)
 }
 
 }  // namespace kgma
+
+extern "C" int kgma_chain_chunk_steps(void) { return kgma::KGMA_CHAIN_STEPS; }
 
 // C ABI: the host half of the device chain on caller-supplied chunk records (tests: the records come from a numpy
 // restatement of the kernel's arithmetic; the product path feeds it what stream8_kernel<..., CHAIN> wrote)

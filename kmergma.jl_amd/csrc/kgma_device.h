@@ -87,11 +87,14 @@ struct DevRecord {
 // exact integer D with a guard band) and for every step of a chunk the host marked hot (it holds a window whose
 // value the host wants).  The host walks the chunks of a record in order: one integer add per regular chunk, one
 // hardware add per raw increment.
-constexpr int KGMA_CHAIN_STEPS = 16;                           // 64-position steps per chunk (1024 positions)
-constexpr int KGMA_CHAIN_STEPS_LOG2 = 4;
+#ifndef KGMA_CHAIN_STEPS_LOG2_V
+#define KGMA_CHAIN_STEPS_LOG2_V 6
+#endif
+constexpr int KGMA_CHAIN_STEPS_LOG2 = KGMA_CHAIN_STEPS_LOG2_V;
+constexpr int KGMA_CHAIN_STEPS = 1 << KGMA_CHAIN_STEPS_LOG2;   // 64-position steps per chunk (64 steps = 4096 positions)
 struct ChainChunk {
     int64_t A0;           // ulps the leading steps add when the incoming value's mantissa is even
-    uint32_t info;        // bits 0-1: dA + 1 (A1 = A0 + dA);  bits 2-7: leading steps (0 ... KGMA_CHAIN_STEPS);
+    uint32_t info;        // bits 0-1: dA + 1 (A1 = A0 + dA);  bits 2-9: leading steps (0 ... KGMA_CHAIN_STEPS);
                           // bit 16: the raw pool overflowed (the increments of this chunk's raw steps are missing)
     uint32_t raw;         // raw steps: first 64-double slot of the raw pool (the steps follow each other)
 };

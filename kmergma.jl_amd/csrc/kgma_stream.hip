@@ -659,17 +659,19 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
     int64_t c_acc = 0;                                                // per lane: ulps its windows added in this chunk (even-parity a's)
     int32_t c_corr = 0, c_dA = 0;                                     // tie corrections for an even incoming value; A1 - A0
     uint32_t c_P = 0;                                                 // parity of the running value (for an even incoming value)
-    bool c_split = true;                                              // no tie yet in this chunk: an odd incoming value has the other parity
-    bool c_raw = false, c_raw_ok = false;                             // this chunk emits raw increments from step c_raw_b0 on
+    // (flags kept in ONE integer that is read through readfirstlane where it steers the step: the compiler then branches
+    //  on the scalar unit instead of masking lanes)
+    constexpr int CS_RAW = 1, CS_RAW_OK = 2, CS_SPLIT = 4;            // raw: this chunk emits raw increments from step c_raw_b0 on;
+    int c_state = CS_SPLIT;                                           // split: no tie yet in this chunk (an odd incoming value has the other parity)
     uint32_t c_raw_base = 0;
     int c_raw_b0 = 0, c_chunk_b0 = 0;
     int64_t c_gid = 0;
-    bool c_bvalid = false;                                            // the binade below holds for the running value
-    int32_t c_Elo = 0, c_Ehi = -1;                                    // E range (stream-relative) that stays inside it, guard band off
+    int32_t c_Elo = 0x7FFFFFFF, c_Ehi = -0x7FFFFFFF - 1;              // E range (stream-relative) that stays inside the binade, guard band
+                                                                      // off; empty (lo > hi): no binade is known to hold
     uint32_t c_XLhi = 0;                                              // high dword of 2^e
     // binade of the exact distance D / (2kN^2), with the E range in which the reference's value provably shares it
     auto chain_binade = [&](const int64_t D) {
-        c_bvalid = false;
+        c_Elo = 0x7FFFFFFF; c_Ehi = -0x7FFFFFFF - 1;
         if (D <= 0) return;
         const double scale = gpp->inv_scale[0];                       // 2kN^2 (an integer)
         const double Dd = (double)D;
@@ -685,7 +687,6 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
         if (!(el <= eh)) return;
         c_Elo = uni((int32_t)el); c_Ehi = uni((int32_t)eh);
         c_XLhi = (uint32_t)uni((int32_t)((uint32_t)(e + 1023) << 20));
-        c_bvalid = true;
     };
     // the rest of this chunk goes out as raw increments, from step b on; its leading steps as one translation
     auto chain_switch_raw = [&](const int b) {
@@ -705,21 +706,22 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
             cc.raw = base;
             a.chain.chunks[c_gid] = cc;
         }
-        c_raw = true; c_raw_ok = ok; c_raw_base = base; c_raw_b0 = b;
-        c_bvalid = false;                                             // nothing watches the binade while the chunk is raw
+        c_state = uni(CS_RAW | (ok ? CS_RAW_OK : 0));
+        c_raw_base = base; c_raw_b0 = b;
+        c_Elo = 0x7FFFFFFF; c_Ehi = -0x7FFFFFFF - 1;                  // nothing watches the binade while the chunk is raw
     };
     auto chain_begin = [&](const int b) {
-        c_chunk_b0 = b; c_acc = 0; c_corr = 0; c_dA = 0; c_P = 0; c_split = true; c_raw = false;
+        c_chunk_b0 = b; c_acc = 0; c_corr = 0; c_dA = 0; c_P = 0; c_state = CS_SPLIT;
         c_gid = td.dist_base + (b >> KGMA_CHAIN_STEPS_LOG2);
         const uint32_t hw = a.chain.hot[c_gid >> 5];
-        if (!c_bvalid && (b << 6) >= nk) {                            // (the first window's D is known)
+        if (uni((int)(c_Elo > c_Ehi)) && (b << 6) >= nk) {            // (no binade, and the first window's D is known)
             const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st_reg[ST_D0HI]) << 32) | (uint32_t)uni(st_reg[ST_D0LO]));
             chain_binade(D0 + 2 * (int64_t)gpp->N[0] * (int64_t)h_carry[0]);
         }
         if ((uni((int)hw) >> (c_gid & 31)) & 1) chain_switch_raw(b);
     };
     auto chain_end = [&](const int b) {
-        if (c_raw) return;
+        if (uni(c_state) & CS_RAW) return;
         const int64_t total = wave_sum_i64(c_acc) + (int64_t)c_corr;
         if (lane == 0) {
             ChainChunk cc;
@@ -998,7 +1000,8 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
                 //  __dadd_rn helpers of the HIP headers carry their own contraction flags and DO fuse)
                 double rl = (double)(uint32_t)Sl[0] * a.chain.invN;   // refVec[left] as RN(S * (1/N))
                 double rr = (double)(uint32_t)Sr[0] * a.chain.invN;   // refVec[right]
-                if (a.chain.form != 0) {
+                if (uni(a.chain.form) != 0) {
+                    asm volatile("");                                 // (a real branch: not both forms and a select)
                     // ... as RN(S / N): the product above is within an ulp of the quotient, its residual S - q N is exact
                     // in one fused multiply-add, and q + residual * RN(1/N) then rounds to the correctly rounded quotient
                     // (Markstein's division step; the host has checked the KFV's entries against exactly this sequence)
@@ -1014,17 +1017,14 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
                 inc = a.chain.SF * t;
                 inc = act ? inc : 0.0;
             }
-            if (!c_raw && ACT != 0) {
-                // every value of the step inside the binade?  (E of a lane without a transition is its lower neighbour's)
-                bool ok = c_bvalid;
-                if (ok) {
-                    const uint64_t inl = __builtin_amdgcn_sicmp(Ecur, c_Elo, 39 /* sge */) & __builtin_amdgcn_sicmp(Ecur, c_Ehi, 41 /* sle */);
-                    ok = (inl | ~ACT) == ~(uint64_t)0;
-                }
-                if (!ok) chain_switch_raw(b);
+            if (!(uni(c_state) & CS_RAW) && ACT != 0) {
+                // every value of the step inside the binade?  (E of a lane without a transition is its lower neighbour's;
+                // an empty range -- no binade known -- fails by itself)
+                const uint64_t inl = __builtin_amdgcn_sicmp(Ecur, c_Elo, 39 /* sge */) & __builtin_amdgcn_sicmp(Ecur, c_Ehi, 41 /* sle */);
+                if ((inl | ~ACT) != ~(uint64_t)0) chain_switch_raw(b);
             }
-            if (c_raw) {
-                if (c_raw_ok) a.chain.raw[((size_t)c_raw_base + (size_t)(b - c_raw_b0)) * 64 + (size_t)lane] = inc;
+            if (uni(c_state) & CS_RAW) {
+                if (uni(c_state) & CS_RAW_OK) a.chain.raw[((size_t)c_raw_base + (size_t)(b - c_raw_b0)) * 64 + (size_t)lane] = inc;
             } else if (ACT != 0) {
                 // RN(v + inc) for an even and an odd v of this binade, as hardware additions: anchors at the end of the
                 // binade the increment moves away from (2^e, or 2^(e+1) - 2 ulp), so that the sums stay inside
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
                         c_P ^= (uint32_t)__builtin_popcountll(O & below) & 1u;
                         const int32_t du = __builtin_amdgcn_readlane(delta, u);
                         const int32_t c0 = c_P ? du : 0;
-                        if (c_split) { c_dA = (c_P ? 0 : du) - c0; c_split = false; }
+                        if (uni(c_state) & CS_SPLIT) { c_dA = (c_P ? 0 : du) - c0; c_state = uni(c_state & ~CS_SPLIT); }
                         c_corr += c0;
                         c_P = 0;
                         O &= ~below;

@@ -32,7 +32,7 @@ EXPORTS = [
     "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips", "kgma_align_hits_device", "kgma_repack_scan_hits",
     "kgma_kmer_count_batch", "kgma_kmer_dist_batch", "kgma_step_begin", "kgma_step_end", "kgma_set_reserved_cus",
     "kgma_scan_aligned", "kgma_get_alignments", "kgma_set_residue_source", "kgma_host_chain_values",
-    "kgma_chain_values", "kgma_host_chain_walk",
+    "kgma_chain_values", "kgma_host_chain_walk", "kgma_chain_chunk_steps",
 ]
 
 
@@ -179,7 +179,11 @@ def host_chain_values(seq: bytes, ref, k: int, windowsize: int, intervals) -> np
     return out[:nn.value]
 
 
-CHAIN_STEPS = 16                 # kgma_device.h: KGMA_CHAIN_STEPS (64-position steps per chunk)
+def chain_steps() -> int:
+    """kgma_device.h: KGMA_CHAIN_STEPS (64-position steps per chunk of the device chain)."""
+    return int(load().kgma_chain_chunk_steps())
+
+
 CHAIN_CHUNK_DTYPE = np.dtype([("A0", "<i8"), ("info", "<u4"), ("raw", "<u4")])   # kgma_device.h: ChainChunk
 
 

@@ -6,7 +6,7 @@ import numpy as np
 
 from kmergma_amd import _lib
 
-STEPS = _lib.CHAIN_STEPS
+STEPS = _lib.chain_steps()
 GUARD = 2.0 ** -29
 
 _CODE = np.full(256, 3, dtype=np.int64)

@@ -22,7 +22,7 @@ def _seq(rng, n, genes):
     return bytes(a)
 
 
-@pytest.mark.parametrize("T", [1024, 4096, 64 * 300])
+@pytest.mark.parametrize("T", [1024, 4096, 64 * 300])   # (stream lengths below, at and above one 4096-position chunk)
 def test_walk_equals_oracle_chain(alp_ref, data_dir, T):
     from kmergma_amd import fasta
     import os
@@ -42,8 +42,8 @@ def test_walk_equals_oracle_chain(alp_ref, data_dir, T):
     iv = [(1, 1), (2, 5), (3100, 3130), (5001, 5300), (12010, 12011), (nwin - 70, nwin)]
     hot = [w for lo, hi in iv for w in range(lo, hi + 1)]
     em = chain_emul.emulate(inc, D, nk, T, scale, hot_windows=hot)
-    n_reg = int(((em["chunks"]["info"] >> 2) & 63 == _lib.CHAIN_STEPS).sum())
-    assert n_reg > 0 and em["raw"].size > 0       # both kinds of chunk are walked
+    n_lead = (em["chunks"]["info"] >> 2) & 255
+    assert int((n_lead > 0).sum()) > 0 and int((n_lead == 0).sum()) > 0 and em["raw"].size > 0   # both kinds of chunk are walked
     vals, drift = _lib.host_chain_walk(first, scale, nk, em["win0"], em["n_valid"], em["chunk_base"], em["D0"], em["chunks"], em["raw"], iv)
     want = np.concatenate([chain[lo - 1:hi] for lo, hi in iv])
     assert np.array_equal(vals, want)

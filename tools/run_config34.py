@@ -53,12 +53,19 @@ def main():
     def chain(name, mode, buff):
         """One scan with KGMA_F_CHAIN_REPLAY (host-side Float64 tie decider): what it costs on this workload."""
         import time
-        t = time.perf_counter()
-        ctx.scan(g, mode, buff, 0, _lib.F_CHAIN_REPLAY, None)
-        wall = (time.perf_counter() - t) * 1e3
-        st = ctx.stats()
-        out[name]["chain_replay"] = {"scan_call_wall_ms": round(wall, 1), "chain_ms": round(st["chain_ms"], 1),
-                                     "record_kfv_pairs": int(st["n_chain_pairs"]), "windows_walked": int(st["chain_windows"]),
+        best = None
+        for _ in range(3):
+            t = time.perf_counter()
+            ctx.scan(g, mode, buff, 0, _lib.F_CHAIN_REPLAY, None)
+            wall = (time.perf_counter() - t) * 1e3
+            st = ctx.stats()
+            if best is None or wall < best[0]:
+                best = (wall, st)
+        wall, st = best
+        out[name]["chain_replay"] = {"scan_call_wall_ms": round(wall, 1), "chain_ms": round(st["chain_ms"], 2),
+                                     "record_kfv_pairs": int(st["n_chain_pairs"]), "pairs_on_device": int(st["chain_device_pairs"]),
+                                     "chain_kernels_ms": round(st["chain_device_ms"], 2), "raw_steps": int(st["chain_raw_steps"]),
+                                     "max_drift": st["chain_max_drift"], "windows_walked": int(st["chain_windows"]),
                                      "n_hits": int(st["n_hits"]), "n_tie_flagged": int(st["n_tie_flagged"])}
 
     ctx.set_refs(6, [refs["RV"]], [refs["ws"]], [30.0], [refs["N"]])
