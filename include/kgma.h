@@ -66,14 +66,21 @@ enum {
                                        reference's running Float64 value does: for each (record, KFV) in
                                        which exact arithmetic has a tie -- equal minima, a minimum equal
                                        to the stale running minimum, a window exactly at the threshold --
-                                       the host re-runs the reference's Float64 update from the record's
-                                       first window (GenomeMiner.jl:46-47,70-77) on its threads and takes
-                                       the decisions from those values.  Costs host time per flagged
-                                       record (about 1.8 ns per window and KFV; kgma_stats.chain_ms); no dip
-                                       is left KGMA_HIT_TIE / KGMA_HIT_AT_THRESHOLD.  The first window's
-                                       sqeuclidean is summed left to right (Julia leaves the order of its
-                                       @simd reduction to the machine).  Ignored with KGMA_F_NO_TIE_RESOLVE
-                                       and by kgma_replay_dips (no residues on that rank).             */
+                                       the reference's Float64 update (GenomeMiner.jl:46-47,70-77) is
+                                       re-run from the record's first window and the decisions are taken
+                                       from those values.  The chain runs ON THE DEVICE (a variant of the
+                                       scan kernel forms every window's increment in the reference's
+                                       operation order; the host adds one integer per 4096-window chunk and
+                                       the raw increments where the value may change binade or is wanted:
+                                       kgma_device.h) for k = 5 ... 7, windows of <= 383 k-mers and KFVs whose
+                                       entries are S * (1/N) or S / N bit for bit; otherwise on host threads
+                                       (about 1.8 ns per window).  kgma_stats.chain_* report both.  No dip is
+                                       left KGMA_HIT_TIE / KGMA_HIT_AT_THRESHOLD.  CONVENTION: the first
+                                       window's sqeuclidean is summed left to right; Julia leaves the order of
+                                       that @simd reduction to the machine, so "identical to the reference"
+                                       means identical under this convention (it is order-free when N is a
+                                       power of two).  Ignored with KGMA_F_NO_TIE_RESOLVE and by
+                                       kgma_replay_dips (no residues on that rank).                    */
 };
 
 /* flags in kgma_hit.flags / kgma_dip.flags */
@@ -136,7 +143,8 @@ typedef struct {
     double replay_ms;          /* host time of the hit state machine                            */
     int64_t device_bytes;      /* device memory held by the context + current genome            */
     int32_t n_tiles, n_launches;
-    double chain_ms;           /* host time of the Float64 chain replay (KGMA_F_CHAIN_REPLAY), 0 if none ran   */
+    double chain_ms;           /* wall time of the Float64 chain replay (KGMA_F_CHAIN_REPLAY: selection, chain kernels,
+                                  downloads, host walk), 0 if none ran                                          */
     int64_t n_chain_pairs;     /* (record, KFV) pairs it re-ran                                                */
     int64_t chain_windows;     /* windows it walked (sum over the pairs)                                       */
     int64_t chain_device_pairs;/* ... of them walked by the chain kernel on the device (the rest: host threads)         */
@@ -235,8 +243,9 @@ int kgma_genome_repack(kgma_ctx *ctx, kgma_genome *g);
  * the reference's Float64 arithmetic produces wherever that does not hang on rounding noise.  Where it does -- dips
  * reported with KGMA_HIT_TIE / KGMA_HIT_AT_THRESHOLD, windows counted in kgma_stats.n_at_threshold -- exact arithmetic's
  * choice is returned unless KGMA_F_CHAIN_REPLAY is passed, which takes those decisions from a replay of the reference's
- * running value and leaves nothing flagged.  So: bit-identical with the flag; without it, bit-identical whenever
- * n_tie_flagged == 0 && n_at_threshold == 0.)
+ * running value and leaves nothing flagged.  So: identical to a sequential IEEE-754 evaluation of the reference with the
+ * flag (first window summed left to right, see the flag); without it, identical whenever n_tie_flagged == 0 &&
+ * n_at_threshold == 0.)
  * genome_pos0 is the cluster
  * engine's `genome_pos` keyword (OmnGenomeMiner.jl:25); ignored (0) by the single engine.
  * Results are kept in the context until the next scan. */
@@ -286,12 +295,12 @@ int kgma_chain_values(kgma_ctx *ctx, const kgma_genome *genome, int64_t contig, 
                       const int64_t *win_hi, int64_t n_intervals, double *out, int64_t cap, int64_t *n_out);
 
 /* HOST half of the device chain, exposed for tests: walks caller-supplied chunk records (the layout of
- * kgma_device.h's ChainChunk: int64 A0, uint32 info, uint32 raw) and raw increments exactly as the product does with
+ * kgma_device.h's ChainChunk: int64 A0, uint32 info, uint32 raw; `pool` = entries and raw increments in 16-byte units) exactly as the product does with
  * the kernel's output.  KGMA_E_STATE: the value drifted more than 2^-31 from the exact distance at a stream start. */
 int kgma_chain_chunk_steps(void);   /* 64-position steps per chunk (kgma_device.h: KGMA_CHAIN_STEPS) */
 int kgma_host_chain_walk(double first, double scale, int32_t nk, int64_t n_streams, const int64_t *win0, const int32_t *n_valid,
-                         const int64_t *chunk_base, const int64_t *D0, const void *chunks, int64_t n_chunks, const double *raw,
-                         int64_t raw_slots, const int64_t *win_lo, const int64_t *win_hi, int64_t n_intervals, double *out,
+                         const int64_t *chunk_base, const int64_t *D0, const void *chunks, int64_t n_chunks, const void *pool,
+                         int64_t pool_units, const int64_t *win_lo, const int64_t *win_hi, int64_t n_intervals, double *out,
                          int64_t cap, int64_t *n_out, double *max_drift);
 
 /* ---- scans sharded INSIDE a record (one process per GPU; kmergma_amd.parallel.scan_sharded) ----------

@@ -42,7 +42,7 @@ bool stream8_derive_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_
 bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16);
 int stream8_variant(int n_kfv);
 hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
-bool chain_applies(int k, int nk, int64_t n_ref);
+bool chain_applies(int k, int nk, int64_t n_ref, bool s16);
 int chain_slots_per_cu(int k, bool s16);
 hipError_t launch_chain(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 int pos_tables_per_pass(int k);
@@ -148,14 +148,16 @@ struct kgma_ctx {
     // first-window D per stream, {raw cursor, status}; one pinned mirror for what comes back
     TileDesc *d_ctiles = nullptr; int64_t ctiles_cap = 0;
     ChainChunk *d_cchunks = nullptr; int64_t cchunks_cap = 0;
-    double *d_craw = nullptr; int64_t craw_cap = 0;                      // doubles
-    uint32_t *d_chot = nullptr; int64_t chot_cap = 0;
+    ChainChunk *d_cpool = nullptr; int64_t cpool_cap = 0;                // units of 16 bytes
+    uint32_t *d_chot = nullptr; int64_t chot_cap = 0;                    // [hot bit words | prefix per word]
+    uint64_t *d_chmask = nullptr; int64_t chmask_cap = 0;                // hot steps of each hot chunk
+    double cpool_per_step = 0;                                           // pool units per step the last chain launches needed beyond their hot steps
     int64_t *d_cD0 = nullptr; int64_t cD0_cap = 0;
     unsigned int *d_cctl = nullptr;
     uint8_t *h_cpin = nullptr; size_t cpin_cap = 0;
     uint64_t next_uid = 1;
     // key of the tile table currently on the device
-    uint64_t tk_uid = 0; int tk_mode = -1, tk_version = 0, tk_k = 0; int64_t tk_maxws = 0;
+    uint64_t tk_uid = 0, tk_version = 0; int tk_mode = -1, tk_k = 0; int64_t tk_maxws = 0;
     // references
     int k = 0, m = 0;
     std::vector<KfvInfo> kfv;
@@ -481,7 +483,8 @@ void kgma_destroy(kgma_ctx *ctx)
     if (ctx->h_chain) (void)hipHostFree(ctx->h_chain);
     if (ctx->d_ctiles) (void)hipFree(ctx->d_ctiles);
     if (ctx->d_cchunks) (void)hipFree(ctx->d_cchunks);
-    if (ctx->d_craw) (void)hipFree(ctx->d_craw);
+    if (ctx->d_cpool) (void)hipFree(ctx->d_cpool);
+    if (ctx->d_chmask) (void)hipFree(ctx->d_chmask);
     if (ctx->d_chot) (void)hipFree(ctx->d_chot);
     if (ctx->d_cD0) (void)hipFree(ctx->d_cD0);
     if (ctx->d_cctl) (void)hipFree(ctx->d_cctl);
@@ -1521,7 +1524,8 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     }
     const int64_t nc = g->n_contigs;
     const bool want_dists = (flags & KGMA_F_RETURN_DISTS) != 0;
-    const int geom_version = use_stream ? 2 + 16 * ctx->reserved_cus + 16 * 1024 * ctx->n_cus + (stream_nw << 24) : 1;
+    // (what the stream table was sized for: reserved CUs < 2^10, CUs < 2^14, streams per CU < 2^16 -- 64 bits, no packing games)
+    const uint64_t geom_version = use_stream ? 2u + ((uint64_t)(uint32_t)ctx->reserved_cus << 4) + ((uint64_t)(uint32_t)ctx->n_cus << 16) + ((uint64_t)(uint32_t)stream_nw << 32) : 1u;
     {
         bool s8 = use_stream;
         if (use_stream)
@@ -1608,6 +1612,9 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         } else {
             P = (int64_t)scan_tile_stride_words((int)(maxws - k + 1)) * 32;
         }
+        if (getenv("KGMA_GEOM_DEBUG"))
+            fprintf(stderr, "scan geometry: %s, %d CUs (%d reserved), %d streams per CU, %lld windows -> streams of %lld\n", use_stream ? "stream" : "bitslice",
+                    ctx->n_cus, ctx->reserved_cus, use_stream ? stream_nw : 0, (long long)total_nwin, (long long)P);
         const int64_t stride_words = P / 32;
         ctx->tile_windows = P;
         for (int64_t c = 0; c < nc; c++) {
@@ -2331,23 +2338,44 @@ static bool chain_device_enabled()
     return !(e && !strcmp(e, "host"));
 }
 
+static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vector<ChainPair> &pairs, std::vector<size_t> el, std::vector<char> &done,
+                                 ChainDevInfo &info);
+
 static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<ChainPair> &pairs, std::vector<char> &done, ChainDevInfo &info)
 {
     const int k = ctx->k;
-    const int64_t NB = (int64_t)1 << (2 * k);
     std::vector<size_t> el;
-    const double ts0 = now_ms();
     for (size_t i = 0; i < pairs.size(); i++) {
         const ChainPair &p = pairs[i];
         const KfvInfo &f = ctx->kfv[(size_t)p.j];
         const int nk = (int)(f.W - k + 1);
-        if (!chain_applies(k, nk, f.N) || f.ref_form < 0 || p.last < 2) continue;
+        if (!chain_applies(k, nk, f.N, f.Smax <= 32767) || f.ref_form < 0 || p.last < 2) continue;
         if (chain_slots_per_cu(k, f.Smax <= 32767) < 1) continue;
         el.push_back(i);
     }
     if (el.empty()) return KGMA_OK;
-    std::stable_sort(el.begin(), el.end(), [&](size_t a, size_t b) { return pairs[a].j < pairs[b].j; });
     (void)hipSetDevice(ctx->device);
+    // batches of bounded size (2^36 windows: a chunk array of 256 MiB), in record order
+    int64_t BATCH_WINDOWS = (int64_t)1 << 36;
+    if (const char *e = getenv("KGMA_CHAIN_BATCH_WINDOWS")) BATCH_WINDOWS = std::max<int64_t>(1, atoll(e));   // tests
+    for (size_t u0 = 0; u0 < el.size();) {
+        size_t u1 = u0;
+        int64_t w = 0;
+        while (u1 < el.size() && (u1 == u0 || w + pairs[el[u1]].last <= BATCH_WINDOWS)) w += pairs[el[u1++]].last;
+        const int rc = chain_on_device_batch(ctx, g, pairs, std::vector<size_t>(el.begin() + (long)u0, el.begin() + (long)u1), done, info);
+        if (rc) return rc;
+        u0 = u1;
+    }
+    return KGMA_OK;
+}
+
+static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vector<ChainPair> &pairs, std::vector<size_t> el, std::vector<char> &done,
+                                 ChainDevInfo &info)
+{
+    const int k = ctx->k;
+    const int64_t NB = (int64_t)1 << (2 * k);
+    const double ts0 = now_ms();
+    std::stable_sort(el.begin(), el.end(), [&](size_t a, size_t b) { return pairs[a].j < pairs[b].j; });
 
     // transitions per stream, per launch (= per KFV): about three rounds of streams over the chip, 64 | T (streams start
     // on plane words), at most 2^18 (the drift a stream may add stays far below the guard band)
@@ -2400,26 +2428,43 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
     const int64_t n_tiles = (int64_t)tiles.size();
     if (n_tiles > 0x7FFFFFF0ll || n_chunks > 0x7FFFFFF0ll) return KGMA_OK;   // (left to the host chain)
 
-    // hot chunks: every chunk that holds a transition into a wanted window
-    std::vector<uint32_t> hot((size_t)(n_chunks + 31) / 32 + 1, 0u);
-    int64_t hot_chunks = 0;
-    for (size_t u = 0; u < el.size(); u++) {
-        const ChainPair &p = pairs[el[u]];
-        const int nk = (int)(ctx->kfv[(size_t)p.j].W - k + 1);
-        for (const ChainInterval &x : p.iv)
-            for (int64_t w = std::max<int64_t>(x.lo, 2); w <= x.hi; w++) {
-                const int64_t si = (w - 2) / ps[u].T;
-                const ChainStream &S = streams[ps[u].s0 + (size_t)si];
-                const int64_t pos = (w - S.win0) + nk - 1;
-                const int64_t cid = S.chunk_base + (pos >> (6 + KGMA_CHAIN_STEPS_LOG2));
-                uint32_t &word = hot[(size_t)(cid >> 5)];
-                if (!((word >> (cid & 31)) & 1u)) { word |= 1u << (cid & 31); hot_chunks++; }
-                // (jump to the chunk's end: the windows of one chunk share the bit)
-                const int64_t chunk_last_pos = ((pos >> (6 + KGMA_CHAIN_STEPS_LOG2)) + 1) * (64 * KGMA_CHAIN_STEPS) - 1;
-                const int64_t w_chunk_last = S.win0 + chunk_last_pos - nk + 1;
-                if (w_chunk_last > w) w = std::min(w_chunk_last, std::min<int64_t>(x.hi, S.win0 + S.n_valid - 1));
-            }
+    // hot steps: every step that holds a transition into a wanted window, as one 64-bit mask per chunk that has any
+    const size_t hot_words = (size_t)(n_chunks + 31) / 32 + 1;
+    std::vector<uint32_t> hot(2 * hot_words, 0u);                      // [bit per chunk | hot chunks before each word]
+    std::vector<uint64_t> hot_masks;
+    int64_t hot_steps = 0;
+    {
+        std::vector<std::pair<int64_t, uint64_t>> marks;               // (chunk, step bit), in stream order per pair
+        for (size_t u = 0; u < el.size(); u++) {
+            const ChainPair &p = pairs[el[u]];
+            const int nk = (int)(ctx->kfv[(size_t)p.j].W - k + 1);
+            for (const ChainInterval &x : p.iv)
+                for (int64_t w = std::max<int64_t>(x.lo, 2); w <= x.hi; w++) {
+                    const int64_t si = (w - 2) / ps[u].T;
+                    const ChainStream &S = streams[ps[u].s0 + (size_t)si];
+                    const int64_t pos = (w - S.win0) + nk - 1;
+                    const int64_t cid = S.chunk_base + (pos >> (6 + KGMA_CHAIN_STEPS_LOG2));
+                    marks.emplace_back(cid, (uint64_t)1 << ((pos >> 6) & (KGMA_CHAIN_STEPS - 1)));
+                    // (jump to the step's last window: the windows of one step share the bit)
+                    const int64_t w_step_last = S.win0 + (pos | 63) - nk + 1;
+                    if (w_step_last > w) w = std::min(w_step_last, std::min<int64_t>(x.hi, S.win0 + S.n_valid - 1));
+                }
+        }
+        std::sort(marks.begin(), marks.end());
+        for (size_t i = 0; i < marks.size();) {
+            uint64_t m = 0;
+            size_t j = i;
+            while (j < marks.size() && marks[j].first == marks[i].first) m |= marks[j++].second;
+            hot[(size_t)(marks[i].first >> 5)] |= 1u << (marks[i].first & 31);
+            hot_masks.push_back(m);
+            hot_steps += __builtin_popcountll(m);
+            i = j;
+        }
+        uint32_t before = 0;
+        for (size_t wd = 0; wd < hot_words; wd++) { hot[hot_words + wd] = before; before += (uint32_t)__builtin_popcount(hot[wd]); }
     }
+    const int64_t hot_chunks = (int64_t)hot_masks.size();
+    if (hot_masks.empty()) hot_masks.push_back(0);
 
     int rc = dev_reserve(ctx, ctx->d_ctiles, ctx->ctiles_cap, n_tiles);
     if (rc) return rc;
@@ -2427,28 +2472,37 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
     if (rc) return rc;
     rc = dev_reserve(ctx, ctx->d_chot, ctx->chot_cap, (int64_t)hot.size());
     if (rc) return rc;
+    rc = dev_reserve(ctx, ctx->d_chmask, ctx->chmask_cap, (int64_t)hot_masks.size());
+    if (rc) return rc;
     rc = dev_reserve(ctx, ctx->d_cD0, ctx->cD0_cap, n_tiles);
     if (rc) return rc;
     if (!ctx->d_cctl) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_cctl), 16));
 
-    // raw pool: the hot chunks, plus room for the chunks that go raw on a binade change; grown once if that was short
-    int64_t raw_slots = hot_chunks * KGMA_CHAIN_STEPS + std::max<int64_t>(1 << 15, total_steps / 16);
-    if (const char *e = getenv("KGMA_CHAIN_RAW_SLOTS")) raw_slots = std::max<int64_t>(1, atoll(e));   // tests: force the regrowth
-    info.setup_ms = now_ms() - ts0;
-    info.chunks = n_chunks;
+    // pool (16-byte units): 32 per raw step + up to KGMA_CHAIN_STEPS entries per detailed chunk.  The hot steps are
+    // known; for the steps that go raw on a binade change there is room for one in a few hundred, and the launch is
+    // repeated once with what it asked for if that was short
+    info.setup_ms += now_ms() - ts0;
+    info.chunks += n_chunks;
+    const int64_t full_units = total_steps * 33 + n_chunks + 64;       // every step raw
+    const int64_t hot_units = hot_steps * 32 + hot_chunks * KGMA_CHAIN_STEPS;
+    int64_t pool_units = hot_units + std::max<int64_t>(1 << 18, std::min<int64_t>(total_steps / 8, (int64_t)1 << 27));
+    if (ctx->cpool_per_step > 0)                                       // (what the previous scans of this context needed, with a margin)
+        pool_units = std::max(pool_units, hot_units + (int64_t)(1.25 * ctx->cpool_per_step * (double)total_steps) + (1 << 16));
+    if (const char *e = getenv("KGMA_CHAIN_POOL_UNITS")) pool_units = std::max<int64_t>(1, atoll(e));   // tests: force the regrowth
     for (int attempt = 0;; attempt++) {
-        info.attempts = attempt + 1;
-        raw_slots = std::min<int64_t>(raw_slots, total_steps + KGMA_CHAIN_STEPS);
-        if (raw_slots > 0xFFFFFFF0ll) return KGMA_OK;
-        if (ctx->craw_cap < raw_slots * 64) {
-            double *fresh = nullptr;
+        info.attempts = std::max(info.attempts, attempt + 1);
+        pool_units = std::min<int64_t>(pool_units, full_units);
+        if (pool_units > 0xFFFFFFF0ll) return KGMA_OK;
+        if (ctx->cpool_cap < pool_units) {
+            ChainChunk *fresh = nullptr;
             int64_t cap = 0;
-            if (dev_reserve(ctx, fresh, cap, raw_slots * 64) != KGMA_OK) { ctx->err.clear(); return KGMA_OK; }   // no room: host chain
-            if (ctx->d_craw) { (void)hipFree(ctx->d_craw); ctx->device_bytes -= ctx->craw_cap * 8; }
-            ctx->d_craw = fresh; ctx->craw_cap = cap;
+            if (dev_reserve(ctx, fresh, cap, pool_units) != KGMA_OK) { ctx->err.clear(); (void)hipGetLastError(); return KGMA_OK; }   // no room: host chain
+            if (ctx->d_cpool) { (void)hipFree(ctx->d_cpool); ctx->device_bytes -= ctx->cpool_cap * (int64_t)sizeof(ChainChunk); }
+            ctx->d_cpool = fresh; ctx->cpool_cap = cap;
         }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ctiles, tiles.data(), (size_t)n_tiles * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chot, hot.data(), hot.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chmask, hot_masks.data(), hot_masks.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_cctl, 0, 16, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         for (const Launch &L : launches) {
@@ -2469,13 +2523,29 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
             a.tiles = ctx->d_ctiles + L.t0;
             a.n_tiles = (int32_t)(L.t1 - L.t0);
             a.Stab = ctx->d_Stab + (size_t)L.j * (size_t)NB;
+            if (k >= 7) {
+                // k = 7: the kernel gathers S from global memory, one int16 per k-mer (the scan's interleaved layout with one slot)
+                std::vector<int> key{L.j, -1};
+                auto it = ctx->sinter.find(key);
+                if (it == ctx->sinter.end()) {
+                    std::vector<int16_t> tab((size_t)NB, 0);
+                    for (int64_t v = 0; v < NB; v++) tab[(size_t)device_index_of((uint32_t)v, k)] = (int16_t)f.S[(size_t)v];
+                    int16_t *d = nullptr;
+                    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d), tab.size() * sizeof(int16_t)));
+                    HIP_TRY(ctx, hipMemcpy(d, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+                    it = ctx->sinter.emplace(key, d).first;
+                }
+                a.Sinter = it->second;
+            }
             a.D0out = ctx->d_cD0 + L.t0;
             a.n_chunk_tiles = a.n_tiles;
             a.chain.chunks = ctx->d_cchunks;
-            a.chain.raw = ctx->d_craw;
-            a.chain.raw_cursor = ctx->d_cctl;
-            a.chain.raw_cap = (unsigned int)raw_slots;
+            a.chain.pool = ctx->d_cpool;
+            a.chain.pool_cursor = ctx->d_cctl;
+            a.chain.pool_cap = (unsigned int)pool_units;
             a.chain.hot = ctx->d_chot;
+            a.chain.hot_prefix = ctx->d_chot + hot_words;
+            a.chain.hot_masks = ctx->d_chmask;
             a.chain.invN = 1.0 / (double)f.N;
             a.chain.Nd = (double)f.N;
             a.chain.form = f.ref_form;
@@ -2491,9 +2561,13 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
         float ms = 0;
         (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
         info.kernel_ms += ms;
-        if (!(ctl[1] & 1u)) { raw_slots = std::min<int64_t>(raw_slots, (int64_t)ctl[0]); break; }
-        if (attempt >= 1 || raw_slots >= total_steps) return KGMA_OK;                 // (cannot happen with a full pool)
-        raw_slots = std::max<int64_t>((int64_t)ctl[0] + KGMA_CHAIN_STEPS, total_steps / 2);
+        if (!(ctl[1] & 1u)) {
+            pool_units = std::min<int64_t>(pool_units, (int64_t)ctl[0]);
+            ctx->cpool_per_step = std::max(0.0, (double)(pool_units - hot_units)) / (double)std::max<int64_t>(1, total_steps);
+            break;
+        }
+        if (attempt >= 1 || pool_units >= full_units) return KGMA_OK;                 // (cannot happen: the second pool is what the first launch asked for)
+        pool_units = (int64_t)ctl[0] + (ctl[0] >> 4) + 4096;
     }
 
     // ---- download: D0 per stream, chunk records, the used part of the raw pool; the pairs' first residues ----
@@ -2510,7 +2584,7 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
     }
     for (Rec &r : recs) { r.dw_off = first_dw; first_dw += r.dw + 2; }
     const size_t off_D0 = 0, off_chunks = off_D0 + (size_t)n_tiles * 8, off_raw = off_chunks + (size_t)n_chunks * sizeof(ChainChunk),
-                 off_first = off_raw + (size_t)raw_slots * 512, pin_need = off_first + first_dw * 4 + 64;
+                 off_first = off_raw + (size_t)pool_units * sizeof(ChainChunk), pin_need = off_first + first_dw * 4 + 64;
     if (pin_need > ctx->cpin_cap) {
         if (ctx->h_cpin) (void)hipHostFree(ctx->h_cpin);
         ctx->h_cpin = nullptr; ctx->cpin_cap = 0;
@@ -2520,13 +2594,13 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_D0, ctx->d_cD0, (size_t)n_tiles * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_chunks, ctx->d_cchunks, (size_t)n_chunks * sizeof(ChainChunk), hipMemcpyDeviceToHost, ctx->stream));
-    if (raw_slots > 0)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_raw, ctx->d_craw, (size_t)raw_slots * 512, hipMemcpyDeviceToHost, ctx->stream));
+    if (pool_units > 0)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_raw, ctx->d_cpool, (size_t)pool_units * sizeof(ChainChunk), hipMemcpyDeviceToHost, ctx->stream));
     for (const Rec &r : recs)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_first + r.dw_off * 4, g->d_inter + 2 * g->cd[(size_t)r.c].word_off, r.dw * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, sync_spin(ctx->stream));
     const double tw0 = now_ms();
-    info.copy_ms = tw0 - tc0;
+    info.copy_ms += tw0 - tc0;
     const int64_t *h_D0 = reinterpret_cast<const int64_t *>(ctx->h_cpin + off_D0);
     for (int64_t t = 0; t < n_tiles; t++) streams[(size_t)t].D0 = h_D0[t];
 
@@ -2562,8 +2636,8 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
         J.nk = (int)(f.W - k + 1);
         J.streams = streams.data() + ps[u].s0; J.n_streams = ps[u].s1 - ps[u].s0;
         J.chunks = reinterpret_cast<const ChainChunk *>(ctx->h_cpin + off_chunks);
-        J.raw = reinterpret_cast<const double *>(ctx->h_cpin + off_raw);
-        J.raw_slots = raw_slots;
+        J.pool = reinterpret_cast<const ChainChunk *>(ctx->h_cpin + off_raw);
+        J.pool_units = pool_units;
         J.iv = p.iv.data(); J.n_iv = p.iv.size(); J.out = p.val.data();
     }
     run_chain_walks(walks.data(), walks.size(), n_threads);
@@ -2581,8 +2655,8 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
         info.windows += pairs[el[u]].last;
         info.raw_steps += J.raw_steps;
     }
-    info.streams = n_tiles;
-    info.walk_ms = now_ms() - tw0;
+    info.streams += n_tiles;
+    info.walk_ms += now_ms() - tw0;
     return KGMA_OK;
 }
 
@@ -2797,6 +2871,32 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
         const int64_t nwin = ctx->contig_nwin[(size_t)p.c];
         ctx->chain_pair[(size_t)p.j * (size_t)nc + (size_t)p.c] = 1;
         ctx->firstF[(size_t)p.j * (size_t)nc + (size_t)p.c] = p.val[0];
+        {
+            // The windows sampled above are the ones whose EXACT distance is under (or within 2^-30 of) the threshold: that
+            // covers every window the reference's value can be under thr at only while the chain stays within 2^-30 of the
+            // exact distance.  Checked where both are known -- the first window and every dip's minimum (the device chain
+            // has checked every stream start too): a chain that drifted further is an error, never a silent miss.
+            auto value_at = [&](int64_t w) -> const double * {
+                size_t off = 0;
+                for (const ChainInterval &x : p.iv) {
+                    if (w >= x.lo && w <= x.hi) return &p.val[off + (size_t)(w - x.lo)];
+                    off += (size_t)(x.hi - x.lo + 1);
+                }
+                return nullptr;
+            };
+            auto drifted = [&](int64_t w, int64_t D) {
+                const double *v = value_at(w);
+                if (!v || D <= 0) return false;
+                const double exact = (double)D / scale, dr = std::fabs(*v - exact) / exact;
+                ctx->stats.chain_max_drift = std::max(ctx->stats.chain_max_drift, dr);
+                return dr > 4.656612873077393e-10;                      // 2^-31
+            };
+            bool bad = drifted(1, ctx->firstD[(size_t)p.j * (size_t)nc + (size_t)p.c]);
+            for (size_t u = p.d0; u < p.d1 && !bad; u++) bad = drifted(ctx->dips[u].argmin, ctx->dips[u].D_min);
+            if (bad)
+                return fail(ctx, KGMA_E_STATE, "chain replay: the running Float64 value of record %d KFV %d has drifted more than 2^-31 from the exact distance; "
+                            "the threshold guard band (2^-30) no longer covers it", p.c, p.j + 1);
+        }
         bool in_run = false;
         DipX cur{};
         int64_t prev_w = 0;
@@ -2904,7 +3004,7 @@ int kgma_chain_values(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int32
     const int rc = chain_on_device(ctx, g, pairs, done, info);
     if (rc) return rc;
     if (!done[0])
-        return fail(ctx, KGMA_E_UNSUPPORTED, "the chain kernel does not serve this KFV (k = 5 or 6, at most 383 k-mers per window, KFV = S * (1/N), last window >= 2) or a check failed");
+        return fail(ctx, KGMA_E_UNSUPPORTED, "the chain kernel does not serve this KFV (k = 5, 6 or 7, at most 383 k-mers per window, KFV = S * (1/N) or S / N entry by entry, last window >= 2) or a check failed");
     memcpy(out, p.val.data(), (size_t)total * sizeof(double));
     ctx->stats.chain_device_pairs = info.pairs; ctx->stats.chain_device_ms = info.kernel_ms;
     ctx->stats.chain_raw_steps = info.raw_steps; ctx->stats.chain_max_drift = info.max_drift;
@@ -3028,8 +3128,10 @@ int kgma_scan_aligned(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t
     if (!consensus || !consensus_len) return fail(ctx, KGMA_E_ARG, "null consensus");
     if (buff < 0) return fail(ctx, KGMA_E_ARG, "buff < 0");
     const int m_used = mode == KGMA_MODE_SINGLE ? 1 : ctx->m;
+    // (an empty consensus is only an error once there is something to align against it, as in the reference, where
+    //  ac_gma_testing!'s default consensus_refseq fails inside pairalign at the first hit, not before)
     for (int j = 0; j < m_used; j++)
-        if (!consensus[j] || consensus_len[j] < 1 || consensus_len[j] > KGMA_ALIGN_MAX_CONSENSUS)
+        if (consensus_len[j] < 0 || consensus_len[j] > KGMA_ALIGN_MAX_CONSENSUS || (consensus_len[j] > 0 && !consensus[j]))
             return fail(ctx, KGMA_E_UNSUPPORTED, "consensus %d: %lld residues", j + 1, (long long)consensus_len[j]);
     ctx->aligns.clear();
     ctx->n_align_device = ctx->n_align_host = 0;
@@ -3051,6 +3153,7 @@ int kgma_scan_aligned(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t
         if (nh == 0) return KGMA_OK;
         const int64_t W = ctx->kfv[0].W;
         const int64_t cl = std::min<int64_t>(consensus_len[0], W);
+        if (cl < 1) return fail(ctx, KGMA_E_UNSUPPORTED, "consensus 1 is empty and %lld hits are to be aligned against it", (long long)nh);
         std::vector<int32_t> hc((size_t)nh);
         std::vector<int64_t> lo((size_t)nh), hi((size_t)nh), first((size_t)nh), last((size_t)nh);
         for (int64_t i = 0; i < nh; i++) { hc[(size_t)i] = ctx->hits[(size_t)i].contig; lo[(size_t)i] = ctx->hits[(size_t)i].lo; hi[(size_t)i] = ctx->hits[(size_t)i].hi; }
@@ -3087,6 +3190,7 @@ int kgma_scan_aligned(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t
             v.erase(std::unique(v.begin(), v.end(), [](const AlignKey &a, const AlignKey &b) { return !(a < b) && !(b < a); }), v.end());
             const int64_t n = (int64_t)v.size();
             if (n == 0) continue;
+            if (consensus_len[j] < 1) return fail(ctx, KGMA_E_UNSUPPORTED, "consensus %d is empty and %lld candidate ranges are to be aligned against it", j + 1, (long long)n);
             std::vector<int32_t> hc((size_t)n);
             std::vector<int64_t> lo((size_t)n), hi((size_t)n), first((size_t)n), last((size_t)n);
             for (int64_t i = 0; i < n; i++) { hc[(size_t)i] = v[(size_t)i].contig; lo[(size_t)i] = v[(size_t)i].lo; hi[(size_t)i] = v[(size_t)i].hi; }

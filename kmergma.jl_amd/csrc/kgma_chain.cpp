@@ -177,7 +177,7 @@ void run_chain_jobs(ChainJob *jobs, size_t n_jobs, int n_threads)
 
 // ---- host half of the device chain ---------------------------------------------------------------------------
 // Inside a binade a double's bit pattern IS its count of ulps, so a regular chunk is one integer add to the pattern
-// (A0 or A0 + dA by the pattern's low bit); raw steps are hardware additions of the increments the device formed.
+// (A0 or A0 + dA by the pattern's low bit) per run of regular steps; raw steps are hardware additions of the increments the device formed.
 // At every stream start the value is compared with the exact distance of that window: the device decided which
 // windows may leave a binade on exact values with a 2^-29 guard band, which is sound while the chain has drifted
 // less than that from the exact value -- 2^-31 is demanded here, a stream adds at most 2^-35.
@@ -220,32 +220,47 @@ void chain_walk_one(ChainWalkJob &J)
         for (int64_t c = 0; c < n_chunks; c++) {
             const ChainChunk cc = J.chunks[S.chunk_base + c];
             const int64_t steps = std::min<int64_t>(KGMA_CHAIN_STEPS, n_blocks - c * KGMA_CHAIN_STEPS);
-            const int64_t nlead = (cc.info >> 2) & 255;
-            if (nlead > steps) return;
-            if (nlead > 0) {
+            auto apply = [&](const ChainChunk &r) {
                 uint64_t bits;
                 memcpy(&bits, &v, 8);
-                const int64_t dA = (int64_t)(cc.info & 3u) - 1;
-                bits += (uint64_t)((bits & 1u) ? cc.A0 + dA : cc.A0);
+                const int64_t dA = (int64_t)(r.info & 3u) - 1;
+                bits += (uint64_t)((bits & 1u) ? r.A0 + dA : r.A0);
                 memcpy(&v, &bits, 8);
+            };
+            int64_t covered = (cc.info >> 2) & 255;                      // the leading run
+            if (covered > steps) return;
+            if (covered > 0) apply(cc);
+            if (!(cc.info & KGMA_CHAIN_DETAIL)) {
+                if (covered != steps) return;
+                continue;
             }
-            if (nlead == steps) continue;
-            if (cc.info & (1u << 16)) { J.status = CHAIN_WALK_OVERFLOW; return; }
-            if ((int64_t)cc.raw + (steps - nlead) > J.raw_slots) return;
-            const double *r = J.raw + (size_t)cc.raw * 64;
-            int64_t p = (c * KGMA_CHAIN_STEPS + nlead) * 64;
-            const int64_t p_end = (c * KGMA_CHAIN_STEPS + steps) * 64;
-            J.raw_steps += steps - nlead;
-            const int64_t w_first = S.win0 + (p - nk + 1), w_last = S.win0 + (p_end - 1 - nk + 1);
-            if (w_last < cur_lo || cur_lo == INT64_MAX) {
-                for (; p < p_end; p++) v += *r++;                        // (positions outside the stream hold 0.0)
-            } else {
-                (void)w_first;
-                for (; p < p_end; p++) {
-                    v += *r++;
-                    const int64_t q = p - nk + 1;
-                    if (q >= 1 && q < S.n_valid) sample(S.win0 + q, v);
+            int64_t e = cc.raw;                                          // entries: later runs and raw steps, in order
+            while (covered < steps) {
+                if (e < 0 || e >= J.pool_units) return;
+                const ChainChunk ent = J.pool[e++];
+                if (!(ent.info & KGMA_CHAIN_RAW)) {
+                    const int64_t m = (ent.info >> 2) & 255;
+                    if (m < 1 || covered + m > steps) return;
+                    apply(ent);
+                    covered += m;
+                    continue;
                 }
+                if ((int64_t)ent.raw + 32 > J.pool_units) return;
+                const double *r = reinterpret_cast<const double *>(J.pool) + (size_t)ent.raw * 2;
+                int64_t p = (c * KGMA_CHAIN_STEPS + covered) * 64;
+                const int64_t p_end = p + 64;
+                J.raw_steps++;
+                const int64_t w_last = S.win0 + (p_end - 1 - nk + 1);
+                if (w_last < cur_lo || cur_lo == INT64_MAX) {
+                    for (; p < p_end; p++) v += *r++;                    // (positions outside the stream hold 0.0)
+                } else {
+                    for (; p < p_end; p++) {
+                        v += *r++;
+                        const int64_t q = p - nk + 1;
+                        if (q >= 1 && q < S.n_valid) sample(S.win0 + q, v);
+                    }
+                }
+                covered += 1;
             }
         }
     }
@@ -290,7 +305,7 @@ extern "C" int kgma_chain_chunk_steps(void) { return kgma::KGMA_CHAIN_STEPS; }
 // restatement of the kernel's arithmetic; the product path feeds it what stream8_kernel<..., CHAIN> wrote)
 extern "C" int kgma_host_chain_walk(double first, double scale, int32_t nk, int64_t n_streams, const int64_t *win0,
                                     const int32_t *n_valid, const int64_t *chunk_base, const int64_t *D0, const void *chunks,
-                                    int64_t n_chunks, const double *raw, int64_t raw_slots, const int64_t *win_lo,
+                                    int64_t n_chunks, const void *pool, int64_t pool_units, const int64_t *win_lo,
                                     const int64_t *win_hi, int64_t n_intervals, double *out, int64_t cap, int64_t *n_out,
                                     double *max_drift)
 {
@@ -315,7 +330,7 @@ extern "C" int kgma_host_chain_walk(double first, double scale, int32_t nk, int6
     if (cap < total) return KGMA_E_ARG;
     kgma::ChainWalkJob J{};
     J.first = first; J.scale = scale; J.nk = nk; J.streams = st.data(); J.n_streams = st.size();
-    J.chunks = static_cast<const kgma::ChainChunk *>(chunks); J.raw = raw; J.raw_slots = raw_slots;
+    J.chunks = static_cast<const kgma::ChainChunk *>(chunks); J.pool = static_cast<const kgma::ChainChunk *>(pool); J.pool_units = pool_units;
     J.iv = iv.data(); J.n_iv = iv.size(); J.out = out;
     kgma::run_chain_walks(&J, 1, 1);
     if (max_drift) *max_drift = J.max_drift;

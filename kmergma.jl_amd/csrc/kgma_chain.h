@@ -53,9 +53,9 @@ struct ChainWalkJob {
     const ChainStream *streams;
     size_t n_streams;
     const ChainChunk *chunks;  // the whole chunk array of the launch
-    const double *raw;         // the raw pool (64 doubles per step)
-    int64_t raw_slots;         // slots downloaded (bounds check)
-    const ChainInterval *iv;   // windows to sample (sorted, disjoint); every chunk that holds one was marked hot
+    const ChainChunk *pool;    // the pool: entries of detailed chunks, raw increments (64 doubles = 32 units per raw step)
+    int64_t pool_units;        // units downloaded (bounds check)
+    const ChainInterval *iv;   // windows to sample (sorted, disjoint); every step that holds one was marked hot
     size_t n_iv;
     double *out;
     int64_t n_out;

@@ -81,29 +81,34 @@ struct DevRecord {
 // the sum lands exactly half way between two doubles (then the even neighbour wins and the result is EVEN whatever
 // v was).  So a run of windows inside one binade is a translation by the sum of its a's, corrected at the ties by
 // the parity the value has there -- a parity that only the run's FIRST tie can inherit from the incoming value.
-// A chain stream cuts its positions into chunks of KGMA_CHAIN_STEPS steps; per chunk it emits the translation for
-// both parities of the incoming value (A0, A1 = A0 + dA) over the chunk's leading steps, and the raw Float64
-// increments of the remaining steps -- from the first step in which some window may leave the binade (decided on the
-// exact integer D with a guard band) and for every step of a chunk the host marked hot (it holds a window whose
-// value the host wants).  The host walks the chunks of a record in order: one integer add per regular chunk, one
-// hardware add per raw increment.
+// A chain stream cuts its positions into steps of 64 and chunks of KGMA_CHAIN_STEPS steps.  A step is RAW when the
+// host marked it hot (it holds a window whose value the host wants) or when one of its windows may leave the binade
+// (decided on the exact integer D with a guard band): its 64 Float64 increments go to the pool.  Every other step
+// is regular, and consecutive regular steps of a chunk are one RUN: a translation for both parities of the incoming
+// value (A0, A1 = A0 + dA).  A chunk without a raw step is its one record in the chunk array; a chunk with raw steps
+// is "detailed": its record holds the leading run and points at a list of entries in the pool, one per later run and
+// per raw step, in order.  The host walks a record's chunks in order: an integer add per run, a hardware add per raw
+// increment (kgma_chain.cpp).
 #ifndef KGMA_CHAIN_STEPS_LOG2_V
 #define KGMA_CHAIN_STEPS_LOG2_V 6
 #endif
 constexpr int KGMA_CHAIN_STEPS_LOG2 = KGMA_CHAIN_STEPS_LOG2_V;
-constexpr int KGMA_CHAIN_STEPS = 1 << KGMA_CHAIN_STEPS_LOG2;   // 64-position steps per chunk (64 steps = 4096 positions)
-struct ChainChunk {
-    int64_t A0;           // ulps the leading steps add when the incoming value's mantissa is even
-    uint32_t info;        // bits 0-1: dA + 1 (A1 = A0 + dA);  bits 2-9: leading steps (0 ... KGMA_CHAIN_STEPS);
-                          // bit 16: the raw pool overflowed (the increments of this chunk's raw steps are missing)
-    uint32_t raw;         // raw steps: first 64-double slot of the raw pool (the steps follow each other)
+constexpr int KGMA_CHAIN_STEPS = 1 << KGMA_CHAIN_STEPS_LOG2;   // 64-position steps per chunk (64 steps = 4096 positions; <= 64: one hot bit per step)
+constexpr uint32_t KGMA_CHAIN_RAW = 1u << 10;                  // entry: one raw step, `raw` = pool unit of its 64 doubles
+constexpr uint32_t KGMA_CHAIN_DETAIL = 1u << 11;               // chunk record: `raw` = pool unit of its entry list
+struct ChainChunk {       // a chunk's record, or an entry of a detailed chunk (16 bytes = one pool unit)
+    int64_t A0;           // ulps the run adds when the incoming value's mantissa is even
+    uint32_t info;        // bits 0-1: dA + 1 (A1 = A0 + dA);  bits 2-9: steps of the run;  KGMA_CHAIN_RAW / KGMA_CHAIN_DETAIL
+    uint32_t raw;
 };
 struct ChainArgs {
     ChainChunk *chunks;           // [all chunks of the launch] (a stream's first chunk: TileDesc::dist_base)
-    double *raw;                  // raw pool: 64 doubles per step
-    unsigned int *raw_cursor;     // slots handed out
-    unsigned int raw_cap;         // slots available
-    const uint32_t *hot;          // one bit per chunk: emit every step raw
+    ChainChunk *pool;             // entries of detailed chunks and raw increments (64 doubles = 32 units per raw step)
+    unsigned int *pool_cursor;    // units handed out
+    unsigned int pool_cap;        // units available
+    const uint32_t *hot;          // one bit per chunk: it has hot steps
+    const uint32_t *hot_prefix;   // per word of `hot`: hot chunks before it
+    const uint64_t *hot_masks;    // per hot chunk, in chunk order: its hot steps
     double invN;                  // RN(1 / N)
     double Nd;                    // N
     int32_t form;                 // how the KFV's Float64 entries follow from S (checked entry by entry on the host):
@@ -112,7 +117,7 @@ struct ChainArgs {
     int32_t pad;
     double SF;                    // ScaleFactor = 1 / k (src/API.jl:86,204)
     double guard;                 // relative guard band around the powers of two (2^-29)
-    unsigned int *status;         // bit 0: raw pool overflow
+    unsigned int *status;         // bit 0: the pool ran out
 };
 
 // Arguments of one scan launch (either kernel).

@@ -27,9 +27,12 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <dlfcn.h>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -656,16 +659,17 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
     const uint32_t sbase = (uint32_t)uni((int)(uint32_t)(uintptr_t)(lds_u32 *)smem);   // LDS byte offset of the S tables (0: the kernel has no static LDS)
 
     // ---- CHAIN state (wave-uniform except c_acc) ---------------------------------------------------------------
-    int64_t c_acc = 0;                                                // per lane: ulps its windows added in this chunk (even-parity a's)
+    int64_t c_acc = 0;                                                // per lane: ulps its windows added in the current regular run (even-parity a's)
     int32_t c_corr = 0, c_dA = 0;                                     // tie corrections for an even incoming value; A1 - A0
     uint32_t c_P = 0;                                                 // parity of the running value (for an even incoming value)
     // (flags kept in ONE integer that is read through readfirstlane where it steers the step: the compiler then branches
     //  on the scalar unit instead of masking lanes)
-    constexpr int CS_RAW = 1, CS_RAW_OK = 2, CS_SPLIT = 4;            // raw: this chunk emits raw increments from step c_raw_b0 on;
-    int c_state = CS_SPLIT;                                           // split: no tie yet in this chunk (an odd incoming value has the other parity)
-    uint32_t c_raw_base = 0;
-    int c_raw_b0 = 0, c_chunk_b0 = 0;
+    constexpr int CS_SPLIT = 1, CS_DETAIL = 2, CS_FULL = 4;           // split: no tie yet in this run (an odd incoming value has the other parity);
+    int c_state = CS_SPLIT;                                           // detail: this chunk has a raw step, its runs go out as entries; full: the pool ran out
+    uint32_t c_ent = 0;                                               // pool unit of the next entry of a detailed chunk
+    int c_run_b0 = 0, c_chunk_b0 = 0;                                 // first step of the current regular run, of the chunk
     int64_t c_gid = 0;
+    uint64_t c_hot = 0;                                               // steps of this chunk that hold a wanted window
     int32_t c_Elo = 0x7FFFFFFF, c_Ehi = -0x7FFFFFFF - 1;              // E range (stream-relative) that stays inside the binade, guard band
                                                                       // off; empty (lo > hi): no binade is known to hold
     uint32_t c_XLhi = 0;                                              // high dword of 2^e
@@ -688,49 +692,87 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
         c_Elo = uni((int32_t)el); c_Ehi = uni((int32_t)eh);
         c_XLhi = (uint32_t)uni((int32_t)((uint32_t)(e + 1023) << 20));
     };
-    // the rest of this chunk goes out as raw increments, from step b on; its leading steps as one translation
-    auto chain_switch_raw = [&](const int b) {
-        const int nlead = b - c_chunk_b0;
-        const int64_t total = wave_sum_i64(c_acc) + (int64_t)c_corr;
-        int left = n_blocks - c_chunk_b0;
-        left = (left > KGMA_CHAIN_STEPS ? KGMA_CHAIN_STEPS : left) - nlead;
+    // n units of the pool (16 bytes each); past its end nothing is written and the launch is repeated with a larger one
+    auto pool_alloc = [&](const unsigned int n) -> uint32_t {
         unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(a.chain.raw_cursor, (unsigned int)left);
+        if (lane == 0) base = atomicAdd(a.chain.pool_cursor, n);
         base = (unsigned int)uni((int)base);
-        const bool ok = (uint64_t)base + (uint64_t)left <= (uint64_t)a.chain.raw_cap;
-        if (lane == 0) {
-            if (!ok) atomicOr(a.chain.status, 1u);
-            ChainChunk cc;
-            cc.A0 = total;
-            cc.info = (uint32_t)(c_dA + 1) | ((uint32_t)nlead << 2) | (ok ? 0u : 1u << 16);
-            cc.raw = base;
-            a.chain.chunks[c_gid] = cc;
+        if ((uint64_t)base + (uint64_t)n > (uint64_t)a.chain.pool_cap) {
+            if (lane == 0) atomicOr(a.chain.status, 1u);
+            c_state = uni(c_state | CS_FULL);
         }
-        c_state = uni(CS_RAW | (ok ? CS_RAW_OK : 0));
-        c_raw_base = base; c_raw_b0 = b;
-        c_Elo = 0x7FFFFFFF; c_Ehi = -0x7FFFFFFF - 1;                  // nothing watches the binade while the chunk is raw
+        return base;
+    };
+    auto run_reset = [&](const int b_next) {
+        c_acc = 0; c_corr = 0; c_dA = 0; c_P = 0;
+        c_state = uni((c_state & ~CS_SPLIT) | CS_SPLIT);
+        c_run_b0 = b_next;
+    };
+    // closes the regular run [c_run_b0, b_end): the chunk's own record while it has no raw step, an entry afterwards
+    auto close_run = [&](const int b_end, const bool to_detail) {
+        const int n = b_end - c_run_b0;
+        const int st = uni(c_state);
+        if (!(st & CS_DETAIL)) {
+            const int64_t total = wave_sum_i64(c_acc) + (int64_t)c_corr;
+            uint32_t base = 0;
+            if (to_detail) {
+                int left = n_blocks - c_chunk_b0;                     // one entry per remaining step at most
+                left = (left > KGMA_CHAIN_STEPS ? KGMA_CHAIN_STEPS : left) - n;
+                base = pool_alloc((unsigned int)left);
+                c_ent = base;
+                c_state = uni(c_state | CS_DETAIL);
+            }
+            if (lane == 0) {
+                ChainChunk cc;
+                cc.A0 = total;
+                cc.info = (uint32_t)(c_dA + 1) | ((uint32_t)n << 2) | (to_detail ? KGMA_CHAIN_DETAIL : 0u);
+                cc.raw = base;
+                a.chain.chunks[c_gid] = cc;
+            }
+        } else if (n > 0) {
+            const int64_t total = wave_sum_i64(c_acc) + (int64_t)c_corr;
+            if (lane == 0 && !(st & CS_FULL)) {
+                ChainChunk cc;
+                cc.A0 = total;
+                cc.info = (uint32_t)(c_dA + 1) | ((uint32_t)n << 2);
+                cc.raw = 0;
+                a.chain.pool[c_ent] = cc;
+            }
+            c_ent += 1;
+        }
+    };
+    // step b goes out as raw increments (it holds a wanted window, or a window of it may leave the binade)
+    auto raw_step = [&](const int b, const double inc) {
+        close_run(b, true);
+        const uint32_t slot = pool_alloc(32);                          // 64 doubles
+        if (!(uni(c_state) & CS_FULL)) {
+            if (lane == 0) {
+                ChainChunk cc;
+                cc.A0 = 0;
+                cc.info = 1u | (1u << 2) | KGMA_CHAIN_RAW;
+                cc.raw = slot;
+                a.chain.pool[c_ent] = cc;
+            }
+            reinterpret_cast<double *>(a.chain.pool)[(size_t)slot * 2 + (size_t)lane] = inc;
+        }
+        c_ent += 1;
+        run_reset(b + 1);
+        c_Elo = 0x7FFFFFFF; c_Ehi = -0x7FFFFFFF - 1;                  // the binade is looked up again at the next step
     };
     auto chain_begin = [&](const int b) {
-        c_chunk_b0 = b; c_acc = 0; c_corr = 0; c_dA = 0; c_P = 0; c_state = CS_SPLIT;
+        c_chunk_b0 = b;
+        c_state = uni(c_state & CS_FULL);
+        run_reset(b);
         c_gid = td.dist_base + (b >> KGMA_CHAIN_STEPS_LOG2);
-        const uint32_t hw = a.chain.hot[c_gid >> 5];
-        if (uni((int)(c_Elo > c_Ehi)) && (b << 6) >= nk) {            // (no binade, and the first window's D is known)
-            const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st_reg[ST_D0HI]) << 32) | (uint32_t)uni(st_reg[ST_D0LO]));
-            chain_binade(D0 + 2 * (int64_t)gpp->N[0] * (int64_t)h_carry[0]);
-        }
-        if ((uni((int)hw) >> (c_gid & 31)) & 1) chain_switch_raw(b);
-    };
-    auto chain_end = [&](const int b) {
-        if (uni(c_state) & CS_RAW) return;
-        const int64_t total = wave_sum_i64(c_acc) + (int64_t)c_corr;
-        if (lane == 0) {
-            ChainChunk cc;
-            cc.A0 = total;
-            cc.info = (uint32_t)(c_dA + 1) | ((uint32_t)(b - c_chunk_b0 + 1) << 2);
-            cc.raw = 0;
-            a.chain.chunks[c_gid] = cc;
+        const uint32_t hw = (uint32_t)uni((int)a.chain.hot[c_gid >> 5]);
+        c_hot = 0;
+        if ((hw >> (c_gid & 31)) & 1u) {
+            const uint32_t ord = (uint32_t)uni((int)a.chain.hot_prefix[c_gid >> 5]) + (uint32_t)__builtin_popcount(hw & ((1u << (c_gid & 31)) - 1u));
+            const uint64_t m = a.chain.hot_masks[ord];
+            c_hot = ((uint64_t)(uint32_t)uni((int)(uint32_t)(m >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)m);
         }
     };
+    auto chain_end = [&](const int b) { close_run(b + 1, false); };
 
     // the stream's first window of KFV j has distance D0: thresholds in E units
     auto set_first_window = [&](const int j, int32_t *st, const int64_t D0) {
@@ -989,7 +1031,8 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
         for (int j = 0; j < NKFV; j++) asm volatile("" : "+v"(sc[j]));   // (the last stage stays one DPP add; the carry is one more add)
         if constexpr (CHAIN) {
             // ---- the reference's Float64 update of this lane's window (GenomeMiner.jl:70-72, same operation order) ----
-            const int32_t Ecur = sc[0] + h_carry[0];                  // (D - D0) / 2N after this lane's transition
+            const int32_t carry_prev = h_carry[0];
+            const int32_t Ecur = sc[0] + carry_prev;                  // (D - D0) / 2N after this lane's transition
             h_carry[0] = __builtin_amdgcn_readlane(Ecur, 63);
             uint64_t ACT = AE;                                        // lanes whose transition belongs to this stream
             bool act = differ;
@@ -1017,14 +1060,20 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
                 inc = a.chain.SF * t;
                 inc = act ? inc : 0.0;
             }
-            if (!(uni(c_state) & CS_RAW) && ACT != 0) {
-                // every value of the step inside the binade?  (E of a lane without a transition is its lower neighbour's;
-                // an empty range -- no binade known -- fails by itself)
+            // hot step (the host wants a window of it): raw.  Otherwise every value of the step must stay inside the
+            // binade (E of a lane without a transition is its lower neighbour's); where no binade is known to hold (after
+            // a raw step, at a stream's start) it is looked up from the value the step starts on
+            bool raw = ((c_hot >> (b & (KGMA_CHAIN_STEPS - 1))) & 1u) != 0;
+            if (!raw && ACT != 0) {
+                if (uni((int)(c_Elo > c_Ehi)) && (b << 6) >= nk) {
+                    const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st_reg[ST_D0HI]) << 32) | (uint32_t)uni(st_reg[ST_D0LO]));
+                    chain_binade(D0 + 2 * (int64_t)gpp->N[0] * (int64_t)carry_prev);
+                }
                 const uint64_t inl = __builtin_amdgcn_sicmp(Ecur, c_Elo, 39 /* sge */) & __builtin_amdgcn_sicmp(Ecur, c_Ehi, 41 /* sle */);
-                if ((inl | ~ACT) != ~(uint64_t)0) chain_switch_raw(b);
+                raw = (inl | ~ACT) != ~(uint64_t)0;
             }
-            if (uni(c_state) & CS_RAW) {
-                if (uni(c_state) & CS_RAW_OK) a.chain.raw[((size_t)c_raw_base + (size_t)(b - c_raw_b0)) * 64 + (size_t)lane] = inc;
+            if (raw) {
+                raw_step(b, inc);
             } else if (ACT != 0) {
                 // RN(v + inc) for an even and an odd v of this binade, as hardware additions: anchors at the end of the
                 // binade the increment moves away from (2^e, or 2^(e+1) - 2 ulp), so that the sums stay inside
@@ -1363,6 +1412,7 @@ static const void *stream8_fn_of(int k, bool s16, int nkfv, int nd = 0)       //
 // the LDS allocation granule and the kernel's registers); one KFV: two 16-wave workgroups = 32 waves per CU
 static const void *chain_fn_of(int k, bool s16)
 {
+    if (k == 7) return reinterpret_cast<const void *>(&stream8_kernel<7, true, 1, 0, true>);
     if (k == 5) return s16 ? reinterpret_cast<const void *>(&stream8_kernel<5, true, 1, 0, true>) : reinterpret_cast<const void *>(&stream8_kernel<5, false, 1, 0, true>);
     return s16 ? reinterpret_cast<const void *>(&stream8_kernel<6, true, 1, 0, true>) : reinterpret_cast<const void *>(&stream8_kernel<6, false, 1, 0, true>);
 }
@@ -1394,13 +1444,44 @@ static GeomVal stream8_geometry_of(int k, bool s16, int nkfv, int nd, bool chain
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     const void *fn = chain ? chain_fn_of(k, s16) : stream8_fn_of(k, s16, nkfv, nd);
+    if (getenv("KGMA_GEOM_DEBUG")) {
+        int rv = 0, dv = 0;
+        (void)hipRuntimeGetVersion(&rv); (void)hipDriverGetVersion(&dv);
+        Dl_info di;
+        memset(&di, 0, sizeof di);
+        (void)dladdr(reinterpret_cast<void *>(&hipRuntimeGetVersion), &di);
+        hipFuncAttributes fa;
+        memset(&fa, 0, sizeof fa);
+        const hipError_t e0 = hipFuncGetAttributes(&fa, fn);
+        fprintf(stderr, "  HIP runtime %d driver %d from %s; kernel: %d registers, %zu B static LDS, %zu B local, max %d threads (%s)\n", rv, dv,
+                di.dli_fname ? di.dli_fname : "?", fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fa.maxThreadsPerBlock, hipGetErrorString(e0));
+    }
     int best_nw = 0, best_blocks = 0;
+    int regs = 0;
+    {
+        hipFuncAttributes fa0;
+        if (hipFuncGetAttributes(&fa0, fn) == hipSuccess) regs = fa0.numRegs;
+    }
     for (int nw = 16; nw >= 4; nw--) {
         const size_t lds = stream8_lds(k, s16, nkfv, nw);
         if (lds > ((size_t)160 << 10)) continue;
         int blocks = 0;
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64 * nw, lds) != hipSuccess) continue;
+        const hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e2 = e1 == hipSuccess ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64 * nw, lds) : e1;
+        if (getenv("KGMA_GEOM_DEBUG"))
+            fprintf(stderr, "  geometry k=%d s16=%d nkfv=%d nd=%d chain=%d: %d waves, %zu B of LDS -> %d workgroups per CU (%s / %s)\n", k, (int)s16, nkfv, nd,
+                    (int)chain, nw, lds, blocks, hipGetErrorString(e1), hipGetErrorString(e2));
+        if (e1 != hipSuccess || e2 != hipSuccess) continue;
+        // The runtime's answer is a lower bound here: with another HIP user in the process (PyTorch loaded after this
+        // library) it was seen to report half the residency for a kernel with a 12-byte private segment.  What the hardware
+        // does follows from the kernel's registers and LDS: 512 vector registers per lane and SIMD in granules of 8, at most
+        // 8 waves per SIMD, 160 KiB of LDS per CU in granules of 1280 bytes.
+        if (regs > 0) {
+            const int per_simd = std::min(8, 512 / (((regs + 7) / 8) * 8));
+            const int by_regs = (4 * per_simd) / nw;
+            const int by_lds = (int)(((size_t)160 << 10) / (((lds + 1279) / 1280) * 1280));
+            blocks = std::max(blocks, std::min(by_regs, by_lds));
+        }
         if (blocks * nw > 32) blocks = 32 / nw;
         if (blocks * nw > best_blocks * best_nw) { best_blocks = blocks; best_nw = nw; }
     }
@@ -1424,10 +1505,10 @@ void stream8_geometry(int k, bool s16, int nkfv, int nd, int *nw_out, int *block
     *nw_out = v.nw; *blocks_out = v.blocks;
 }
 
-// ---- chain variant (one KFV, k = 5 or 6): streams resident per CU, launch
-bool chain_applies(int k, int nk, int64_t n_ref)
+// ---- chain variant (one KFV, k = 5, 6 or 7): streams resident per CU, launch
+bool chain_applies(int k, int nk, int64_t n_ref, bool s16)
 {
-    return (k == 5 || k == 6) && nk <= KGMA_STREAM8_MAX_NK && n_ref < ((int64_t)1 << 22);
+    return (k == 5 || k == 6 || (k == 7 && s16)) && nk <= KGMA_STREAM8_MAX_NK && n_ref < ((int64_t)1 << 22);
 }
 
 int chain_slots_per_cu(int k, bool s16)
@@ -1440,13 +1521,15 @@ hipError_t launch_chain(const ScanArgs &a, const GroupParams &gp, hipStream_t st
 {
     const bool s16 = gp.s_fits_i16 != 0;
     const GeomVal v = stream8_geometry_of(gp.k, s16, 1, 0, true);
-    if (v.nw < 1 || gp.n_kfv != 1 || !chain_applies(gp.k, gp.nk, gp.N[0])) return hipErrorInvalidConfiguration;
+    if (v.nw < 1 || gp.n_kfv != 1 || !chain_applies(gp.k, gp.nk, gp.N[0], s16)) return hipErrorInvalidConfiguration;
     const int nw = v.nw;
     const size_t lds = stream8_lds(gp.k, s16, 1, nw);
     const unsigned grid = (unsigned)((a.n_tiles + nw - 1) / nw);
     hipError_t e = hipFuncSetAttribute(chain_fn_of(gp.k, s16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (gp.k == 5) {
+    if (gp.k == 7) {
+        hipLaunchKernelGGL((stream8_kernel<7, true, 1, 0, true>), dim3(grid), dim3(64u * nw), lds, st, a, gp);
+    } else if (gp.k == 5) {
         if (s16) hipLaunchKernelGGL((stream8_kernel<5, true, 1, 0, true>), dim3(grid), dim3(64u * nw), lds, st, a, gp);
         else hipLaunchKernelGGL((stream8_kernel<5, false, 1, 0, true>), dim3(grid), dim3(64u * nw), lds, st, a, gp);
     } else {

@@ -152,7 +152,7 @@ def load():
     L.kgma_set_residue_source.argtypes = [vp, FETCH_FN, vp]
     L.kgma_host_chain_values.argtypes = [C.c_char_p, i64, P(dbl), i32, i64, P(i64), P(i64), i64, P(dbl), i64, P(i64)]
     L.kgma_chain_values.argtypes = [vp, vp, i64, i32, P(i64), P(i64), i64, P(dbl), i64, P(i64)]
-    L.kgma_host_chain_walk.argtypes = [dbl, dbl, i32, i64, P(i64), P(i32), P(i64), P(i64), vp, i64, P(dbl), i64, P(i64), P(i64), i64,
+    L.kgma_host_chain_walk.argtypes = [dbl, dbl, i32, i64, P(i64), P(i32), P(i64), P(i64), vp, i64, vp, i64, P(i64), P(i64), i64,
                                        P(dbl), i64, P(i64), P(dbl)]
     L.kgma_stream.argtypes = [vp]
     L.kgma_stream.restype = vp
@@ -187,15 +187,19 @@ def chain_steps() -> int:
 CHAIN_CHUNK_DTYPE = np.dtype([("A0", "<i8"), ("info", "<u4"), ("raw", "<u4")])   # kgma_device.h: ChainChunk
 
 
-def host_chain_walk(first: float, scale: float, nk: int, win0, n_valid, chunk_base, D0, chunks, raw, intervals):
-    """kgma_host_chain_walk: the host half of the device chain on caller-supplied chunk records (tests).  Returns
-    (values at the windows of `intervals`, largest drift seen at a stream start)."""
+CHAIN_RAW, CHAIN_DETAIL = 1 << 10, 1 << 11      # kgma_device.h: KGMA_CHAIN_RAW / KGMA_CHAIN_DETAIL
+
+
+def host_chain_walk(first: float, scale: float, nk: int, win0, n_valid, chunk_base, D0, chunks, pool, intervals):
+    """kgma_host_chain_walk: the host half of the device chain on caller-supplied chunk records (tests).  `pool`: the
+    entries of detailed chunks and the raw increments, as an array of CHAIN_CHUNK_DTYPE units (16 bytes each; a raw step's
+    64 doubles take 32 units).  Returns (values at the windows of `intervals`, largest drift seen at a stream start)."""
     win0 = np.ascontiguousarray(win0, dtype=np.int64)
     n_valid = np.ascontiguousarray(n_valid, dtype=np.int32)
     chunk_base = np.ascontiguousarray(chunk_base, dtype=np.int64)
     D0 = np.ascontiguousarray(D0, dtype=np.int64)
     chunks = np.ascontiguousarray(chunks, dtype=CHAIN_CHUNK_DTYPE)
-    raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1)
+    pool = np.ascontiguousarray(pool, dtype=CHAIN_CHUNK_DTYPE).reshape(-1)
     lo = np.asarray([a for a, _ in intervals], dtype=np.int64)
     hi = np.asarray([b for _, b in intervals], dtype=np.int64)
     n = int((hi - lo + 1).sum())
@@ -204,7 +208,7 @@ def host_chain_walk(first: float, scale: float, nk: int, win0, n_valid, chunk_ba
     drift = C.c_double(0)
     st = load().kgma_host_chain_walk(float(first), float(scale), int(nk), win0.size, _np_ptr(win0, C.c_int64), _np_ptr(n_valid, C.c_int32),
                                      _np_ptr(chunk_base, C.c_int64), _np_ptr(D0, C.c_int64), chunks.ctypes.data_as(C.c_void_p), chunks.size,
-                                     _np_ptr(raw, C.c_double) if raw.size else None, raw.size // 64, _np_ptr(lo, C.c_int64),
+                                     pool.ctypes.data_as(C.c_void_p) if pool.size else None, pool.size, _np_ptr(lo, C.c_int64),
                                      _np_ptr(hi, C.c_int64), lo.size, _np_ptr(out, C.c_double), out.size, C.byref(nn), C.byref(drift))
     if st != KGMA_OK:
         raise KgmaError(st, "kgma_host_chain_walk failed")

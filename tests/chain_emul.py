@@ -70,94 +70,117 @@ def _binade(Dv: int, scale: float):
 
 
 def emulate(inc, D, nk: int, T: int, scale: float, hot_windows=(), last=None):
-    """Streams of T transitions over windows 1..last; returns dict(win0, n_valid, chunk_base, D0, chunks, raw)."""
+    """Streams of T transitions over windows 1..last, as the kernel lays them out: per chunk one record (its leading run
+    of regular steps), and for a chunk with raw steps -- hot ones, or steps in which a window may leave the binade -- a list
+    of entries in the pool (later runs and raw steps, in order).  Returns dict(win0, n_valid, chunk_base, D0, chunks, pool)."""
     nwin = len(D)
     last = nwin if last is None else last
     hot_windows = set(int(w) for w in hot_windows)
     win0s, nvs, cbases, D0s = [], [], [], []
     chunks = []
-    raw = []
+    pool = []                                        # units: (A0, info, raw) tuples or raw arrays of 64 doubles (32 units)
+    pool_units = [0]
+
+    def pool_raw(vals):
+        pool.append(("r", vals)); pool_units[0] += 32
+        return pool_units[0] - 32
+
     for win0 in range(1, last, T):
         n_valid = min(T + 1, last - win0 + 1)
         n_pos = n_valid + nk - 1
         n_blocks = (n_pos + 63) // 64
         win0s.append(win0); nvs.append(n_valid); cbases.append(len(chunks)); D0s.append(int(D[win0 - 1]))
         bin_ = None
+
+        def lanes(b):
+            p = np.arange(b * 64, (b + 1) * 64)
+            q = p - nk + 1
+            act = (q >= 1) & (q < n_valid)
+            return act, win0 + q - 1                  # transition t leads from window t to t + 1
+
         for cb in range(0, n_blocks, STEPS):
             steps = min(STEPS, n_blocks - cb)
-            # positions of the chunk -> transitions
-            def lanes(step):
-                p = np.arange((cb + step) * 64, (cb + step + 1) * 64)
-                q = p - nk + 1
-                act = (q >= 1) & (q < n_valid)
-                t = win0 + q - 1                       # transition t leads from window t to t + 1
-                return act, t
-            hot = False
-            for step in range(steps):
-                act, t = lanes(step)
-                if any((int(x) + 1) in hot_windows for x in t[act]):
-                    hot = True
-            if bin_ is None and cb * 64 >= nk:
-                # D after the last lane of the previous step
-                pq = cb * 64 - 1 - nk + 1
-                wprev = win0 + min(max(pq, 0), n_valid - 1)
-                bin_ = _binade(int(D[wprev - 1]), scale)
-            if cb == 0:
-                pass
-            nlead = 0
-            A = [0, 0]
-            P = [0, 1]
-            is_raw = hot
-            acc = 0
-            corr = 0
-            dA = 0
+            acc = corr = dA = par = 0
             split = True
-            par = 0
-            step = 0
-            raw_base = len(raw)
-            while step < steps and not is_raw:
-                act, t = lanes(step)
-                if act.any():
-                    if bin_ is None and (cb + step) * 64 + 63 >= nk and (cb + step) * 64 < nk + 64:
-                        bin_ = _binade(int(D[win0 - 1]), scale)     # the step that completes the warm-up knows D0
+            run0 = 0
+            detailed = False
+            rec = None                                # the chunk's own record
+            ents = []                                 # entries (in order) once detailed
+            for step in range(steps):
+                b = cb + step
+                act, t = lanes(b)
+                hot = any((int(x) + 1) in hot_windows for x in t[act])
+                iv = np.where(act, inc[np.clip(t - 1, 0, len(inc) - 1)], 0.0)
+                raw = hot
+                if not raw and act.any():
+                    if bin_ is None:
+                        if b * 64 >= nk:
+                            prev_q = min(max(b * 64 - nk, 0), n_valid - 1)      # window the step starts on (local)
+                            bin_ = _binade(int(D[win0 - 1 + prev_q]), scale)
+                        elif b * 64 + 63 >= nk - 1:
+                            bin_ = _binade(int(D[win0 - 1]), scale)               # the step that completes the warm-up knows D0
                     ok = bin_ is not None
                     if ok:
                         e, lo, hi = bin_
-                        Da = D[t[act]]                                 # D after each active transition (window t + 1)
+                        Da = D[t[act]]                                            # D after each active transition (window t + 1)
                         ok = bool(np.all((Da > lo) & (Da < hi)))
-                    if not ok:
-                        is_raw = True
-                        break
-                    iv = np.where(act, inc[np.clip(t - 1, 0, len(inc) - 1)], 0.0)
-                    neg = np.signbit(iv)
-                    x0 = np.where(neg, np.ldexp(1.0, e + 1) - 2 * np.ldexp(1.0, e - 52), np.ldexp(1.0, e))
-                    x1 = (x0.view(np.int64) | 1).view(np.float64)
-                    r0 = x0 + iv
-                    r1 = x1 + iv
-                    a = r0.view(np.int64) - x0.view(np.int64)
-                    delta = (r1.view(np.int64) - r0.view(np.int64)) - 1
-                    acc += int(a.sum())
-                    for u in range(64):
-                        if delta[u] != 0:
-                            c0 = int(delta[u]) if par else 0
-                            if split:
-                                dA = (0 if par else int(delta[u])) - c0
-                                split = False
-                            corr += c0
-                            par = 0
-                        else:
-                            par ^= int(a[u]) & 1
-                step += 1
-            nlead = step
-            info = (dA + 1) | (nlead << 2)
-            if nlead < steps:
-                bin_ = None
-                for st2 in range(nlead, steps):
-                    act, t = lanes(st2)
-                    raw.append(np.where(act, inc[np.clip(t - 1, 0, len(inc) - 1)], 0.0))
-            chunks.append((acc + corr, info, raw_base if nlead < steps else 0))
+                    raw = not ok
+                if raw:
+                    n = step - run0
+                    if not detailed:
+                        rec = (acc + corr, (dA + 1) | (n << 2) | _lib.CHAIN_DETAIL)
+                        detailed = True
+                    elif n > 0:
+                        ents.append(("e", (acc + corr, (dA + 1) | (n << 2), 0)))
+                    ents.append(("r", iv))
+                    acc = corr = dA = par = 0; split = True; run0 = step + 1
+                    bin_ = None
+                    continue
+                if not act.any():
+                    continue
+                neg = np.signbit(iv)
+                x0 = np.where(neg, np.ldexp(1.0, e + 1) - 2 * np.ldexp(1.0, e - 52), np.ldexp(1.0, e))
+                x1 = (x0.view(np.int64) | 1).view(np.float64)
+                r0 = x0 + iv
+                r1 = x1 + iv
+                a = r0.view(np.int64) - x0.view(np.int64)
+                delta = (r1.view(np.int64) - r0.view(np.int64)) - 1
+                acc += int(a.sum())
+                for u in range(64):
+                    if delta[u] != 0:
+                        c0 = int(delta[u]) if par else 0
+                        if split:
+                            dA = (0 if par else int(delta[u])) - c0
+                            split = False
+                        corr += c0
+                        par = 0
+                    else:
+                        par ^= int(a[u]) & 1
+            n = steps - run0
+            if not detailed:
+                chunks.append((acc + corr, (dA + 1) | (n << 2), 0))
+            else:
+                if n > 0:
+                    ents.append(("e", (acc + corr, (dA + 1) | (n << 2), 0)))
+                # the entry list is contiguous; the raw blocks follow anywhere in the pool
+                base = pool_units[0]
+                where = []
+                for _ in ents:
+                    pool.append(None); pool_units[0] += 1
+                    where.append(len(pool) - 1)
+                for (kind, val), pos in zip(ents, where):
+                    pool[pos] = ("e", val) if kind == "e" else ("e", (0, 1 | (1 << 2) | _lib.CHAIN_RAW, pool_raw(val)))
+                chunks.append((rec[0], rec[1], base))
     ch = np.zeros(len(chunks), dtype=_lib.CHAIN_CHUNK_DTYPE)
-    for i, (a0, info, rb) in enumerate(chunks):
-        ch[i] = (a0, info, rb)
-    rawa = np.concatenate(raw) if raw else np.zeros(0)
-    return dict(win0=np.array(win0s), n_valid=np.array(nvs), chunk_base=np.array(cbases), D0=np.array(D0s), chunks=ch, raw=rawa)
+    for i, c3 in enumerate(chunks):
+        ch[i] = c3
+    pl = np.zeros(pool_units[0], dtype=_lib.CHAIN_CHUNK_DTYPE)
+    u = 0
+    for kind, val in pool:
+        if kind == "e":
+            pl[u] = val
+            u += 1
+        else:
+            pl[u:u + 32].view(np.float64)[:] = val
+            u += 32
+    return dict(win0=np.array(win0s), n_valid=np.array(nvs), chunk_base=np.array(cbases), D0=np.array(D0s), chunks=ch, pool=pl)

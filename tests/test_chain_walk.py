@@ -42,15 +42,15 @@ def test_walk_equals_oracle_chain(alp_ref, data_dir, T):
     iv = [(1, 1), (2, 5), (3100, 3130), (5001, 5300), (12010, 12011), (nwin - 70, nwin)]
     hot = [w for lo, hi in iv for w in range(lo, hi + 1)]
     em = chain_emul.emulate(inc, D, nk, T, scale, hot_windows=hot)
-    n_lead = (em["chunks"]["info"] >> 2) & 255
-    assert int((n_lead > 0).sum()) > 0 and int((n_lead == 0).sum()) > 0 and em["raw"].size > 0   # both kinds of chunk are walked
-    vals, drift = _lib.host_chain_walk(first, scale, nk, em["win0"], em["n_valid"], em["chunk_base"], em["D0"], em["chunks"], em["raw"], iv)
+    detailed = (em["chunks"]["info"] & _lib.CHAIN_DETAIL) != 0
+    assert int(detailed.sum()) > 0 and int((~detailed).sum()) > 0 and em["pool"].size > 0   # both kinds of chunk are walked
+    vals, drift = _lib.host_chain_walk(first, scale, nk, em["win0"], em["n_valid"], em["chunk_base"], em["D0"], em["chunks"], em["pool"], iv)
     want = np.concatenate([chain[lo - 1:hi] for lo, hi in iv])
     assert np.array_equal(vals, want)
     assert drift < 2.0 ** -40
     # every window (all chunks hot): the raw path alone
     em2 = chain_emul.emulate(inc, D, nk, T, scale, hot_windows=range(1, nwin + 1))
-    v2, _ = _lib.host_chain_walk(first, scale, nk, em2["win0"], em2["n_valid"], em2["chunk_base"], em2["D0"], em2["chunks"], em2["raw"], [(1, nwin)])
+    v2, _ = _lib.host_chain_walk(first, scale, nk, em2["win0"], em2["n_valid"], em2["chunk_base"], em2["D0"], em2["chunks"], em2["pool"], [(1, nwin)])
     assert np.array_equal(v2, chain)
 
 
@@ -64,11 +64,11 @@ def test_walk_checks_drift_and_ties(alp_ref):
     nwin = len(D)
     em = chain_emul.emulate(inc, D, nk, 2048, scale, hot_windows=[nwin])
     chain = np.cumsum(np.concatenate([[first], inc]))          # (numpy's cumsum is the sequential sum)
-    vals, _ = _lib.host_chain_walk(first, scale, nk, em["win0"], em["n_valid"], em["chunk_base"], em["D0"], em["chunks"], em["raw"], [(nwin, nwin)])
+    vals, _ = _lib.host_chain_walk(first, scale, nk, em["win0"], em["n_valid"], em["chunk_base"], em["D0"], em["chunks"], em["pool"], [(nwin, nwin)])
     assert vals[0] == chain[-1]
     # the walk reaches the last window through regular chunks only, ties included (N = 84: half-ulp sums occur)
     assert int((em["chunks"]["info"] & 3 != 1).sum()) > 0       # some chunk's two parities differ
     # a first value that is off by more than 2^-31: refused, not silently walked
     with pytest.raises(_lib.KgmaError):
-        _lib.host_chain_walk(first * (1 + 2.0 ** -28), scale, nk, em["win0"], em["n_valid"], em["chunk_base"], em["D0"], em["chunks"], em["raw"],
+        _lib.host_chain_walk(first * (1 + 2.0 ** -28), scale, nk, em["win0"], em["n_valid"], em["chunk_base"], em["D0"], em["chunks"], em["pool"],
                              [(nwin, nwin)])

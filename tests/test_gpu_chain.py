@@ -93,14 +93,14 @@ def test_chain_values_raw_pool_regrowth(ctx, alp_ref, genes, monkeypatch):
     ctx.set_refs(k, [RV], [W], [30.0], [alp_ref["N"]])
     g = ctx.genome_from_host([seq])
     try:
-        monkeypatch.setenv("KGMA_CHAIN_RAW_SLOTS", "3")                 # far too small: the second attempt has room
+        monkeypatch.setenv("KGMA_CHAIN_POOL_UNITS", "100")             # far too small: the second attempt has room
         v = g.chain_values(0, 1, [(1, len(chain))])
         assert np.array_equal(v, chain)
     finally:
         g.free()
 
 
-def test_chain_values_cluster_kfvs_and_k5(ctx, alp_clusters, genes, data_dir):
+def test_chain_values_cluster_kfvs_and_other_k(ctx, alp_clusters, genes, data_dir):
     from kmergma_amd import refprep
     rng = np.random.default_rng(24)
     seq = _rich_seq(rng, 40_000, genes)
@@ -116,14 +116,16 @@ def test_chain_values_cluster_kfvs_and_k5(ctx, alp_clusters, genes, data_dir):
             assert np.array_equal(v, od[j]), f"KFV {j + 1}"
     finally:
         g.free()
-    RV, ws, cons, (S, N) = refprep.gen_ref_ws_cons(os.path.join(data_dir, "Alp_V_ref.fasta"), 5, return_int=True)
-    _, od1 = orc.single_scan([seq], RV, 5, ws, 30.0, 50, return_dists=True)
-    ctx.set_refs(5, [RV], [ws], [30.0], [N])
-    g = ctx.genome_from_host([seq])
-    try:
-        assert np.array_equal(g.chain_values(0, 1, [(2, len(seq) - ws + 1)]), od1)
-    finally:
-        g.free()
+    for kk in (5, 7):                                                    # (k = 7: the S table is gathered from global memory)
+        RV, ws, cons, (S, N) = refprep.gen_ref_ws_cons(os.path.join(data_dir, "Alp_V_ref.fasta"), kk, return_int=True)
+        _, od1 = orc.single_scan([seq], RV, kk, ws, 30.0, 50, return_dists=True)
+        ctx.set_refs(kk, [RV], [ws], [30.0], [N])
+        g = ctx.genome_from_host([seq])
+        try:
+            assert np.array_equal(g.chain_values(0, 1, [(2, len(seq) - ws + 1)]), od1), f"k = {kk}"
+            assert np.array_equal(g.chain_values(0, 1, [(20_000, 20_001)]), od1[19_998:20_000]), f"k = {kk}"
+        finally:
+            g.free()
 
 
 def test_chain_replay_runs_on_the_device_and_agrees_with_the_host_chain(ctx, alp_ref, genes, monkeypatch):
@@ -149,5 +151,29 @@ def test_chain_replay_runs_on_the_device_and_agrees_with_the_host_chain(ctx, alp
         hits2, st2 = ctx.hits(), ctx.stats()
         assert st2["chain_device_pairs"] == 0 and st2["n_chain_pairs"] == st["n_chain_pairs"]
         assert [(hit_key(h), h["dist"]) for h in hits2] == [(hit_key(h), h["dist"]) for h in hits]
+    finally:
+        g.free()
+
+
+def test_chain_values_where_the_distance_hovers_on_a_power_of_two(ctx, alp_ref):
+    """W = 222 puts the random-sequence distance at 32.1 +- 0.9: the value crosses 2^5 every few dozen windows, so most
+    chunks leave the regular path at some step (decided on exact values with a guard band) and the raw pool is what the
+    estimate did not foresee.  Values still bit for bit, every window and sparse ones."""
+    rng = np.random.default_rng(26)
+    k, W, RV = 6, 222, alp_ref["RV"]
+    seq = random_dna(rng, 700_000)
+    chain = _oracle_chain(seq, RV, k, W)
+    nwin = len(seq) - W + 1
+    e = np.floor(np.log2(chain))
+    assert int((e[1:] != e[:-1]).sum()) > 3000
+    ctx.set_refs(k, [RV], [W], [30.0], [alp_ref["N"]])
+    g = ctx.genome_from_host([seq])
+    try:
+        iv = [(1, 1), (250_000, 250_010), (nwin, nwin)]
+        v = g.chain_values(0, 1, iv)
+        assert np.array_equal(v, np.concatenate([chain[lo - 1:hi] for lo, hi in iv]))
+        st = ctx.stats()
+        assert st["chain_raw_steps"] > (nwin // 64) // 10         # a tenth of all steps or more went out raw
+        assert np.array_equal(g.chain_values(0, 1, [(1, nwin)]), chain)
     finally:
         g.free()

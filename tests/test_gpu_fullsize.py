@@ -262,3 +262,171 @@ def test_config4_cluster_mode_400mb(ctx):
     assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi]
     assert [h["D"] for h in hits] == [h["D"] for h in ohi]
     assert len(hits) >= 60
+
+
+def test_chain_on_a_chr1_size_record(ctx, refs):
+    """The Float64 chain over a record of 2.5e8 windows (the longest GRCh38 record): the device chain's values at windows
+    spread over the record -- the last one after 2.5e8 sequential roundings -- equal the oracle's running value bit for
+    bit, the drift it measured at its stream starts is far inside the guard band, and a tie-dense scan in chain mode
+    gives the oracle's hits."""
+    k, W, N, RV = 6, refs["ws"], refs["N"], refs["RV"]
+    L = 248_956_422
+    ctx.set_refs(k, [RV], [W], [34.0], [N])
+    g = ctx.genome_synthetic([L], 4242)
+    g.poke(0, 1, b"N" * 10_000)
+    plants = workloads.planted_genes(refs["genes"], [L], 40, 4243)
+    for c, pos, data in plants:
+        g.poke(0, max(pos, 10_400), data)
+    g.repack()
+    try:
+        seq = _fetch_all(g, [L])
+        thr = 34.0
+        ohits, od = orc.single_scan(seq, RV, k, W, thr, 50, return_dists=True, hit_cap=1 << 20)
+        nwin = L - W + 1
+        assert len(od) == nwin - 1
+        ctx.set_refs(k, [RV], [W], [thr], [N])
+        iv = [(2, 3), (1_000_000, 1_000_002), (100_000_000, 100_000_000), (nwin - 5, nwin)]
+        v = g.chain_values(0, 1, iv)
+        want = np.concatenate([od[lo - 2:hi - 1] for lo, hi in iv])
+        assert np.array_equal(v, want)
+        st = ctx.stats()
+        assert 0 < st["chain_max_drift"] < 2.0 ** -36
+        print("chr1-size chain: kernels %.2f ms, %d raw steps, drift %.3g" % (st["chain_device_ms"], st["chain_raw_steps"], st["chain_max_drift"]))
+        ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_CHAIN_REPLAY, None)
+        hits, st = ctx.hits(), ctx.stats()
+        assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohits]
+        assert st["n_tie_flagged"] == 0
+        for a, b in zip(hits, ohits):
+            if a["flags"] & _lib.HIT_CHAIN:
+                assert a["dist"] == b["dist"]
+        print("chr1-size chain-mode scan: %d hits, %d chain pairs (%d on the device), chain %.2f ms" %
+              (len(hits), st["n_chain_pairs"], st["chain_device_pairs"], st["chain_ms"]))
+    finally:
+        g.free()
+
+
+def _oracle_omn_per_record(seqs, KFVs, k, ws, thr, buff, workers=16):
+    """orc.omn_scan record by record on a thread pool (the C oracle releases the GIL); records are independent
+    (OmnGenomeMiner.jl:59,66,73-78 re-initialise all state) and genome_pos is the prefix sum of ALL record lengths (:159)."""
+    import concurrent.futures as cf
+    pos = np.concatenate([[0], np.cumsum([len(s) for s in seqs])])
+
+    def one(c):
+        h, _ = orc.omn_scan([seqs[c]], KFVs, k, ws, thr, buff, int(pos[c]), hit_cap=1 << 16)
+        for x in h:
+            x["contig"] = c
+        return h
+    order = sorted(range(len(seqs)), key=lambda c: -len(seqs[c]))
+    with cf.ThreadPoolExecutor(max_workers=workers) as ex:
+        res = dict(zip(order, ex.map(one, order)))
+    return [h for c in range(len(seqs)) for h in res[c]]
+
+
+def test_config4_grch38_size_chain_mode_vs_float_oracle(ctx):
+    """configs[3] at its full size: cluster mode (5 KFVs, W = 288,288,288,289,290, buff = 100) on the 3.09 Gb GRCh38-size
+    genome, KGMA_F_CHAIN_REPLAY (the mode findGenes_cluster_mode's mirror runs), against the reference-order Float64 oracle
+    run over every record: the hit lists are identical, chain-decided hits carry the oracle's distance bit for bit."""
+    import time
+    c = workloads.fixture_clusters(DATA, 6)
+    thr = [37, 33, 38, 34, 28]
+    ctx.set_refs(6, c["KFVs"], c["ws"], thr, c["N"])
+    from kmergma_amd import fasta
+    genes = [r.sequence.upper() for r in fasta.read_fasta(os.path.join(DATA, "Alp_V_ref.fasta"))]
+    g, plants, lens = workloads.make_grch38_like(ctx, genes, seed=38, n_plants=512, scale=1.0)
+    assert sum(lens) > 3_000_000_000
+    ctx.scan(g, _lib.MODE_OMN, 100, 0, _lib.F_CHAIN_REPLAY, None)          # (first call: buffers, tile table)
+    t0 = time.perf_counter()
+    ctx.scan(g, _lib.MODE_OMN, 100, 0, _lib.F_CHAIN_REPLAY, None)
+    t_scan = time.perf_counter() - t0
+    hits_c, dips_c, st_c = ctx.hits(), ctx.dips(), ctx.stats()
+    seqs = _fetch_all(g, lens)
+    g.free()
+    t0 = time.perf_counter()
+    ohits = _oracle_omn_per_record(seqs, c["KFVs"], 6, c["ws"], thr, 100)
+    t_orc = time.perf_counter() - t0
+    print(f"config 4 (3.09 Gb): {len(hits_c)} hits, {st_c['n_chain_pairs']} chain pairs ({st_c['chain_device_pairs']} on the device), "
+          f"chain {st_c['chain_ms']:.1f} ms (kernels {st_c['chain_device_ms']:.1f}), scan call {t_scan * 1e3:.1f} ms; oracle {t_orc:.1f} s on 16 threads")
+    assert [hit_key(h) for h in hits_c] == [hit_key(h) for h in ohits]
+    assert st_c["n_tie_flagged"] == 0 and not any(d["flags"] & 3 for d in dips_c)
+    assert st_c["n_chain_pairs"] > 0 and st_c["chain_device_pairs"] == st_c["n_chain_pairs"]
+    for a, b in zip(hits_c, ohits):
+        assert abs(a["dist"] - b["dist"]) <= 1e-6 * b["dist"]
+        if a["flags"] & _lib.HIT_CHAIN:
+            assert a["dist"] == b["dist"]
+    assert len(hits_c) >= 300
+
+
+def test_config5_100gb_k7_eight_kfvs_full_size(ctx):
+    """configs[4] at its full size on one GPU: 100 records x 1e9 bases generated on the device, k = 7, 8 KFVs (thresholds on
+    the half-integer lattice, so that the single-sequence clusters tie and sit on their thresholds).  The whole genome is
+    scanned in exact mode and in chain mode; every planted gene of low divergence is found where it was planted; ONE whole
+    record (1e9 bases, all 8 KFVs) is scanned by both oracles and compared hit for hit -- exact mode against the integer
+    oracle, chain mode against the reference-order Float64 oracle."""
+    import concurrent.futures as cf
+    import time
+    from kmergma_amd import fasta, refprep
+    k = 7
+    tf = os.path.join(DATA, "Alp_V_ref.fasta")
+    cutoffs = [6, 7, 7.7, 8.5, 9.5, 12, 22]
+    KFVs, ws, cons, inv, ints = refprep.cluster_ref_API(tf, k, cutoffs=cutoffs, include_avg=False, return_int=True)
+    KFVs, ws, cons, ints = refprep.eliminate_null_params(KFVs, ws, cons, inv, ints)
+    S = [x for x, _ in ints]; N = [n for _, n in ints]
+    assert len(ws) == 8
+    thr = [round(2 * float(t)) / 2 for t in refprep.estimate_optimal_threshold(KFVs, ws, buffer=7, num_trials=30)]
+    genes = [r.sequence.upper() for r in fasta.read_fasta(tf)]
+    n_rec, rec_len, R = 100, 1_000_000_000, 7
+    lens = [rec_len] * n_rec
+    ctx.set_refs(k, KFVs, ws, thr, N)
+    g = ctx.genome_synthetic(lens, 100)
+    g.poke(R, 1, b"N" * 10_000)
+    plants = workloads.planted_genes(genes, lens, 2000, 105, max_rate=0.10)
+    plants = [(c, max(pos, 10_400), data) for c, pos, data in plants]
+    for c, pos, data in plants:
+        g.poke(c, pos, data)
+    g.repack()
+    try:
+        t0 = time.perf_counter()
+        ctx.scan(g, _lib.MODE_OMN, 100, 0, _lib.F_NO_TIE_RESOLVE, None)
+        t_exact = time.perf_counter() - t0
+        hits_x, st_x = ctx.hits_array().copy(), ctx.stats()
+        t0 = time.perf_counter()
+        ctx.scan(g, _lib.MODE_OMN, 100, 0, _lib.F_CHAIN_REPLAY, None)
+        t_chain = time.perf_counter() - t0
+        hits_c, st_c = ctx.hits_array().copy(), ctx.stats()
+        print(f"config 5 (100 Gb, one GPU): exact mode {t_exact:.2f} s ({st_x['scan_ms']:.0f} ms of kernels), {len(hits_x)} hits; chain mode "
+              f"{t_chain:.2f} s, {len(hits_c)} hits, {st_c['n_chain_pairs']} chain pairs ({st_c['chain_device_pairs']} on the device), chain "
+              f"{st_c['chain_ms']:.0f} ms (kernels {st_c['chain_device_ms']:.0f} ms)")
+        assert st_c["n_tie_flagged"] == 0
+        # planted genes (cluster engine: cmi = best window start - 1)
+        by_c = {}
+        for h in hits_c:
+            by_c.setdefault(int(h["contig"]), []).append(int(h["cmi"]) + 1)
+        found = sum(1 for c, pos, data in plants if any(abs(s - pos) <= 60 for s in by_c.get(c, [])))
+        assert found >= 0.6 * len(plants), (found, len(plants))
+        # one whole record against both oracles
+        seq = b"".join(g.fetch(R, 1 + o, min(1 << 28, rec_len - o)) for o in range(0, rec_len, 1 << 28))
+        gp0 = R * rec_len
+        T = [orc.int_threshold(t, k, n) for t, n in zip(thr, N)]
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(max_workers=2) as ex:
+            f1 = ex.submit(orc.omn_scan, [seq], KFVs, k, ws, thr, 100, gp0, False, None, 1 << 16)
+            f2 = ex.submit(orc.omn_scan_int, [seq], S, N, k, ws, T, 100, gp0, False, None, 1 << 16)
+            ohits, _ = f1.result()
+            ohi, _ = f2.result()
+        print(f"  record {R}: both oracles in {time.perf_counter() - t0:.0f} s, {len(ohits)} / {len(ohi)} hits")
+        for o in ohits + ohi:
+            o["contig"] = R
+        mine_c = [dict(contig=int(h["contig"]), kfv=int(h["kfv"]), cmi=int(h["cmi"]), lo=int(h["lo"]), hi=int(h["hi"]), genome_pos=int(h["genome_pos"]),
+                       dist=float(h["dist"]), flags=int(h["flags"])) for h in hits_c if int(h["contig"]) == R]
+        mine_x = [dict(contig=int(h["contig"]), kfv=int(h["kfv"]), cmi=int(h["cmi"]), lo=int(h["lo"]), hi=int(h["hi"]), genome_pos=int(h["genome_pos"]),
+                       D=int(h["D"])) for h in hits_x if int(h["contig"]) == R]
+        assert [hit_key(h) for h in mine_x] == [hit_key(h) for h in ohi]
+        assert [h["D"] for h in mine_x] == [h["D"] for h in ohi]
+        assert [hit_key(h) for h in mine_c] == [hit_key(h) for h in ohits]
+        for a, b in zip(mine_c, ohits):
+            assert abs(a["dist"] - b["dist"]) <= 1e-6 * b["dist"]
+            if a["flags"] & _lib.HIT_CHAIN:
+                assert a["dist"] == b["dist"]
+        assert len(ohits) >= 10
+    finally:
+        g.free()

@@ -18,7 +18,7 @@ def source_hash():
     h = hashlib.sha256()
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kmergma.jl_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
+        if name.endswith((".hip", ".h", ".cpp")):
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
@@ -36,7 +36,8 @@ def main():
     ap.add_argument("--records", type=int, default=100)
     ap.add_argument("--windowsize", type=int, default=289)
     ap.add_argument("--workload", default="bench.py default: one synthetic 100 Gb genome (100 records x 1e9 bases) on one GPU")
-    ap.add_argument("--kernel", default="stream_kernel")
+    ap.add_argument("--kernel", default="stream8_kernel<6, true, 1, 0, false>",
+                    help="substring of the scan kernel's name (the chain variant ends in `true>`: it must not be averaged in)")
     args = ap.parse_args()
     stats_csv = glob.glob(os.path.join(args.src, "trace", "*", "*_kernel_stats.csv"))[0]
     shutil.copy(stats_csv, args.dst_prefix + "_bench_kernel_stats.csv")
