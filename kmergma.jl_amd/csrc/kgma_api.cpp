@@ -50,6 +50,7 @@ int64_t align_trace_bytes(int m, int n);
 hipError_t launch_align(const uint8_t *ascii, const AlignJob *jobs, int n_jobs, const uint8_t *cons, int m, int go, int ge,
                         uint8_t *trace, int64_t trace_stride, int max_n, int64_t *out, hipStream_t st);
 hipError_t launch_fasta_count(const uint8_t *raw, int64_t n, uint32_t *counts, hipStream_t st);
+hipError_t launch_fasta_blank(uint8_t *raw, const int64_t *ranges, int n_ranges, hipStream_t st);
 hipError_t launch_gather_ranges(const uint8_t *src, const int64_t *desc, int n, uint8_t *dst, hipStream_t st);
 hipError_t launch_export(uint8_t *res, uint8_t *host, int64_t d0_slots, int64_t d0_used, unsigned int rec_cap, unsigned int inline_recs,
                          int do_gather, const TileDesc *tiles, const ContigDesc *cd, const uint8_t *ascii, const int64_t *Wtab,
@@ -114,6 +115,51 @@ struct kgma_genome {
     int64_t device_bytes = 0;
 };
 
+// Two pinned staging buffers used alternately: the CPU fills one while the DMA engine drains the other
+// (host bytes -> device at the pace of the slower of memcpy and PCIe instead of their sum).
+struct StagePipe {
+    uint8_t *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int cur = 0;
+    size_t cap = 0;
+    hipStream_t st = nullptr;
+    bool init(size_t cap_, hipStream_t st_)
+    {
+        cap = cap_; st = st_;
+        for (int i = 0; i < 2; i++)
+            if (hipHostMalloc(reinterpret_cast<void **>(&buf[i]), cap, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+        return true;
+    }
+    uint8_t *acquire()                        // buffer to fill next (waits for its previous copy)
+    {
+        if (busy[cur]) { (void)hipEventSynchronize(ev[cur]); busy[cur] = false; }
+        return buf[cur];
+    }
+    hipError_t submit(uint8_t *dst, size_t n) // copy the buffer just filled to the device, switch buffers
+    {
+        hipError_t e = hipMemcpyAsync(dst, buf[cur], n, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(ev[cur], st);
+        busy[cur] = true;
+        cur ^= 1;
+        return e;
+    }
+    void drain()
+    {
+        for (int i = 0; i < 2; i++)
+            if (busy[i]) { (void)hipEventSynchronize(ev[i]); busy[i] = false; }
+    }
+    ~StagePipe()
+    {
+        drain();
+        for (int i = 0; i < 2; i++) {
+            if (buf[i]) (void)hipHostFree(buf[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+        }
+    }
+};
+
 // kgma_step_begin / kgma_step_end: one findGenes step run by a helper thread of the context, so that the
 // caller's thread can queue other work (the hit exchange of the previous step) while the GPU scans.
 struct StepWorker {
@@ -144,6 +190,11 @@ struct kgma_ctx {
     char kernel_name[48] = "";
     uint8_t *d_gath = nullptr, *h_gath = nullptr; size_t gath_cap = 0;   // tie-replay residue gather: [desc | residues]
     uint32_t *h_chain = nullptr; size_t chain_cap = 0;                   // chain replay: pinned copy of the records' 2-bit codes (dwords)
+    // ingest: pinned staging pair and device scratch, kept between genomes (allocating and pinning them cost a third of a
+    // 400 MB ingest); scratch beyond 2 GiB is given back after use
+    StagePipe *pipe = nullptr;
+    uint8_t *d_ingest = nullptr; int64_t ingest_cap = 0;                 // raw FASTA text on the device
+    uint32_t *d_icounts = nullptr; int64_t icounts_cap = 0;
     // chain on the device (stream8_kernel<..., CHAIN>): stream table, chunk records, raw increments, hot-chunk bits,
     // first-window D per stream, {raw cursor, status}; one pinned mirror for what comes back
     TileDesc *d_ctiles = nullptr; int64_t ctiles_cap = 0;
@@ -481,6 +532,9 @@ void kgma_destroy(kgma_ctx *ctx)
     if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->h_gath) (void)hipHostFree(ctx->h_gath);
     if (ctx->h_chain) (void)hipHostFree(ctx->h_chain);
+    delete ctx->pipe;
+    if (ctx->d_ingest) (void)hipFree(ctx->d_ingest);
+    if (ctx->d_icounts) (void)hipFree(ctx->d_icounts);
     if (ctx->d_ctiles) (void)hipFree(ctx->d_ctiles);
     if (ctx->d_cchunks) (void)hipFree(ctx->d_cchunks);
     if (ctx->d_cpool) (void)hipFree(ctx->d_cpool);
@@ -822,50 +876,16 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
 // ------------------------------------------------------------------------------------------
 // genomes
 // ------------------------------------------------------------------------------------------
-// Two pinned staging buffers used alternately: the CPU fills one while the DMA engine drains the other
-// (host bytes -> device at the pace of the slower of memcpy and PCIe instead of their sum).
-struct StagePipe {
-    uint8_t *buf[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    bool busy[2] = {false, false};
-    int cur = 0;
-    size_t cap = 0;
-    hipStream_t st = nullptr;
-    bool init(size_t cap_, hipStream_t st_)
-    {
-        cap = cap_; st = st_;
-        for (int i = 0; i < 2; i++)
-            if (hipHostMalloc(reinterpret_cast<void **>(&buf[i]), cap, hipHostMallocDefault) != hipSuccess ||
-                hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
-        return true;
-    }
-    uint8_t *acquire()                        // buffer to fill next (waits for its previous copy)
-    {
-        if (busy[cur]) { (void)hipEventSynchronize(ev[cur]); busy[cur] = false; }
-        return buf[cur];
-    }
-    hipError_t submit(uint8_t *dst, size_t n) // copy the buffer just filled to the device, switch buffers
-    {
-        hipError_t e = hipMemcpyAsync(dst, buf[cur], n, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipEventRecord(ev[cur], st);
-        busy[cur] = true;
-        cur ^= 1;
-        return e;
-    }
-    void drain()
-    {
-        for (int i = 0; i < 2; i++)
-            if (busy[i]) { (void)hipEventSynchronize(ev[i]); busy[i] = false; }
-    }
-    ~StagePipe()
-    {
-        drain();
-        for (int i = 0; i < 2; i++) {
-            if (buf[i]) (void)hipHostFree(buf[i]);
-            if (ev[i]) (void)hipEventDestroy(ev[i]);
-        }
-    }
-};
+// the context's staging pair (2 x 32 MiB of pinned memory), made on first use
+static StagePipe *ctx_pipe(kgma_ctx *ctx)
+{
+    if (ctx->pipe) { ctx->pipe->drain(); return ctx->pipe; }
+    StagePipe *p = new (std::nothrow) StagePipe();
+    if (!p) return nullptr;
+    if (!p->init((size_t)32 << 20, ctx->stream)) { delete p; return nullptr; }
+    ctx->pipe = p;
+    return p;
+}
 
 static int genome_layout(kgma_ctx *ctx, kgma_genome *g, const int64_t *contig_len, int64_t n_contigs)
 {
@@ -977,12 +997,13 @@ int kgma_genome_from_host(kgma_ctx *ctx, const uint8_t *const *contig_ascii, con
     int rc = genome_layout(ctx, g, contig_len, n_contigs);
     if (rc != KGMA_OK) { kgma_genome_free(ctx, g); return rc; }
     // stream the records through two pinned staging buffers (fill one while the other is copied)
-    const size_t stage_cap = (size_t)32 << 20;
-    StagePipe pipe;
-    if (!pipe.init(stage_cap, ctx->stream)) {
+    StagePipe *pp = ctx_pipe(ctx);
+    if (!pp) {
         kgma_genome_free(ctx, g);
         return fail(ctx, KGMA_E_NOMEM, "cannot allocate the pinned staging buffers");
     }
+    StagePipe &pipe = *pp;
+    const size_t stage_cap = pipe.cap;
     uint8_t *stage = pipe.acquire();
     int64_t win_base = 0;   // device offset of stage[0]
     size_t fill = 0;        // bytes of the window in use
@@ -1070,56 +1091,40 @@ int kgma_genome_from_fasta(kgma_ctx *ctx, const uint8_t *text, int64_t n, kgma_g
     if (!out || n < 0 || (n > 0 && !text)) return fail(ctx, KGMA_E_ARG, "null argument");
     *out = nullptr;
     (void)hipSetDevice(ctx->device);
+    const bool dbg = getenv("KGMA_INGEST_DEBUG") != nullptr;
+    double tq = now_ms();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        const double t = now_ms();
+        fprintf(stderr, "  ingest: %-28s %8.3f ms\n", what, t - tq);
+        tq = t;
+    };
     constexpr int64_t FB = 4096;
-    // ---- host: locate the header lines (a '>' at the start of a line); O(file) memchr only ----
-    // (a header is a '>' right after a line break, wherever the scan starts: the ranges of the threads are independent)
+    // ---- upload the raw text through the staging pair, padded with '\n' to a block multiple; the threads that fill a
+    //      staging buffer also look for the header lines in the stretch they have just copied (a '>' at the start of a
+    //      line: the text is in their cache), so that the search costs no pass of its own.  The header lines are turned
+    //      into line breaks on the device afterwards (fasta_blank_kernel) ------------------------------------------
     struct Hdr { int64_t begin, end; };            // [begin, end): from '>' to just past its '\n'
     std::vector<Hdr> hdrs;
     const int n_thr = ingest_threads();
-    {
-        std::vector<std::vector<Hdr>> found((size_t)n_thr);
-        parallel_ranges(n, n_thr, (int64_t)8 << 20, [&](int t, int64_t b0, int64_t e0) {
-            const uint8_t *p = text + b0, *e = text + e0;
-            while (p < e) {
-                const uint8_t *q = static_cast<const uint8_t *>(memchr(p, '>', (size_t)(e - p)));
-                if (!q) break;
-                if (q == text || q[-1] == '\n') {
-                    const uint8_t *nl = static_cast<const uint8_t *>(memchr(q, '\n', (size_t)(text + n - q)));
-                    const int64_t hb = q - text, he = nl ? (nl - text) + 1 : n;
-                    found[(size_t)t].push_back(Hdr{hb, he});
-                    p = text + he;
-                } else {
-                    p = q + 1;
-                }
-            }
-        });
-        for (const std::vector<Hdr> &f : found) hdrs.insert(hdrs.end(), f.begin(), f.end());
-    }
-    const int64_t n_rec = (int64_t)hdrs.size();
-    if (n_rec == 0 && n > 0) {
-        for (int64_t i = 0; i < n; i++)
-            if (text[i] > 0x20) return fail(ctx, KGMA_E_ARG, "FASTA text has sequence data before the first '>' header");
-    }
-    if (n_rec > 0x7FFFFFF0ll) return fail(ctx, KGMA_E_UNSUPPORTED, "too many records");
-    if (n_rec > 0)
-        for (int64_t i = 0; i < hdrs[0].begin; i++)
-            if (text[i] > 0x20) return fail(ctx, KGMA_E_ARG, "FASTA text has sequence data before the first '>' header");
-
-    // ---- upload the text with header lines blanked, padded with '\n' to a block multiple -----
     const int64_t nb = (n + FB - 1) / FB;
     const int64_t n_pad = std::max<int64_t>(nb, 1) * FB;
     uint8_t *d_raw = nullptr;
     uint32_t *d_counts = nullptr;
-    int64_t *d_base = nullptr, *d_rs = nullptr;
-    StagePipe pipe;
+    int64_t *d_base = nullptr, *d_rs = nullptr, *d_ranges = nullptr;
     kgma_genome *g = nullptr;
     int rc = KGMA_OK;
+    StagePipe *pp = ctx_pipe(ctx);
+    if (!pp) return fail(ctx, KGMA_E_NOMEM, "cannot allocate the pinned staging buffers");
+    StagePipe &pipe = *pp;
     auto cleanup = [&]() {
         pipe.drain();
-        if (d_raw) (void)hipFree(d_raw);
-        if (d_counts) (void)hipFree(d_counts);
         if (d_base) (void)hipFree(d_base);
         if (d_rs) (void)hipFree(d_rs);
+        if (d_ranges) (void)hipFree(d_ranges);
+        if (ctx->ingest_cap > ((int64_t)2 << 30)) {                  // (large scratch is not kept)
+            (void)hipFree(ctx->d_ingest); ctx->d_ingest = nullptr; ctx->device_bytes -= ctx->ingest_cap; ctx->ingest_cap = 0;
+        }
     };
 #define FA_TRY(expr)                                                                              \
     do {                                                                                          \
@@ -1131,35 +1136,68 @@ int kgma_genome_from_fasta(kgma_ctx *ctx, const uint8_t *text, int64_t n, kgma_g
             return rc;                                                                            \
         }                                                                                         \
     } while (0)
-    FA_TRY(hipMalloc(reinterpret_cast<void **>(&d_raw), (size_t)n_pad));
-    FA_TRY(hipMalloc(reinterpret_cast<void **>(&d_counts), (size_t)std::max<int64_t>(nb, 1) * sizeof(uint32_t)));
-    const size_t stage_cap = (size_t)32 << 20;
-    if (!pipe.init(stage_cap, ctx->stream)) {
-        cleanup();
-        return fail(ctx, KGMA_E_NOMEM, "cannot allocate the pinned staging buffers");
-    }
+    rc = dev_reserve(ctx, ctx->d_ingest, ctx->ingest_cap, n_pad);
+    if (rc) return rc;
+    rc = dev_reserve(ctx, ctx->d_icounts, ctx->icounts_cap, std::max<int64_t>(nb, 1));
+    if (rc) return rc;
+    d_raw = ctx->d_ingest;
+    d_counts = ctx->d_icounts;
+    lap("scratch + staging");
     {
-        size_t hi = 0;   // first header that may intersect the current chunk
-        for (int64_t off = 0; off < n_pad; off += (int64_t)stage_cap) {
+        const int64_t stage_cap = (int64_t)pipe.cap;
+        std::vector<std::vector<Hdr>> found((size_t)n_thr);
+        int64_t hdr_done = 0;                              // text before this offset belongs to a header line already found
+        for (int64_t off = 0; off < n_pad; off += stage_cap) {
             uint8_t *stage = pipe.acquire();               // (the other buffer may still be on its way to the device)
-            const int64_t len = std::min<int64_t>((int64_t)stage_cap, n_pad - off);
+            const int64_t len = std::min<int64_t>(stage_cap, n_pad - off);
             const int64_t data = std::max<int64_t>(0, std::min<int64_t>(len, n - off));
+            for (std::vector<Hdr> &f : found) f.clear();
             if (data)
-                parallel_ranges(data, n_thr, (int64_t)2 << 20, [&](int, int64_t b0, int64_t e0) { memcpy(stage + b0, text + off + b0, (size_t)(e0 - b0)); });
+                parallel_ranges(data, n_thr, (int64_t)2 << 20, [&](int t, int64_t b0, int64_t e0) {
+                    memcpy(stage + b0, text + off + b0, (size_t)(e0 - b0));
+                    const uint8_t *p = stage + b0, *e = stage + e0;
+                    while (p < e) {
+                        const uint8_t *q = static_cast<const uint8_t *>(memchr(p, '>', (size_t)(e - p)));
+                        if (!q) break;
+                        const int64_t pos = off + (q - stage);                   // position in the text
+                        if (pos == 0 || text[pos - 1] == '\n') {
+                            const uint8_t *nl = static_cast<const uint8_t *>(memchr(text + pos, '\n', (size_t)(n - pos)));
+                            const int64_t he = nl ? (nl - text) + 1 : n;
+                            found[(size_t)t].push_back(Hdr{pos, he});
+                            if (he >= off + e0) break;                            // (the line runs past this thread's stretch)
+                            p = stage + (he - off);
+                        } else {
+                            p = q + 1;
+                        }
+                    }
+                });
             if (len > data) memset(stage + data, '\n', (size_t)(len - data));
-            while (hi < hdrs.size() && hdrs[hi].end <= off) hi++;
-            for (size_t h = hi; h < hdrs.size() && hdrs[h].begin < off + len; h++) {
-                const int64_t b = std::max<int64_t>(hdrs[h].begin, off), e = std::min<int64_t>(hdrs[h].end, off + len);
-                if (e > b) memset(stage + (b - off), '\n', (size_t)(e - b));
-            }
+            for (const std::vector<Hdr> &f : found)
+                for (const Hdr &h : f)
+                    if (h.begin >= hdr_done) { hdrs.push_back(h); hdr_done = h.end; }   // (a '>' inside a header line found earlier is text)
             FA_TRY(pipe.submit(d_raw + off, (size_t)len));
         }
+    }
+    lap("staged upload + header search");
+    const int64_t n_rec = (int64_t)hdrs.size();
+    if (n_rec > 0x7FFFFFF0ll) { cleanup(); return fail(ctx, KGMA_E_UNSUPPORTED, "too many records"); }
+    {
+        const int64_t lead = n_rec > 0 ? hdrs[0].begin : n;
+        for (int64_t i = 0; i < lead; i++)
+            if (text[i] > 0x20) { cleanup(); return fail(ctx, KGMA_E_ARG, "FASTA text has sequence data before the first '>' header"); }
+    }
+    if (n_rec > 0) {
+        static_assert(sizeof(Hdr) == 16, "header ranges are uploaded as int64 pairs");
+        FA_TRY(hipMalloc(reinterpret_cast<void **>(&d_ranges), (size_t)n_rec * sizeof(Hdr)));
+        FA_TRY(hipMemcpyAsync(d_ranges, hdrs.data(), (size_t)n_rec * sizeof(Hdr), hipMemcpyHostToDevice, ctx->stream));
+        FA_TRY(launch_fasta_blank(d_raw, d_ranges, (int)n_rec, ctx->stream));
     }
     // ---- kernel 1: residues per block; host prefix sum -> block bases --------------------------
     FA_TRY(launch_fasta_count(d_raw, n_pad, d_counts, ctx->stream));
     std::vector<uint32_t> counts((size_t)std::max<int64_t>(nb, 1), 0);
     FA_TRY(hipMemcpyAsync(counts.data(), d_counts, (size_t)std::max<int64_t>(nb, 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     FA_TRY(hipStreamSynchronize(ctx->stream));
+    lap("upload drained + count kernel");
     std::vector<int64_t> base((size_t)std::max<int64_t>(nb, 1) + 1, 0);
     for (int64_t b = 0; b < nb; b++) base[(size_t)b + 1] = base[(size_t)b] + counts[(size_t)b];
     const int64_t total_res = nb > 0 ? base[(size_t)nb] : 0;
@@ -1187,6 +1225,7 @@ int kgma_genome_from_fasta(kgma_ctx *ctx, const uint8_t *text, int64_t n, kgma_g
     for (int64_t c = 0; c < n_rec; c++) rs[(size_t)c] = residues_before(hdrs[(size_t)c].begin);
     rs[(size_t)n_rec] = total_res;
     for (int64_t c = 0; c < n_rec; c++) lens[(size_t)c] = rs[(size_t)c + 1] - rs[(size_t)c];
+    lap("record table (host)");
     // ---- layout, kernel 2 (scatter), pack ---------------------------------------------------------
     g = new (std::nothrow) kgma_genome();
     if (!g) { cleanup(); return fail(ctx, KGMA_E_NOMEM, "out of host memory"); }
@@ -1208,8 +1247,11 @@ int kgma_genome_from_fasta(kgma_ctx *ctx, const uint8_t *text, int64_t n, kgma_g
         FA_TRY(hipStreamSynchronize(ctx->stream));
     }
 #undef FA_TRY
+    lap("layout + scatter kernel");
     cleanup();
+    lap("free scratch");
     rc = kgma_genome_repack(ctx, g);
+    lap("pack launched");
     if (rc != KGMA_OK) { kgma_genome_free(ctx, g); return rc; }
     *out = g;
     return KGMA_OK;

@@ -232,6 +232,13 @@ __global__ __launch_bounds__(256) void fasta_count_kernel(const uint8_t *__restr
     if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// header lines (and whatever else the host lists) become line breaks: ranges[2h], ranges[2h+1) per workgroup h
+__global__ __launch_bounds__(256) void fasta_blank_kernel(uint8_t *__restrict__ raw, const int64_t *__restrict__ ranges, int n_ranges)
+{
+    for (int h = blockIdx.x; h < n_ranges; h += gridDim.x)
+        for (int64_t i = ranges[2 * h] + threadIdx.x; i < ranges[2 * h + 1]; i += 256) raw[i] = '\n';
+}
+
 // rec_start[c] = index (in residue order over the whole file) of record c's first residue
 __global__ __launch_bounds__(256) void fasta_scatter_kernel(const uint8_t *__restrict__ raw, int64_t n,
                                                             const int64_t *__restrict__ block_base,
@@ -1243,6 +1250,13 @@ hipError_t launch_fasta_count(const uint8_t *raw, int64_t n, uint32_t *counts, h
     const int64_t nb = (n + FASTA_BLOCK - 1) / FASTA_BLOCK;
     if (nb <= 0) return hipSuccess;
     hipLaunchKernelGGL(fasta_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, raw, n, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_fasta_blank(uint8_t *raw, const int64_t *ranges, int n_ranges, hipStream_t st)
+{
+    if (n_ranges <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fasta_blank_kernel, dim3((unsigned)std::min(n_ranges, 65535)), dim3(256), 0, st, raw, ranges, n_ranges);
     return hipGetLastError();
 }
 

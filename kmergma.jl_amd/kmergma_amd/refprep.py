@@ -253,7 +253,9 @@ def estimate_optimal_threshold(RV, average_length, seed: int = 42, num_trials: i
         rv = np.asarray(rv, dtype=np.float64)
         k = int(round(np.log(rv.size) / np.log(4)))
         total = 0.0
-        seqs = [bytes(_BASES[i] for i in rng.integers(0, 4, size=length)) for _ in range(num_trials)]
+        # (the same draws as one rng.integers call per trial; the residue bytes are looked up in one numpy gather)
+        lut = np.frombuffer(bytes(_BASES), dtype=np.uint8)
+        seqs = [lut[rng.integers(0, 4, size=length)].tobytes() for _ in range(num_trials)]
         dists = ctx.kmer_dist_batch(seqs, rv, k) if ctx is not None else [kmer_dist(seq, rv, k) for seq in seqs]
         for d in dists:                                  # summed in trial order (:13-15)
             total += float(d)
