@@ -316,8 +316,36 @@ int kgma_resolve_ties_local(kgma_ctx *ctx, const kgma_genome *genome);
  * EQUALS the stale running minimum left by an earlier dip (GenomeMiner.jl:93-103) -- a tie only the hit state machine
  * can see -- is decided by asking the caller for the residues of the stretch in between: fn must write `len` residue
  * characters of record `contig` starting at 1-based `pos` and return 0 (anything else: the tie stays KGMA_HIT_TIE).
- * NULL (default): such ties stay flagged.  The chain replay (KGMA_F_CHAIN_REPLAY) is not run by kgma_replay_dips. */
+ * NULL (default): such ties stay flagged.  (KGMA_F_CHAIN_REPLAY needs kgma_set_chain_source below.) */
 typedef int (*kgma_fetch_fn)(void *user, int32_t contig, int64_t pos, int64_t len, uint8_t *out);
+/* Chain-value source for kgma_replay_dips with KGMA_F_CHAIN_REPLAY: rank 0 holds no residues, so the reference's running
+ * Float64 value (src/GenomeMiner.jl:46-47,70-77) of the (record, KFV) pairs that need it is produced where the residues
+ * are.  fn receives the pairs (0-based record, 1-based KFV) and, per pair, the sorted disjoint window intervals
+ * win_lo/win_hi[iv_begin[p] .. iv_begin[p+1]) whose values are wanted (the first is always window 1), and writes one
+ * Float64 per wanted window, pair after pair, in window order; it returns 0 on success.  A multi-GPU host serves it by
+ * running kgma_chain_export on every rank's slices of the record (in whole-record window order a slice ends one
+ * transition before the next begins) and walking the pieces in order with kgma_host_chain_walk, each piece starting on
+ * the value the previous one ended on (kmergma_amd.parallel.scan_sharded).  NULL (default): kgma_replay_dips ignores the
+ * flag, ties stay flagged. */
+typedef int (*kgma_chain_fn)(void *user, int64_t n_pairs, const int32_t *contig, const int32_t *kfv, const int64_t *iv_begin,
+                             const int64_t *win_lo, const int64_t *win_hi, double *values);
+int kgma_set_chain_source(kgma_ctx *ctx, kgma_chain_fn fn, void *user);
+/* 2 k N^2 of KFV `kfv` (1-based): exact distance = D / scale (what kgma_host_chain_walk checks the chain against); N as given
+ * to or inferred by kgma_set_refs. */
+int kgma_kfv_scale(kgma_ctx *ctx, int32_t kfv, double *scale, int64_t *n_refs);
+/* The tested windows inside the threshold guard band found by the last scan (0-based record, 1-based KFV, window start):
+ * they travel with the dips, because the chain replay samples the running value at them.  kgma_set_att hands the merged
+ * list to the NEXT kgma_replay_dips. */
+int kgma_get_att(kgma_ctx *ctx, int32_t *contig, int32_t *kfv, int64_t *pos, int64_t cap, int64_t *n);
+int kgma_set_att(kgma_ctx *ctx, const int32_t *contig, const int32_t *kfv, const int64_t *pos, int64_t n);
+/* The chain kernel's output for windows 1 .. last_window of one record and KFV, for a caller that joins the pieces of a
+ * record cut across GPUs: the streams (kgma_chain_export_copy: first window, windows, first chunk, exact D of the first
+ * window), the chunk records and the pool exactly as kgma_host_chain_walk takes them; the steps that hold a window of
+ * win_lo/win_hi are raw.  *first = the Float64 distance of the record's window 1 (summed left to right). */
+int kgma_chain_export(kgma_ctx *ctx, const kgma_genome *genome, int64_t contig, int32_t kfv, int64_t last_window,
+                      const int64_t *win_lo, const int64_t *win_hi, int64_t n_intervals, int64_t *n_streams, int64_t *n_chunks,
+                      int64_t *pool_units, double *first);
+int kgma_chain_export_copy(kgma_ctx *ctx, int64_t *win0, int32_t *n_valid, int64_t *chunk_base, int64_t *D0, void *chunks, void *pool);
 int kgma_set_residue_source(kgma_ctx *ctx, kgma_fetch_fn fn, void *user);
 int kgma_get_dip_last_min(kgma_ctx *ctx, int64_t *out, int64_t cap, int64_t *n);   /* last window attaining each dip's minimum */
 int kgma_replay_dips(kgma_ctx *ctx, int32_t mode, int64_t buff, int64_t genome_pos0, uint32_t flags, int64_t n_records,

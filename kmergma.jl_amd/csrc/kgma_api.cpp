@@ -246,6 +246,10 @@ struct kgma_ctx {
     unsigned int aux_used = 0;
     std::vector<kgma_hit> hits;
     kgma_fetch_fn fetch = nullptr; void *fetch_user = nullptr;   // residue source for kgma_replay_dips (dips found on other GPUs)
+    kgma_chain_fn chain_src = nullptr; void *chain_user = nullptr;   // chain-value source for kgma_replay_dips (the residues are on other GPUs)
+    std::vector<AttWin> att_next;            // guard-band windows handed over for the next kgma_replay_dips (kgma_set_att)
+    // kgma_chain_export: one pair's chain material, kept for kgma_chain_export_copy
+    std::vector<ChainStream> cx_streams; std::vector<ChainChunk> cx_chunks, cx_pool; double cx_first = 0;
     std::vector<kgma_alignment> aligns;      // alignments the hit state machine consumed (kgma_scan_aligned), in order
     int64_t n_align_device = 0, n_align_host = 0;
     std::vector<int64_t> contig_len;
@@ -2381,7 +2385,7 @@ static bool chain_device_enabled()
 }
 
 static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vector<ChainPair> &pairs, std::vector<size_t> el, std::vector<char> &done,
-                                 ChainDevInfo &info);
+                                 ChainDevInfo &info, bool export_only = false);
 
 static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<ChainPair> &pairs, std::vector<char> &done, ChainDevInfo &info)
 {
@@ -2412,7 +2416,7 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
 }
 
 static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vector<ChainPair> &pairs, std::vector<size_t> el, std::vector<char> &done,
-                                 ChainDevInfo &info)
+                                 ChainDevInfo &info, bool export_only)
 {
     const int k = ctx->k;
     const int64_t NB = (int64_t)1 << (2 * k);
@@ -2664,6 +2668,18 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
         for (size_t u = 0; u < el.size(); u++)
             if (!jobs[u].ok) return fail(ctx, KGMA_E_HIP, "internal: first window of record %d KFV %d", pairs[el[u]].c, pairs[el[u]].j + 1);
     }
+    if (export_only) {
+        // (kgma_chain_export: one pair; its material goes to the caller, who walks it where the whole record's pieces meet)
+        ctx->cx_streams.assign(streams.begin(), streams.end());
+        const ChainChunk *hc = reinterpret_cast<const ChainChunk *>(ctx->h_cpin + off_chunks), *hp = reinterpret_cast<const ChainChunk *>(ctx->h_cpin + off_raw);
+        ctx->cx_chunks.assign(hc, hc + n_chunks);
+        ctx->cx_pool.assign(hp, hp + pool_units);
+        ctx->cx_first = first.empty() ? 0.0 : first[0];
+        for (size_t u = 0; u < el.size(); u++) done[el[u]] = 1;
+        info.pairs += (int64_t)el.size();
+        info.streams += n_tiles;
+        return KGMA_OK;
+    }
     int n_threads = (int)std::thread::hardware_concurrency();
     if (const char *e = getenv("KGMA_CHAIN_THREADS")) n_threads = atoi(e);
     n_threads = std::max(1, std::min(n_threads, 64));
@@ -2722,12 +2738,12 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
     // (A) ties inside one dip are decided where that is provably independent of the chain's history
     {
         TieResolver tr{ctx, g, {}, {}, {}, nullptr, {}, {}};
-        tr.prefetch();
+        if (g) tr.prefetch();                                          // (no genome: kgma_replay_dips, residues through the source)
         for (size_t i = 0; i < ctx->dips.size(); i++) {
             kgma_dip &d = ctx->dips[i];
             if (!(d.flags & KGMA_HIT_TIE)) continue;
             const TieResolver::Result r = tr.replay(d.kfv - 1, d.contig, d.argmin, d.D_min, d.argmin, ctx->dip_argl[i], d.D_min, false,
-                                                    tr.prefetched(i));
+                                                    g ? tr.prefetched(i) : nullptr);
             if (r.ok && !r.sensitive) {
                 d.argmin = r.pos;
                 d.flags = (d.flags & ~(uint32_t)KGMA_HIT_TIE) | KGMA_HIT_TIE_RESOLVED;
@@ -2814,7 +2830,31 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
     // ---- the chains: on the device where its kernel applies, the rest (and whatever failed a check there) on the host ----
     std::vector<char> on_device(pairs.size(), 0);
     ChainDevInfo dev;
-    if (chain_device_enabled()) {
+    if (!g) {
+        // kgma_replay_dips: the residues are with the ranks that scanned them; the caller's source runs the chain there
+        // (kgma_chain_export per slice) and hands back the values at the wanted windows
+        if (!ctx->chain_src) return fail(ctx, KGMA_E_STATE, "chain replay without a genome needs a chain source (kgma_set_chain_source)");
+        std::vector<int32_t> pc(pairs.size()), pj(pairs.size());
+        std::vector<int64_t> ivb(pairs.size() + 1, 0), lo, hi;
+        size_t nv = 0;
+        for (size_t i = 0; i < pairs.size(); i++) {
+            pc[i] = pairs[i].c; pj[i] = pairs[i].j + 1;
+            for (const ChainInterval &x : pairs[i].iv) { lo.push_back(x.lo); hi.push_back(x.hi); }
+            ivb[i + 1] = (int64_t)lo.size();
+            nv += pairs[i].val.size();
+        }
+        std::vector<double> vals(nv, 0.0);
+        const int src = ctx->chain_src(ctx->chain_user, (int64_t)pairs.size(), pc.data(), pj.data(), ivb.data(), lo.data(), hi.data(), vals.data());
+        if (src != 0) return fail(ctx, KGMA_E_STATE, "the chain source failed (status %d)", src);
+        size_t off = 0;
+        for (size_t i = 0; i < pairs.size(); i++) {
+            std::copy(vals.begin() + (long)off, vals.begin() + (long)(off + pairs[i].val.size()), pairs[i].val.begin());
+            off += pairs[i].val.size();
+            on_device[i] = 1;
+            dev.pairs++;
+            dev.windows += pairs[i].last;
+        }
+    } else if (chain_device_enabled()) {
         const int drc = chain_on_device(ctx, g, pairs, on_device, dev);
         if (drc) return drc;
     }
@@ -3295,7 +3335,11 @@ int kgma_replay_dips(kgma_ctx *ctx, int32_t mode, int64_t buff, int64_t genome_p
     ctx->dips.assign(dips, dips + n_dips);
     ctx->dip_argl.assign(dip_last_min, dip_last_min + n_dips);
     ctx->dip_aux.assign((size_t)n_dips, -1);
-    ctx->att.clear(); ctx->chain_pair.clear(); ctx->firstF.clear(); ctx->dip_fmin.clear(); ctx->dip_fexit.clear();
+    ctx->att.swap(ctx->att_next);                                      // (kgma_set_att; empty otherwise)
+    ctx->att_next.clear();
+    for (const kgma_ctx::AttWin &a : ctx->att)
+        if (a.contig < 0 || a.contig >= n_records || a.kfv < 0 || a.kfv >= ctx->m) return fail(ctx, KGMA_E_ARG, "kgma_set_att: window of record %d / KFV %d", a.contig, a.kfv + 1);
+    ctx->chain_pair.clear(); ctx->firstF.clear(); ctx->dip_fmin.clear(); ctx->dip_fexit.clear();
     for (int64_t i = 1; i < n_dips; i++) {
         const kgma_dip &a = dips[i - 1], &b = dips[i];
         const bool ordered = a.contig < b.contig || (a.contig == b.contig && (a.kfv < b.kfv || (a.kfv == b.kfv && a.start < b.start)));
@@ -3310,7 +3354,101 @@ int kgma_replay_dips(kgma_ctx *ctx, int32_t mode, int64_t buff, int64_t genome_p
     ctx->have_dists = false;
     ctx->last_mode = mode;
     ctx->stats.n_dips = n_dips;
+    reset_chain_stats(ctx);
+    if ((flags & KGMA_F_CHAIN_REPLAY) && !(flags & KGMA_F_NO_TIE_RESOLVE) && ctx->chain_src) {
+        const int rc = chain_decide(ctx, nullptr, mode);
+        if (rc) return rc;
+    }
     return replay_hits(ctx, nullptr, mode, buff, genome_pos0, flags, align, align_user);
+}
+
+int kgma_kfv_scale(kgma_ctx *ctx, int32_t kfv, double *scale, int64_t *n_refs)
+{
+    if (!ctx || !scale) return KGMA_E_ARG;
+    if (kfv < 1 || kfv > ctx->m) return fail(ctx, KGMA_E_ARG, "no such KFV");
+    const KfvInfo &f = ctx->kfv[(size_t)(kfv - 1)];
+    *scale = 2.0 * (double)ctx->k * (double)f.N * (double)f.N;
+    if (n_refs) *n_refs = f.N;
+    return KGMA_OK;
+}
+
+int kgma_set_chain_source(kgma_ctx *ctx, kgma_chain_fn fn, void *user)
+{
+    if (!ctx) return KGMA_E_ARG;
+    ctx->chain_src = fn; ctx->chain_user = user;
+    return KGMA_OK;
+}
+
+int kgma_get_att(kgma_ctx *ctx, int32_t *contig, int32_t *kfv, int64_t *pos, int64_t cap, int64_t *n)
+{
+    if (!ctx || !n) return KGMA_E_ARG;
+    *n = (int64_t)ctx->att.size();
+    if (!contig && !kfv && !pos) return KGMA_OK;
+    if (!contig || !kfv || !pos || cap < *n) return fail(ctx, KGMA_E_ARG, "kgma_get_att: capacity %lld < %lld", (long long)cap, (long long)*n);
+    for (int64_t i = 0; i < *n; i++) { contig[i] = ctx->att[(size_t)i].contig; kfv[i] = ctx->att[(size_t)i].kfv + 1; pos[i] = ctx->att[(size_t)i].pos; }
+    return KGMA_OK;
+}
+
+int kgma_set_att(kgma_ctx *ctx, const int32_t *contig, const int32_t *kfv, const int64_t *pos, int64_t n)
+{
+    if (!ctx || n < 0 || (n && (!contig || !kfv || !pos))) return KGMA_E_ARG;
+    ctx->att_next.clear();
+    for (int64_t i = 0; i < n; i++) ctx->att_next.push_back(kgma_ctx::AttWin{contig[i], kfv[i] - 1, pos[i]});
+    std::sort(ctx->att_next.begin(), ctx->att_next.end(), [](const kgma_ctx::AttWin &a, const kgma_ctx::AttWin &b) {
+        if (a.contig != b.contig) return a.contig < b.contig;
+        if (a.kfv != b.kfv) return a.kfv < b.kfv;
+        return a.pos < b.pos;
+    });
+    return KGMA_OK;
+}
+
+int kgma_chain_export(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int32_t kfv, int64_t last_window, const int64_t *win_lo,
+                      const int64_t *win_hi, int64_t n_intervals, int64_t *n_streams, int64_t *n_chunks, int64_t *pool_units, double *first)
+{
+    if (!ctx || !g || !n_streams || !n_chunks || !pool_units || !first || n_intervals < 0 || (n_intervals && (!win_lo || !win_hi))) return KGMA_E_ARG;
+    if (ctx->m == 0) return fail(ctx, KGMA_E_STATE, "kgma_set_refs has not been called");
+    if (kfv < 1 || kfv > ctx->m || contig < 0 || contig >= g->n_contigs) return fail(ctx, KGMA_E_ARG, "no such record / KFV");
+    const KfvInfo &f = ctx->kfv[(size_t)(kfv - 1)];
+    const int64_t nwin = g->cd[(size_t)contig].len - f.W + 1;
+    if (last_window < 2 || last_window > nwin) return fail(ctx, KGMA_E_ARG, "last window %lld outside 2 ... %lld", (long long)last_window, (long long)nwin);
+    std::vector<ChainPair> pairs(1);
+    ChainPair &p = pairs[0];
+    p.c = (int32_t)contig; p.j = kfv - 1; p.d0 = p.d1 = p.a0 = p.a1 = 0;
+    int64_t prev = 0;
+    for (int64_t i = 0; i < n_intervals; i++) {
+        if (win_lo[i] < 1 || win_hi[i] < win_lo[i] || win_lo[i] <= prev || win_hi[i] > last_window) return fail(ctx, KGMA_E_ARG, "window intervals must be sorted, disjoint and <= the last window");
+        p.iv.push_back(ChainInterval{win_lo[i], win_hi[i]});
+        prev = win_hi[i];
+    }
+    p.last = last_window;
+    {
+        kgma_genome *gm = const_cast<kgma_genome *>(g);
+        const int src = genome_sync(ctx, gm);
+        if (src) return src;
+    }
+    const int k = ctx->k;
+    if (!chain_applies(k, (int)(f.W - k + 1), f.N, f.Smax <= 32767) || f.ref_form < 0 || chain_slots_per_cu(k, f.Smax <= 32767) < 1)
+        return fail(ctx, KGMA_E_UNSUPPORTED, "the chain kernel does not serve this KFV");
+    std::vector<char> done(1, 0);
+    ChainDevInfo info;
+    (void)hipSetDevice(ctx->device);
+    const int rc = chain_on_device_batch(ctx, g, pairs, std::vector<size_t>(1, 0), done, info, true);
+    if (rc) return rc;
+    if (!done[0]) return fail(ctx, KGMA_E_NOMEM, "the chain kernel's buffers do not fit");
+    *n_streams = (int64_t)ctx->cx_streams.size(); *n_chunks = (int64_t)ctx->cx_chunks.size(); *pool_units = (int64_t)ctx->cx_pool.size();
+    *first = ctx->cx_first;
+    return KGMA_OK;
+}
+
+int kgma_chain_export_copy(kgma_ctx *ctx, int64_t *win0, int32_t *n_valid, int64_t *chunk_base, int64_t *D0, void *chunks, void *pool)
+{
+    if (!ctx || !win0 || !n_valid || !chunk_base || !D0 || !chunks) return KGMA_E_ARG;
+    for (size_t i = 0; i < ctx->cx_streams.size(); i++) {
+        win0[i] = ctx->cx_streams[i].win0; n_valid[i] = ctx->cx_streams[i].n_valid; chunk_base[i] = ctx->cx_streams[i].chunk_base; D0[i] = ctx->cx_streams[i].D0;
+    }
+    if (!ctx->cx_chunks.empty()) memcpy(chunks, ctx->cx_chunks.data(), ctx->cx_chunks.size() * sizeof(ChainChunk));
+    if (pool && !ctx->cx_pool.empty()) memcpy(pool, ctx->cx_pool.data(), ctx->cx_pool.size() * sizeof(ChainChunk));
+    return KGMA_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -32,7 +32,8 @@ EXPORTS = [
     "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips", "kgma_align_hits_device", "kgma_repack_scan_hits",
     "kgma_kmer_count_batch", "kgma_kmer_dist_batch", "kgma_step_begin", "kgma_step_end", "kgma_set_reserved_cus",
     "kgma_scan_aligned", "kgma_get_alignments", "kgma_set_residue_source", "kgma_host_chain_values",
-    "kgma_chain_values", "kgma_host_chain_walk", "kgma_chain_chunk_steps",
+    "kgma_chain_values", "kgma_host_chain_walk", "kgma_chain_chunk_steps", "kgma_set_chain_source", "kgma_get_att", "kgma_set_att",
+    "kgma_chain_export", "kgma_chain_export_copy", "kgma_kfv_scale",
 ]
 
 
@@ -72,6 +73,8 @@ DIP_DTYPE = np.dtype([("contig", "<i4"), ("kfv", "<i4"), ("start", "<i8"), ("end
 ALIGN_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                        C.POINTER(C.c_int64), C.POINTER(C.c_int64))
 FETCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_uint8))
+CHAIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                       C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double))
 
 
 class KgmaError(RuntimeError):
@@ -150,6 +153,12 @@ def load():
     L.kgma_scan_aligned.argtypes = [vp, vp, i32, i64, i64, C.c_uint32, P(C.c_char_p), P(i64), i32, i32]
     L.kgma_get_alignments.argtypes = [vp, P(KgmaAlignment), i64, P(i64), P(i64), P(i64)]
     L.kgma_set_residue_source.argtypes = [vp, FETCH_FN, vp]
+    L.kgma_set_chain_source.argtypes = [vp, CHAIN_FN, vp]
+    L.kgma_kfv_scale.argtypes = [vp, i32, P(dbl), P(i64)]
+    L.kgma_get_att.argtypes = [vp, P(i32), P(i32), P(i64), i64, P(i64)]
+    L.kgma_set_att.argtypes = [vp, P(i32), P(i32), P(i64), i64]
+    L.kgma_chain_export.argtypes = [vp, vp, i64, i32, i64, P(i64), P(i64), i64, P(i64), P(i64), P(i64), P(dbl)]
+    L.kgma_chain_export_copy.argtypes = [vp, P(i64), P(i32), P(i64), P(i64), vp, vp]
     L.kgma_host_chain_values.argtypes = [C.c_char_p, i64, P(dbl), i32, i64, P(i64), P(i64), i64, P(dbl), i64, P(i64)]
     L.kgma_chain_values.argtypes = [vp, vp, i64, i32, P(i64), P(i64), i64, P(dbl), i64, P(i64)]
     L.kgma_host_chain_walk.argtypes = [dbl, dbl, i32, i64, P(i64), P(i32), P(i64), P(i64), vp, i64, vp, i64, P(i64), P(i64), i64,
@@ -488,6 +497,76 @@ class Context:
                 return 1
         self._fetch_cb = FETCH_FN(tramp)                 # kept alive with the context
         self._check(load().kgma_set_residue_source(self._h, self._fetch_cb, None))
+
+    def set_chain_source(self, source: Optional[Callable]) -> None:
+        """kgma_set_chain_source: `source(pairs) -> list of arrays`, pairs = [(record, kfv (1-based), [(lo, hi), ...]), ...],
+        must return for every pair the reference's running Float64 value at its wanted windows, in order; None removes it."""
+        if source is None:
+            self._chain_cb = None
+            self._check(load().kgma_set_chain_source(self._h, C.cast(None, CHAIN_FN), None))
+            return
+
+        def tramp(_u, n_pairs, contig, kfv, ivb, lo, hi, values):
+            try:
+                pairs = []
+                for p in range(int(n_pairs)):
+                    pairs.append((int(contig[p]), int(kfv[p]), [(int(lo[i]), int(hi[i])) for i in range(int(ivb[p]), int(ivb[p + 1]))]))
+                out = source(pairs)
+                off = 0
+                for (c, j, iv), v in zip(pairs, out):
+                    n = sum(b - a + 1 for a, b in iv)
+                    v = np.ascontiguousarray(v, dtype=np.float64)
+                    if v.size != n:
+                        return 2
+                    C.memmove(C.addressof(values.contents) + 8 * off, v.ctypes.data, 8 * n)
+                    off += n
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._chain_cb = CHAIN_FN(tramp)                 # kept alive with the context
+        self._check(load().kgma_set_chain_source(self._h, self._chain_cb, None))
+
+    def kfv_scale(self, kfv: int) -> float:
+        """2 k N^2 of KFV `kfv` (1-based)."""
+        sc = C.c_double(0)
+        self._check(load().kgma_kfv_scale(self._h, int(kfv), C.byref(sc), None))
+        return sc.value
+
+    def att(self) -> np.ndarray:
+        """kgma_get_att: tested windows inside the threshold guard band, as an (n, 3) int64 array (record, 1-based KFV, window)."""
+        n = C.c_int64(0)
+        self._check(load().kgma_get_att(self._h, None, None, None, 0, C.byref(n)))
+        c = np.zeros(max(n.value, 1), dtype=np.int32); j = np.zeros(max(n.value, 1), dtype=np.int32); p = np.zeros(max(n.value, 1), dtype=np.int64)
+        if n.value:
+            self._check(load().kgma_get_att(self._h, _np_ptr(c, C.c_int32), _np_ptr(j, C.c_int32), _np_ptr(p, C.c_int64), n.value, C.byref(n)))
+        return np.stack([c[:n.value].astype(np.int64), j[:n.value].astype(np.int64), p[:n.value]], axis=1) if n.value else np.zeros((0, 3), dtype=np.int64)
+
+    def set_att(self, att) -> None:
+        """kgma_set_att: guard-band windows ((n, 3): record, 1-based KFV, window) for the next replay_dips."""
+        a = np.asarray(att, dtype=np.int64).reshape(-1, 3)
+        c = np.ascontiguousarray(a[:, 0], dtype=np.int32); j = np.ascontiguousarray(a[:, 1], dtype=np.int32); p = np.ascontiguousarray(a[:, 2], dtype=np.int64)
+        n = a.shape[0]
+        self._check(load().kgma_set_att(self._h, _np_ptr(c, C.c_int32) if n else None, _np_ptr(j, C.c_int32) if n else None,
+                                        _np_ptr(p, C.c_int64) if n else None, n))
+
+    def chain_export(self, genome: "Genome", contig: int, kfv: int, last_window: int, intervals) -> dict:
+        """kgma_chain_export: the chain kernel's output for windows 1 .. last_window of (record, KFV), as host_chain_walk takes
+        it: dict(first, win0, n_valid, chunk_base, D0, chunks, pool)."""
+        lo = np.asarray([a for a, _ in intervals], dtype=np.int64)
+        hi = np.asarray([b for _, b in intervals], dtype=np.int64)
+        ns, nc, npool, first = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_double(0)
+        self._check(load().kgma_chain_export(self._h, genome._h, int(contig), int(kfv), int(last_window), _np_ptr(lo, C.c_int64) if lo.size else None,
+                                             _np_ptr(hi, C.c_int64) if hi.size else None, lo.size, C.byref(ns), C.byref(nc), C.byref(npool),
+                                             C.byref(first)))
+        win0 = np.zeros(max(ns.value, 1), dtype=np.int64); nv = np.zeros(max(ns.value, 1), dtype=np.int32)
+        cb = np.zeros(max(ns.value, 1), dtype=np.int64); D0 = np.zeros(max(ns.value, 1), dtype=np.int64)
+        chunks = np.zeros(max(nc.value, 1), dtype=CHAIN_CHUNK_DTYPE); pool = np.zeros(max(npool.value, 1), dtype=CHAIN_CHUNK_DTYPE)
+        self._check(load().kgma_chain_export_copy(self._h, _np_ptr(win0, C.c_int64), _np_ptr(nv, C.c_int32), _np_ptr(cb, C.c_int64), _np_ptr(D0, C.c_int64),
+                                                  chunks.ctypes.data_as(C.c_void_p), pool.ctypes.data_as(C.c_void_p)))
+        return dict(first=first.value, win0=win0[:ns.value], n_valid=nv[:ns.value], chunk_base=cb[:ns.value], D0=D0[:ns.value],
+                    chunks=chunks[:nc.value], pool=pool[:npool.value])
 
     def resolve_ties_local(self, genome: "Genome") -> None:
         self._check(load().kgma_resolve_ties_local(self._h, genome._h))

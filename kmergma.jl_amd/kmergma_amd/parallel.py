@@ -9,7 +9,7 @@ GPU with no data-path collective, and ONE variable-length gather brings the hit 
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import Optional, List, Sequence, Tuple
 
 import numpy as np
 
@@ -294,8 +294,10 @@ class RecordSource:
         return RecordSource([len(r) for r in recs], lambda c, b, e: recs[c][b:e])
 
 
-def local_scan(ctx, records, my_slices: Sequence[Tuple[int, int, int]], mode: int, flags: int = 0) -> dict:
-    """One rank's part: scan the slices, decide local ties, return dips in whole-record coordinates."""
+def local_scan(ctx, records, my_slices: Sequence[Tuple[int, int, int]], mode: int, flags: int = 0, keep_genome: bool = False) -> dict:
+    """One rank's part: scan the slices, decide local ties, return dips (and the guard-band windows) in whole-record
+    coordinates.  keep_genome: the slices' device genome stays alive in payload["_genome"] (the caller frees it): the chain
+    replay may come back for it (serve_chain_request)."""
     from . import _lib
     src = RecordSource.of(records)
     mode_single = mode == _lib.MODE_SINGLE
@@ -305,21 +307,33 @@ def local_scan(ctx, records, my_slices: Sequence[Tuple[int, int, int]], mode: in
     for (c, u, v) in my_slices:
         b, e = slice_bases(u, v, src.lengths[c], mode_single, ws, ctx.k)
         pieces.append(src.fetch(c, b, e))
-    payload = dict(slices=list(my_slices), dips=np.zeros(0, dtype=_lib.DIP_DTYPE), last_min=np.zeros(0, dtype=np.int64), first_D={})
+    payload = dict(slices=list(my_slices), dips=np.zeros(0, dtype=_lib.DIP_DTYPE), last_min=np.zeros(0, dtype=np.int64), first_D={},
+                   att=np.zeros((0, 3), dtype=np.int64))
     if not pieces:
         return payload
     g = ctx.genome_from_host(pieces)
     try:
-        ctx.scan_device(g, mode, flags)
+        ctx.scan_device(g, mode, flags & ~_lib.F_CHAIN_REPLAY)
         if not (flags & _lib.F_NO_TIE_RESOLVE):
             ctx.resolve_ties_local(g)
         dips = ctx.dips_array().copy()
         last_min = ctx.dip_last_min().copy()
         fw = [ctx.first_window(j + 1) for j in range(m)]
-    finally:
+        att = ctx.att().copy()
+    except Exception:
+        g.free()
+        raise
+    if keep_genome:
+        payload["_genome"] = g
+    else:
         g.free()
     off = np.array([u - 1 for (_, u, _) in my_slices], dtype=np.int64)
     rec = np.array([c for (c, _, _) in my_slices], dtype=np.int32)
+    if att.shape[0]:
+        loc = att[:, 0]
+        att[:, 2] += off[loc]
+        att[:, 0] = rec[loc]
+    payload["att"] = att
     if dips.size:
         loc = dips["contig"].astype(np.int64)
         o = off[loc]
@@ -337,7 +351,7 @@ def local_scan(ctx, records, my_slices: Sequence[Tuple[int, int, int]], mode: in
 
 
 # ---- the ranks' dips travel as ONE fixed-layout int64 tensor per rank (RCCL / gloo all_gather), like the hit records ----
-_PAYLOAD_HEADER = 8       # n_dips, n_first, status, error class, error record, error position, rank, reserved
+_PAYLOAD_HEADER = 8       # n_dips, n_first, status, error class, error record, error position, rank, n_att
 
 
 def encode_payload(payload: dict, m: int) -> np.ndarray:
@@ -346,8 +360,9 @@ def encode_payload(payload: dict, m: int) -> np.ndarray:
     dips = np.ascontiguousarray(payload["dips"], dtype=_lib.DIP_DTYPE)
     nd = int(dips.shape[0])
     first = sorted(payload["first_D"].items())
-    out = np.zeros(_PAYLOAD_HEADER + nd * 9 + len(first) * (1 + m), dtype=np.int64)
-    out[0], out[1] = nd, len(first)
+    att = np.asarray(payload.get("att", np.zeros((0, 3), dtype=np.int64)), dtype=np.int64).reshape(-1, 3)
+    out = np.zeros(_PAYLOAD_HEADER + nd * 9 + len(first) * (1 + m) + att.size, dtype=np.int64)
+    out[0], out[1], out[7] = nd, len(first), att.shape[0]
     err = payload.get("error")
     if err:
         out[2:7] = [int(err["status"]), int(err["kind"]), int(err["record"]), int(err["position"]), int(err["rank"])]
@@ -360,6 +375,7 @@ def encode_payload(payload: dict, m: int) -> np.ndarray:
         out[p] = c
         out[p + 1:p + 1 + m] = vals
         p += 1 + m
+    out[p:p + att.size] = att.reshape(-1)
     return out
 
 
@@ -374,10 +390,12 @@ def decode_payload(buf: np.ndarray, m: int) -> dict:
     for _ in range(nf):
         first_D[int(buf[p])] = [int(x) for x in buf[p + 1:p + 1 + m]]
         p += 1 + m
+    na = int(buf[7])
+    att = buf[p:p + 3 * na].reshape(na, 3).copy()
     err = None
     if int(buf[2]) != 0:
         err = dict(status=int(buf[2]), kind=int(buf[3]), record=int(buf[4]), position=int(buf[5]), rank=int(buf[6]))
-    return dict(dips=dips, last_min=last_min, first_D=first_D, error=err)
+    return dict(dips=dips, last_min=last_min, first_D=first_D, error=err, att=att)
 
 
 def gather_payloads(payload: dict, m: int, device=None, group=None) -> List[dict]:
@@ -397,6 +415,151 @@ def gather_payloads(payload: dict, m: int, device=None, group=None) -> List[dict
     bufs = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(bufs, buf, group=group)
     return [decode_payload(bufs[r][:int(sizes[r])].cpu().numpy(), m) for r in range(world)]
+
+
+def _gather_int64(enc: np.ndarray, device=None, group=None) -> List[np.ndarray]:
+    """Every rank's int64 block on every rank (sizes first, then one padded all_gather)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = device if device is not None else torch.device("cpu")
+    size = torch.tensor([enc.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size, group=group)
+    mx = max(max(int(x) for x in sizes), 1)
+    buf = torch.zeros(mx, dtype=torch.int64, device=dev)
+    if enc.size:
+        buf[:enc.size] = torch.from_numpy(np.ascontiguousarray(enc)).to(dev)
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    return [bufs[r][:int(sizes[r])].cpu().numpy() for r in range(world)]
+
+
+def _bcast_int64(enc: Optional[np.ndarray], src: int = 0, device=None, group=None) -> np.ndarray:
+    """Rank `src`'s int64 block on every rank (its size first)."""
+    import torch
+    import torch.distributed as dist
+    dev = device if device is not None else torch.device("cpu")
+    size = torch.tensor([0 if enc is None else int(enc.size)], dtype=torch.int64, device=dev)
+    dist.broadcast(size, src, group=group)
+    n = int(size)
+    buf = torch.zeros(max(n, 1), dtype=torch.int64, device=dev)
+    if enc is not None and n:
+        buf[:n] = torch.from_numpy(np.ascontiguousarray(enc)).to(dev)
+    dist.broadcast(buf, src, group=group)
+    return buf[:n].cpu().numpy()
+
+
+# ---- chain replay of a sharded scan (KGMA_F_CHAIN_REPLAY): the running Float64 value of a record is produced piece by piece
+#      where the residues are -- every rank runs the chain kernel over its slices of the record (kgma_chain_export; a slice
+#      stops one transition before the next begins), the pieces travel to rank 0 as int64 blocks, and rank 0 walks them in
+#      order, each piece starting on the value the previous one ended on (kgma_host_chain_walk) ------------------------
+def encode_chain_request(pairs) -> np.ndarray:
+    out = [len(pairs)]
+    for c, j, iv in pairs:
+        out += [c, j, len(iv)]
+        for a, b in iv:
+            out += [a, b]
+    return np.asarray(out, dtype=np.int64)
+
+
+def decode_chain_request(buf: np.ndarray):
+    pairs, p = [], 1
+    for _ in range(int(buf[0])):
+        c, j, n = int(buf[p]), int(buf[p + 1]), int(buf[p + 2])
+        p += 3
+        iv = [(int(buf[p + 2 * i]), int(buf[p + 2 * i + 1])) for i in range(n)]
+        p += 2 * n
+        pairs.append((c, j, iv))
+    return pairs
+
+
+def serve_chain_request(ctx, genome, my_slices, nwin_of, pairs) -> np.ndarray:
+    """This rank's pieces of the requested chains: for every pair and every slice of mine of that record, the chain kernel's
+    output over the slice's windows (local coordinates), as one int64 block:
+    [n_pieces | per piece: record, kfv, u, local_last, n_streams, n_chunks, n_pool, first (bits), status, win0.., n_valid..,
+     chunk_base.., D0.., chunks (2 words each), pool (2 words each)]."""
+    from . import _lib
+    pieces = []
+    for c, j, iv in pairs:
+        last_needed = iv[-1][1]
+        for i, (cc, u, v) in enumerate(my_slices):
+            if cc != c or genome is None:
+                continue
+            v_eff = v if v >= nwin_of[c] else v - 1              # a slice stops one transition before the next one begins
+            g_last = min(v_eff, last_needed)
+            if g_last <= u and u != 1:
+                continue
+            local_last = max(g_last - u + 1, 2)
+            if v - u + 1 < 2:
+                continue
+            hot = [(max(a, u + 1) - u + 1, min(b, g_last) - u + 1) for a, b in iv if min(b, g_last) >= max(a, u + 1)]
+            if not hot or hot[-1][1] < local_last:
+                hot.append((local_last, local_last))                # the value the next piece starts on
+            head = [c, j, u, local_last, 0, 0, 0, 0, 0]
+            try:
+                ex = ctx.chain_export(genome, i, j, local_last, hot)
+                head[4:8] = [ex["win0"].size, ex["chunks"].size, ex["pool"].size, int(np.float64(ex["first"]).view(np.int64))]
+                body = [ex["win0"].astype(np.int64), ex["n_valid"].astype(np.int64), ex["chunk_base"].astype(np.int64), ex["D0"].astype(np.int64),
+                        np.ascontiguousarray(ex["chunks"]).view(np.int64).reshape(-1), np.ascontiguousarray(ex["pool"]).view(np.int64).reshape(-1)]
+            except _lib.KgmaError as e:
+                head[8] = int(e.status) or 1
+                body = []
+            pieces.append(np.concatenate([np.asarray(head, dtype=np.int64)] + body))
+    return np.concatenate([np.asarray([len(pieces)], dtype=np.int64)] + pieces) if pieces else np.asarray([0], dtype=np.int64)
+
+
+def decode_chain_pieces(buf: np.ndarray) -> List[dict]:
+    from . import _lib
+    out, p = [], 1
+    for _ in range(int(buf[0])):
+        c, j, u, local_last, ns, nc, npool, fbits, status = (int(x) for x in buf[p:p + 9])
+        p += 9
+        d = dict(record=c, kfv=j, u=u, local_last=local_last, status=status)
+        if status == 0:
+            d["first"] = float(np.int64(fbits).view(np.float64))
+            d["win0"], d["n_valid"], d["chunk_base"], d["D0"] = (buf[p + t * ns:p + (t + 1) * ns].copy() for t in range(4))
+            p += 4 * ns
+            d["chunks"] = buf[p:p + 2 * nc].copy().view(_lib.CHAIN_CHUNK_DTYPE)
+            p += 2 * nc
+            d["pool"] = buf[p:p + 2 * npool].copy().view(_lib.CHAIN_CHUNK_DTYPE)
+            p += 2 * npool
+        out.append(d)
+    return out
+
+
+def walk_chain_pieces(ctx, pairs, pieces: List[dict], ws: Sequence[int]) -> List[np.ndarray]:
+    """Rank 0: the values at every pair's wanted windows, from the pieces of all ranks."""
+    from . import _lib
+    out = []
+    for c, j, iv in pairs:
+        mine = sorted((d for d in pieces if d["record"] == c and d["kfv"] == j), key=lambda d: d["u"])
+        if any(d["status"] for d in mine):
+            raise _lib.KgmaError(next(d["status"] for d in mine if d["status"]), f"a rank could not run the chain kernel for record {c} KFV {j}")
+        scale, nk = ctx.kfv_scale(j), int(ws[j - 1]) - ctx.k + 1
+        vals = {}
+        v, reached = None, 0                                       # value at global window `reached`
+        for d in mine:
+            u, ll = d["u"], d["local_last"]
+            if u == 1:
+                v, reached = d["first"], 1
+            if v is None or reached != u:
+                raise _lib.KgmaError(_lib.KGMA_E_STATE, f"chain pieces of record {c} KFV {j} do not join at window {u} (reached {reached})")
+            g_last = u + ll - 1
+            want = [(max(a, u + 1 if u > 1 else 1), min(b, g_last)) for a, b in iv]
+            want = [(a - u + 1, b - u + 1) for a, b in want if b >= a]
+            if not want or want[-1][1] < ll:
+                want.append((ll, ll))                              # the value the next piece starts on
+            got, _ = _lib.host_chain_walk(v, scale, nk, d["win0"], d["n_valid"], d["chunk_base"], d["D0"], d["chunks"], d["pool"], want)
+            q = 0
+            for a, b in want:
+                for w in range(a, b + 1):
+                    vals[w + u - 1] = got[q]
+                    q += 1
+            v, reached = vals[g_last], g_last
+        res = np.asarray([vals[w] for a, b in iv for w in range(a, b + 1)], dtype=np.float64)
+        out.append(res)
+    return out
 
 
 def merge_payloads(payloads: Sequence[dict], n_records: int, m: int):
@@ -480,29 +643,56 @@ def scan_sharded(ctx, records, mode: int, buff: int = 50, genome_pos: int = 0, f
     # a rank-local failure (a residue outside A/C/G/T/N in this rank's slices, a record shorter than k-1, a
     # record-buffer overflow) must not leave the other ranks blocked in the collective: it travels in the header of the
     # rank's block, the collective completes, and EVERY rank raises the first error in record order
+    chain = bool(flags & _lib.F_CHAIN_REPLAY) and not (flags & _lib.F_NO_TIE_RESOLVE)
+    genome = None
     try:
-        payload = local_scan(ctx, src, plan[rank], mode, flags)
+        payload = local_scan(ctx, src, plan[rank], mode, flags, keep_genome=chain)
+        genome = payload.pop("_genome", None)
         payload["error"] = None
     except _lib.KgmaError as e:
         payload = dict(slices=list(plan[rank]), dips=np.zeros(0, dtype=_lib.DIP_DTYPE), last_min=np.zeros(0, dtype=np.int64),
-                       first_D={}, error=_error_entry(e, plan[rank], src, mode_single, ws, ctx.k, rank))
-    gathered = gather_payloads(payload, m, device=device, group=group)
-    errors = sorted((p["error"] for p in gathered if p.get("error")), key=lambda t: (t["record"], t["position"], t["rank"]))
-    if errors:
-        e = errors[0]
-        if e["kind"] == 1:
-            raise _lib.BadBaseError(e["status"], f"record {e['record']} position {e['position']}: residue is not one of A/C/G/T/N "
-                                                 f"(KeyError, Consts.jl:22-28) [found by rank {e['rank']}]")
-        if e["kind"] == 2:
-            raise _lib.RecordBoundsError(e["status"], f"record {e['record']} has fewer than k-1 residues (BoundsError, "
-                                                      f"OmnGenomeMiner.jl:84-86) [found by rank {e['rank']}]")
-        raise _lib.KgmaError(e["status"], f"rank {e['rank']} failed while scanning its slices of record {e['record']}")
-    if rank != 0:
-        return []
-    dips, last_min, first_D = merge_payloads(gathered, len(lengths), m)
-    ctx.set_residue_source(lambda c, pos, n: src.fetch(c, pos - 1, pos - 1 + n))
+                       first_D={}, att=np.zeros((0, 3), dtype=np.int64), error=_error_entry(e, plan[rank], src, mode_single, ws, ctx.k, rank))
     try:
-        ctx.replay_dips(mode, buff, genome_pos, flags, lengths, first_D, dips, last_min, align)
+        gathered = gather_payloads(payload, m, device=device, group=group)
+        errors = sorted((p["error"] for p in gathered if p.get("error")), key=lambda t: (t["record"], t["position"], t["rank"]))
+        if errors:
+            e = errors[0]
+            if e["kind"] == 1:
+                raise _lib.BadBaseError(e["status"], f"record {e['record']} position {e['position']}: residue is not one of A/C/G/T/N "
+                                                     f"(KeyError, Consts.jl:22-28) [found by rank {e['rank']}]")
+            if e["kind"] == 2:
+                raise _lib.RecordBoundsError(e["status"], f"record {e['record']} has fewer than k-1 residues (BoundsError, "
+                                                          f"OmnGenomeMiner.jl:84-86) [found by rank {e['rank']}]")
+            raise _lib.KgmaError(e["status"], f"rank {e['rank']} failed while scanning its slices of record {e['record']}")
+        nwin_of = [record_windows(int(L), mode_single, ws, ctx.k) for L in lengths]
+        if rank != 0:
+            # serve rank 0's chain requests (none, or one per replay) until it says it is done
+            while chain:
+                req = _bcast_int64(None, 0, device=device, group=group)
+                if req.size == 0:
+                    break
+                _gather_int64(serve_chain_request(ctx, genome, plan[rank], nwin_of, decode_chain_request(req)), device=device, group=group)
+            return []
+        dips, last_min, first_D = merge_payloads(gathered, len(lengths), m)
+        ctx.set_residue_source(lambda c, pos, n: src.fetch(c, pos - 1, pos - 1 + n))
+        if chain:
+            att = np.concatenate([p["att"] for p in gathered]) if gathered else np.zeros((0, 3), dtype=np.int64)
+            ctx.set_att(np.unique(att, axis=0) if att.shape[0] else att)     # (a window shared by two slices is reported by both)
+
+            def source(pairs):
+                _bcast_int64(encode_chain_request(pairs), 0, device=device, group=group)
+                blocks = _gather_int64(serve_chain_request(ctx, genome, plan[0], nwin_of, pairs), device=device, group=group)
+                pieces = [d for b in blocks for d in decode_chain_pieces(b)]
+                return walk_chain_pieces(ctx, pairs, pieces, ws if not mode_single else [ctx.ws[0]])
+            ctx.set_chain_source(source)
+        try:
+            ctx.replay_dips(mode, buff, genome_pos, flags, lengths, first_D, dips, last_min, align)
+        finally:
+            ctx.set_residue_source(None)
+            if chain:
+                ctx.set_chain_source(None)
+                _bcast_int64(np.zeros(0, dtype=np.int64), 0, device=device, group=group)     # releases the other ranks
+        return ctx.hits()
     finally:
-        ctx.set_residue_source(None)
-    return ctx.hits()
+        if genome is not None:
+            genome.free()

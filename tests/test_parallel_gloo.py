@@ -261,3 +261,27 @@ def test_dip_exchange_world4_gloo():
     assert not any(d["exit_pos"] == 0 for d in merged)
     keys = [(int(d["contig"]), int(d["kfv"]), int(d["start"])) for d in merged]
     assert keys == sorted(keys)
+
+
+def test_chain_request_and_piece_blocks_round_trip():
+    """The int64 blocks of the sharded chain replay (parallel.scan_sharded with KGMA_F_CHAIN_REPLAY): requests rank 0
+    broadcasts, guard-band windows in the dip payload, and the pieces the ranks send back (streams, chunk records, pool)."""
+    from kmergma_amd import _lib
+    pairs = [(0, 1, [(1, 1), (130, 171)]), (2, 3, [(1, 1), (5, 5), (900, 1200)])]
+    assert parallel.decode_chain_request(parallel.encode_chain_request(pairs)) == pairs
+    pay = dict(slices=[(0, 1, 10)], dips=np.zeros(0, dtype=_lib.DIP_DTYPE), last_min=np.zeros(0, dtype=np.int64), first_D={0: [7, 8]},
+               att=np.array([[0, 1, 44], [0, 2, 45]], dtype=np.int64), error=None)
+    got = parallel.decode_payload(parallel.encode_payload(pay, 2), 2)
+    assert np.array_equal(got["att"], pay["att"]) and got["first_D"] == {0: [7, 8]}
+    # a piece block as serve_chain_request lays it out
+    chunks = np.zeros(3, dtype=_lib.CHAIN_CHUNK_DTYPE)
+    chunks["A0"] = [5, -7, 1 << 40]; chunks["info"] = [1 | (64 << 2), 2 | (3 << 2) | _lib.CHAIN_DETAIL, 1 | (1 << 2) | _lib.CHAIN_RAW]; chunks["raw"] = [0, 9, 41]
+    pool = np.zeros(34, dtype=_lib.CHAIN_CHUNK_DTYPE)
+    pool[2:34].view(np.float64)[:] = np.arange(64) * 0.125
+    head = np.asarray([2, 3, 4097, 500, 2, 3, 34, int(np.float64(36.5).view(np.int64)), 0], dtype=np.int64)
+    body = [np.asarray([1, 301]), np.asarray([301, 200]), np.asarray([0, 2]), np.asarray([111, 222]), chunks.view(np.int64).reshape(-1), pool.view(np.int64).reshape(-1)]
+    block = np.concatenate([np.asarray([1], dtype=np.int64), head] + [b.astype(np.int64) for b in body])
+    (d,) = parallel.decode_chain_pieces(block)
+    assert (d["record"], d["kfv"], d["u"], d["local_last"], d["first"]) == (2, 3, 4097, 500, 36.5)
+    assert np.array_equal(d["win0"], [1, 301]) and np.array_equal(d["D0"], [111, 222])
+    assert np.array_equal(d["chunks"], chunks) and np.array_equal(d["pool"], pool)
