@@ -2531,7 +2531,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
     info.chunks += n_chunks;
     const int64_t full_units = total_steps * 33 + n_chunks + 64;       // every step raw
     const int64_t hot_units = hot_steps * 32 + hot_chunks * KGMA_CHAIN_STEPS;
-    int64_t pool_units = hot_units + std::max<int64_t>(1 << 18, std::min<int64_t>(total_steps / 8, (int64_t)1 << 27));
+    int64_t pool_units = hot_units + std::max<int64_t>(1 << 18, std::min<int64_t>(total_steps / 8, (int64_t)1 << 28));
     if (ctx->cpool_per_step > 0)                                       // (what the previous scans of this context needed, with a margin)
         pool_units = std::max(pool_units, hot_units + (int64_t)(1.25 * ctx->cpool_per_step * (double)total_steps) + (1 << 16));
     if (const char *e = getenv("KGMA_CHAIN_POOL_UNITS")) pool_units = std::max<int64_t>(1, atoll(e));   // tests: force the regrowth

@@ -89,6 +89,22 @@ def main():
         times.append(time.perf_counter() - t1)
     st = ctx.stats()
     hits = ctx.hits_array()
+    chain = None
+    if world == 1:
+        # the same scan in chain mode (KGMA_F_CHAIN_REPLAY: what findGenes_cluster_mode's mirror runs): twice, the second
+        # with the context's buffers and pool estimate in place
+        for _ in range(2):
+            t1 = time.perf_counter()
+            ctx.scan(g, _lib.MODE_OMN, 100, genome_pos0, _lib.F_CHAIN_REPLAY, None)
+            dt = time.perf_counter() - t1
+            sc = ctx.stats()
+            chain = {"scan_wall_s": round(dt, 4), "chain_ms": round(sc["chain_ms"], 1), "chain_kernels_ms": round(sc["chain_device_ms"], 1),
+                     "record_kfv_pairs": int(sc["n_chain_pairs"]), "pairs_on_device": int(sc["chain_device_pairs"]),
+                     "windows_walked": int(sc["chain_windows"]), "raw_steps": int(sc["chain_raw_steps"]), "max_drift": sc["chain_max_drift"],
+                     "n_hits": int(sc["n_hits"]), "n_tie_flagged": int(sc["n_tie_flagged"])}
+        ctx.scan(g, _lib.MODE_OMN, 100, genome_pos0, 0, None)
+        st = ctx.stats()
+        hits = ctx.hits_array()
     kernel_s = st["scan_ms"] * 1e-3
     wall_s = min(times)
     bases = st["bases_scanned"]
@@ -136,6 +152,7 @@ def main():
         "pack_ms": round(st["pack_ms"], 2), "generate_and_pack_s": round(t_gen, 2),
         "n_hits": n_hits_total, "n_dips_rank0": int(st["n_dips"]), "planted": len(plants), "planted_found": found,
         "device_GB": round(st["device_bytes"] / 1e9, 1),
+        "chain_mode": chain,
     }
     print(json.dumps(out, indent=1))
     if args.out:
