@@ -2729,7 +2729,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
 // stale running minimum" (GenomeMiner.jl:93-103), which is only known once the hit state machine runs.
 // Every other pair has no exact tie anywhere, so exact arithmetic and the chain decide alike.
 // ------------------------------------------------------------------------------------------
-static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
+static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff)
 {
     const double t0 = now_ms();
     const int k = ctx->k, m = ctx->m;
@@ -2753,6 +2753,32 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
     // ---- select the pairs ------------------------------------------------------------------
     typedef ChainPair Pair;
     std::vector<Pair> pairs;
+    // (cluster engine) does the widest candidate range of a dip meet that of another dip of its record?
+    std::vector<char> dip_meets_other(ctx->dips.size(), 0);
+    if (mode == KGMA_MODE_OMN) {
+        struct Rg { int64_t lo, hi; size_t u; };
+        std::vector<Rg> rg;
+        size_t u0 = 0;
+        const size_t ndp = ctx->dips.size();
+        while (u0 < ndp) {
+            size_t u1 = u0;
+            rg.clear();
+            while (u1 < ndp && ctx->dips[u1].contig == ctx->dips[u0].contig) {
+                const kgma_dip &d = ctx->dips[u1];
+                const int64_t W = ctx->kfv[(size_t)(d.kfv - 1)].W;
+                rg.push_back(Rg{d.start - 1 - buff, d.end - 1 + W - 1 + buff, u1});     // CMI = best window - 1, anywhere in the dip
+                u1++;
+            }
+            std::sort(rg.begin(), rg.end(), [](const Rg &a, const Rg &b) { return a.lo < b.lo; });
+            int64_t reach = INT64_MIN;                                                 // farthest end among the ranges before
+            for (size_t i = 0; i < rg.size(); i++) {
+                if (reach >= rg[i].lo) dip_meets_other[rg[i].u] = 1;
+                if (i + 1 < rg.size() && rg[i + 1].lo <= rg[i].hi) dip_meets_other[rg[i].u] = 1;
+                reach = std::max(reach, rg[i].hi);
+            }
+            u0 = u1;
+        }
+    }
     {
         size_t di = 0, ai = 0;
         const size_t nd = ctx->dips.size(), na = ctx->att.size();
@@ -2791,10 +2817,19 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode)
                     if (CMI > goal_ind) { goal_ind = CMI + W - 1; currmin = d.D_exit; }
                 }
             } else if (!need) {
-                // cluster engine: whether a hit is emitted (and the running minimum reset) depends on the
-                // alignment callback (OmnGenomeMiner.jl:126,139,152): take the superset "two equal minima"
-                std::sort(mins.begin(), mins.end());
-                need = std::adjacent_find(mins.begin(), mins.end()) != mins.end();
+                // cluster engine: whether a hit is emitted (and the running minimum reset) depends on the alignment
+                // callback (OmnGenomeMiner.jl:126,139,152), so its state machine cannot be run ahead.  What can tie:
+                // a dip's minimum with the first window's value (curr_mins starts there, :73-74), or with the STALE
+                // minimum an earlier dip A of the same KFV left behind -- and a dip only leaves one when it is
+                // suppressed (:126 CMI in prev_hit_range, :139 aligned range not disjoint from it); the accepted hit's
+                // range is a sub-range of its candidate range max(CMI-buff,1) : CMI+ws-1+buff, so A can only be suppressed
+                // if its candidate range meets that of another dip of the record (any KFV).  Superset taken: equal minima
+                // A before B where A's widest possible candidate range meets another dip's.
+                for (size_t u = p.d0; u < p.d1 && !need; u++) need = ctx->dips[u].D_min == mins[0];
+                for (size_t u = p.d0; u < p.d1 && !need; u++) {
+                    if (!dip_meets_other[u]) continue;
+                    for (size_t v = u + 1; v < p.d1 && !need; v++) need = ctx->dips[v].D_min == ctx->dips[u].D_min;
+                }
             }
             if (need) pairs.push_back(std::move(p));
         }
@@ -3044,7 +3079,7 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
     if (rc) return rc;
     reset_chain_stats(ctx);
     if ((flags & KGMA_F_CHAIN_REPLAY) && !(flags & KGMA_F_NO_TIE_RESOLVE)) {
-        rc = chain_decide(ctx, g, mode);
+        rc = chain_decide(ctx, g, mode, buff);
         if (rc) return rc;
     }
     return replay_hits(ctx, g, mode, buff, genome_pos0, flags, align, align_user);
@@ -3221,7 +3256,7 @@ int kgma_scan_aligned(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t
     if (rc) return rc;
     reset_chain_stats(ctx);
     if ((flags & KGMA_F_CHAIN_REPLAY) && !(flags & KGMA_F_NO_TIE_RESOLVE)) {
-        rc = chain_decide(ctx, g, mode);
+        rc = chain_decide(ctx, g, mode, buff);
         if (rc) return rc;
     } else if (!(flags & KGMA_F_NO_TIE_RESOLVE)) {
         rc = kgma_resolve_ties_local(ctx, g);                          // the dips' best windows are final before they are aligned
@@ -3356,7 +3391,7 @@ int kgma_replay_dips(kgma_ctx *ctx, int32_t mode, int64_t buff, int64_t genome_p
     ctx->stats.n_dips = n_dips;
     reset_chain_stats(ctx);
     if ((flags & KGMA_F_CHAIN_REPLAY) && !(flags & KGMA_F_NO_TIE_RESOLVE) && ctx->chain_src) {
-        const int rc = chain_decide(ctx, nullptr, mode);
+        const int rc = chain_decide(ctx, nullptr, mode, buff);
         if (rc) return rc;
     }
     return replay_hits(ctx, nullptr, mode, buff, genome_pos0, flags, align, align_user);

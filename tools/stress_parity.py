@@ -40,8 +40,12 @@ def key(h):
     return (h["contig"], h["kfv"], h["cmi"], h["lo"], h["hi"], h["genome_pos"])
 
 
+KSET = None          # --k: restrict the k-mer lengths (e.g. 5,6,7: the ones the chain kernel serves)
+DEVICE_PAIRS = [0, 0]     # chain pairs walked on the device / in all
+
+
 def one_case(ctx, rng, case):
-    k = int(rng.integers(2, 11))
+    k = int(rng.integers(2, 11)) if not KSET else int(rng.choice(KSET))
     base_len = int(rng.choice([rng.integers(k + 2, 60), rng.integers(60, 400), rng.integers(400, 2030 + k)]))
     m = int(rng.choice([1, 1, 2, 3, 5, 8]))
     # reference sets: m clusters of mutated copies of related genes, lengths spread by up to +-6
@@ -55,6 +59,8 @@ def one_case(ctx, rng, case):
         RV, W, cons, (S, N) = refprep.gen_ref_ws_cons(recs, k, return_int=True)
         if W <= k or W - k + 1 > 2031:
             return None
+        if case % 3 == 1:
+            RV = np.asarray(S, dtype=np.float64) / float(N)      # the division form of cluster_ref_API (ReferenceGeneration.jl:118)
         KFVs.append(RV); ws.append(W); Ss.append(S); Ns.append(N); genes.append(g)
     # genome
     contigs = []
@@ -119,6 +125,7 @@ def one_case(ctx, rng, case):
         # chain replay: identical to the reference-order Float64 oracle, chain-decided hits carry its distance bit for bit
         assert [key(h) for h in hits_c] == [key(h) for h in ohf], "chain replay vs float oracle"
         assert st_c["n_tie_flagged"] == 0, "chain replay left a tie flagged"
+        DEVICE_PAIRS[0] += int(st_c["chain_device_pairs"]); DEVICE_PAIRS[1] += int(st_c["n_chain_pairs"])
         for a, b in zip(hits_c, ohf):
             if a["flags"] & _lib.HIT_CHAIN:
                 assert a["dist"] == b["dist"], "chain replay distance"
@@ -155,7 +162,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--k", default="", help="comma-separated k-mer lengths to draw from (default: 2 ... 10)")
     args = ap.parse_args()
+    global KSET
+    KSET = [int(x) for x in args.k.split(",")] if args.k else None
     ctx = _lib.Context(0)
     t0 = time.time()
     n = skipped = total_hits = amb = 0
@@ -175,7 +185,8 @@ def main():
         if n % 50 == 0:
             print(f"{n} cases ok ({skipped} skipped), {total_hits} hits, {amb} cases with flagged float differences, "
                   f"{time.time() - t0:.0f}s", flush=True)
-    print(f"DONE {n} cases ok, {skipped} skipped, {total_hits} hits compared, {amb} cases with flagged differences")
+    print(f"DONE {n} cases ok, {skipped} skipped, {total_hits} hits compared, {amb} cases with flagged differences; "
+          f"chain pairs: {DEVICE_PAIRS[1]}, {DEVICE_PAIRS[0]} of them walked on the device")
 
 
 if __name__ == "__main__":
