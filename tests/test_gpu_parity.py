@@ -969,3 +969,12 @@ def test_stream8_int32_s_tables(ctx, k):
     assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi] and len(ohi) > 0
     for j in range(2):
         assert np.array_equal(dists[j], oD[j] / (2.0 * k * N[j] ** 2))
+    # the chain kernel's int32-table variant: the reference's running Float64 value at every window, bit for bit
+    _, od = orc.single_scan([contigs[0]], KFVs[0], k, L, thr1, 50, return_dists=True)
+    ctx.set_refs(k, [KFVs[0]], [L], [thr1], [N[0]])
+    gen = ctx.genome_from_host([contigs[0]])
+    try:
+        assert np.array_equal(gen.chain_values(0, 1, [(2, len(contigs[0]) - L + 1)]), od)
+        assert np.array_equal(gen.chain_values(0, 1, [(100_000, 100_001)]), od[99_998:100_000])
+    finally:
+        gen.free()
