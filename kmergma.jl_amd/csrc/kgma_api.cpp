@@ -43,7 +43,7 @@ bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16);
 int stream8_variant(int n_kfv);
 hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
 bool chain_applies(int k, int nk, int64_t n_ref, bool s16);
-int chain_slots_per_cu(int k, bool s16);
+int chain_slots_per_cu(int k, bool s16, int nkfv);
 hipError_t launch_chain(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 int pos_tables_per_pass(int k);
 int64_t align_trace_bytes(int m, int n);
@@ -2396,7 +2396,7 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
         const KfvInfo &f = ctx->kfv[(size_t)p.j];
         const int nk = (int)(f.W - k + 1);
         if (!chain_applies(k, nk, f.N, f.Smax <= 32767) || f.ref_form < 0 || p.last < 2) continue;
-        if (chain_slots_per_cu(k, f.Smax <= 32767) < 1) continue;
+        if (chain_slots_per_cu(k, f.Smax <= 32767, 1) < 1) continue;
         el.push_back(i);
     }
     if (el.empty()) return KGMA_OK;
@@ -2421,58 +2421,126 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
     const int k = ctx->k;
     const int64_t NB = (int64_t)1 << (2 * k);
     const double ts0 = now_ms();
-    std::stable_sort(el.begin(), el.end(), [&](size_t a, size_t b) { return pairs[a].j < pairs[b].j; });
-
-    // transitions per stream, per launch (= per KFV): about three rounds of streams over the chip, 64 | T (streams start
-    // on plane words), at most 2^18 (the drift a stream may add stays far below the guard band)
-    struct Launch { int j; size_t t0, t1; int64_t T; };
-    struct PairStreams { size_t s0, s1; int64_t T; };
+    // ---- launch groups: the KFVs of one window size share the count table of a pass, so up to `maxg` of them that are
+    //      wanted on this batch CAN go into one launch (slots; a record's streams carry the mask of the slots it is flagged
+    //      for).  Measured, it does not pay: the flags are sparse (config 5: 268 of 800 (record, KFV) pairs, a record is
+    //      rarely wanted for two KFVs of one size), every slot costs its prefix sum in every step, and the 2-4 slot variants
+    //      spill 60-320 scalar registers -- config 4 (k = 6): chain kernels 16.0 ms with one KFV per launch, 18.8 ms with
+    //      two slots, 30.4 ms with four; a 20 Gb config-5 genome (k = 7): 145 ms against 191 ms with four slots.  So: one
+    //      KFV per launch; KGMA_CHAIN_GROUP=2..4 keeps the grouped form reachable for tests and for tie-dense inputs.
+    int maxg = 1;
+    if (const char *e = getenv("KGMA_CHAIN_GROUP")) maxg = std::max(1, std::min(4, atoi(e)));
+    struct Launch { std::vector<int> kfvs; size_t t0, t1; int64_t T, chunk0, n_chunks; size_t d0_off; bool s16; };
+    struct PairStreams { size_t s0, s1; int64_t T; };            // into `streams` (per pair: its slot's chunk and D0 indices)
     std::vector<TileDesc> tiles;
     std::vector<ChainStream> streams;
+    std::vector<size_t> stream_d0;                                // index of each stream's first-window D in the downloaded array
     std::vector<PairStreams> ps(el.size());
     std::vector<Launch> launches;
     int64_t n_chunks = 0, total_steps = 0;
-    for (size_t u0 = 0; u0 < el.size();) {
-        const int j = pairs[el[u0]].j;
-        size_t u1 = u0;
-        int64_t windows_j = 0;
-        while (u1 < el.size() && pairs[el[u1]].j == j) windows_j += pairs[el[u1++]].last;
-        const KfvInfo &f = ctx->kfv[(size_t)j];
-        const int nk = (int)(f.W - k + 1);
+    size_t d0_total = 0;
+    {
+        // KFVs wanted, by (k-mers per window, int16 tables)
+        std::vector<int> kf;
+        for (size_t u : el) kf.push_back(pairs[u].j);
+        std::sort(kf.begin(), kf.end());
+        kf.erase(std::unique(kf.begin(), kf.end()), kf.end());
+        std::stable_sort(kf.begin(), kf.end(), [&](int a, int b) {
+            const KfvInfo &fa = ctx->kfv[(size_t)a], &fb = ctx->kfv[(size_t)b];
+            if (fa.W != fb.W) return fa.W < fb.W;
+            return (fa.Smax <= 32767) > (fb.Smax <= 32767);
+        });
+        for (size_t i = 0; i < kf.size();) {
+            const KfvInfo &f0 = ctx->kfv[(size_t)kf[i]];
+            const bool s16 = f0.Smax <= 32767;
+            size_t e = i + 1;
+            while (e < kf.size() && (int)(e - i) < (s16 ? maxg : 1) && ctx->kfv[(size_t)kf[e]].W == f0.W && (ctx->kfv[(size_t)kf[e]].Smax <= 32767) == s16 &&
+                   chain_slots_per_cu(k, s16, (int)(e - i) + 1) > 0)
+                e++;
+            Launch L;
+            L.kfvs.assign(kf.begin() + (long)i, kf.begin() + (long)e);
+            L.s16 = s16; L.t0 = L.t1 = 0; L.T = 0; L.chunk0 = L.n_chunks = 0; L.d0_off = 0;
+            launches.push_back(L);
+            i = e;
+        }
+    }
+    for (Launch &L : launches) {
+        const int nslots = (int)L.kfvs.size();
+        const int nk = (int)(ctx->kfv[(size_t)L.kfvs[0]].W - k + 1);
+        // the records of this launch: per record the slots wanted and the last window any of them wants
+        struct Rec { int32_t c; uint32_t mask; int64_t last; };
+        std::vector<Rec> recs;
+        for (size_t u = 0; u < el.size(); u++) {
+            const ChainPair &p = pairs[el[u]];
+            const auto it = std::find(L.kfvs.begin(), L.kfvs.end(), p.j);
+            if (it == L.kfvs.end()) continue;
+            const uint32_t bit = 1u << (it - L.kfvs.begin());
+            auto r = std::find_if(recs.begin(), recs.end(), [&](const Rec &x) { return x.c == p.c; });
+            if (r == recs.end()) recs.push_back(Rec{p.c, bit, p.last});
+            else { r->mask |= bit; r->last = std::max(r->last, p.last); }
+        }
+        std::sort(recs.begin(), recs.end(), [](const Rec &a, const Rec &b) { return a.c < b.c; });
+        int64_t windows = 0;
+        for (const Rec &r : recs) windows += r.last;
+        // transitions per stream: about three rounds of streams over the chip, 64 | T (streams start on plane words), at most
+        // 2^18 (the drift a stream may add stays far below the guard band)
         int64_t T;
         {
-            const int64_t slots = (int64_t)std::max(1, ctx->n_cus) * chain_slots_per_cu(k, f.Smax <= 32767);
-            T = (windows_j + slots * 3 - 1) / (slots * 3);
+            const int64_t slots = (int64_t)std::max(1, ctx->n_cus) * chain_slots_per_cu(k, L.s16, nslots);
+            T = (windows + slots * 3 - 1) / (slots * 3);
             if (const char *e = getenv("KGMA_CHAIN_STREAM")) T = atoll(e);                     // experiments / tests
             T = std::min<int64_t>(std::max<int64_t>(((T + 63) / 64) * 64, 1024), (int64_t)1 << 18);
         }
-        launches.push_back(Launch{j, tiles.size(), tiles.size(), T});
-        for (size_t u = u0; u < u1; u++) {
-            const ChainPair &p = pairs[el[u]];
-            ps[u].s0 = streams.size();
-            ps[u].T = T;
-            for (int64_t win0 = 1; win0 < p.last; win0 += T) {
+        L.T = T;
+        L.t0 = tiles.size();
+        L.chunk0 = n_chunks;
+        int64_t local_chunks = 0;
+        std::vector<std::pair<size_t, size_t>> rec_tiles(recs.size());
+        for (size_t ri = 0; ri < recs.size(); ri++) {
+            const Rec &r = recs[ri];
+            rec_tiles[ri].first = tiles.size();
+            for (int64_t win0 = 1; win0 < r.last; win0 += T) {
                 TileDesc td;
-                td.word_base = g->cd[(size_t)p.c].word_off + (win0 - 1) / 32;
+                td.word_base = g->cd[(size_t)r.c].word_off + (win0 - 1) / 32;
                 td.win0 = win0;
-                td.dist_base = n_chunks;                               // (chain launches: the stream's first chunk)
-                td.n_valid = (int32_t)std::min<int64_t>(T + 1, p.last - win0 + 1);
-                td.first_test = 0;
-                td.contig = p.c;
+                td.dist_base = L.chunk0 + local_chunks;                // (chain launches: slot 0's chunk of the stream's first chunk)
+                td.n_valid = (int32_t)std::min<int64_t>(T + 1, r.last - win0 + 1);
+                td.first_test = (int32_t)r.mask;                       // (chain launches: the slots this record wants)
+                td.contig = r.c;
                 td.pad = 0;
                 tiles.push_back(td);
-                streams.push_back(ChainStream{win0, n_chunks, 0, td.n_valid, 0});
                 const int64_t nb = ((int64_t)td.n_valid + nk - 1 + 63) >> 6;
-                n_chunks += (nb + KGMA_CHAIN_STEPS - 1) / KGMA_CHAIN_STEPS;
-                total_steps += nb;
+                local_chunks += (nb + KGMA_CHAIN_STEPS - 1) / KGMA_CHAIN_STEPS;
+                total_steps += nb * __builtin_popcount(r.mask);
+            }
+            rec_tiles[ri].second = tiles.size();
+        }
+        L.t1 = tiles.size();
+        L.n_chunks = local_chunks;
+        n_chunks += local_chunks * nslots;
+        L.d0_off = d0_total;
+        d0_total += (size_t)ctx->m * (L.t1 - L.t0);                   // the kernel indexes first-window D by [KFV][stream of the launch]
+        // every pair's view of its record's streams: its own slot's chunk records and first-window D
+        for (size_t u = 0; u < el.size(); u++) {
+            const ChainPair &p = pairs[el[u]];
+            const auto it = std::find(L.kfvs.begin(), L.kfvs.end(), p.j);
+            if (it == L.kfvs.end()) continue;
+            const int64_t slot = it - L.kfvs.begin();
+            size_t ri = 0;
+            while (recs[ri].c != p.c) ri++;
+            ps[u].s0 = streams.size();
+            ps[u].T = T;
+            for (size_t t = rec_tiles[ri].first; t < rec_tiles[ri].second; t++) {
+                const TileDesc &td = tiles[t];
+                if (td.win0 >= p.last) break;                           // (the record's streams go on for another slot)
+                streams.push_back(ChainStream{td.win0, td.dist_base + slot * L.n_chunks, 0, td.n_valid, 0});
+                stream_d0.push_back(L.d0_off + (size_t)p.j * (L.t1 - L.t0) + (t - L.t0));
             }
             ps[u].s1 = streams.size();
         }
-        launches.back().t1 = tiles.size();
-        u0 = u1;
     }
     const int64_t n_tiles = (int64_t)tiles.size();
-    if (n_tiles > 0x7FFFFFF0ll || n_chunks > 0x7FFFFFF0ll) return KGMA_OK;   // (left to the host chain)
+    if (n_tiles > 0x7FFFFFF0ll || n_chunks > 0x7FFFFFF0ll || (int64_t)d0_total > 0x7FFFFFF0ll) return KGMA_OK;   // (left to the host chain)
 
     // hot steps: every step that holds a transition into a wanted window, as one 64-bit mask per chunk that has any
     const size_t hot_words = (size_t)(n_chunks + 31) / 32 + 1;
@@ -2520,7 +2588,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
     if (rc) return rc;
     rc = dev_reserve(ctx, ctx->d_chmask, ctx->chmask_cap, (int64_t)hot_masks.size());
     if (rc) return rc;
-    rc = dev_reserve(ctx, ctx->d_cD0, ctx->cD0_cap, n_tiles);
+    rc = dev_reserve(ctx, ctx->d_cD0, ctx->cD0_cap, (int64_t)d0_total);
     if (rc) return rc;
     if (!ctx->d_cctl) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_cctl), 16));
 
@@ -2552,30 +2620,40 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_cctl, 0, 16, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         for (const Launch &L : launches) {
-            const KfvInfo &f = ctx->kfv[(size_t)L.j];
+            const int nslots = (int)L.kfvs.size();
             GroupParams gp;
             memset(&gp, 0, sizeof gp);
             ScanArgs a;
             memset(&a, 0, sizeof a);
-            gp.n_kfv = 1; gp.k = k;
-            gp.nk = gp.nk_min = (int32_t)(f.W - k + 1);
-            gp.n_sizes = 1; gp.sizes[0] = gp.nk; gp.nk_of[0] = gp.nk;
-            gp.kfv_id[0] = 1;                                       // (table and D0 pointers below are this KFV's)
-            gp.N[0] = (int32_t)f.N;
-            gp.sumS2[0] = f.sumS2;
-            gp.inv_scale[0] = 2.0 * (double)k * (double)f.N * (double)f.N;
-            gp.s_fits_i16 = f.Smax <= 32767 ? 1 : 0;
+            gp.n_kfv = nslots; gp.k = k;
+            gp.nk = gp.nk_min = (int32_t)(ctx->kfv[(size_t)L.kfvs[0]].W - k + 1);
+            gp.n_sizes = 1; gp.sizes[0] = gp.nk;
+            gp.s_fits_i16 = L.s16 ? 1 : 0;
+            for (int u = 0; u < nslots; u++) {
+                const KfvInfo &f = ctx->kfv[(size_t)L.kfvs[(size_t)u]];
+                gp.nk_of[u] = gp.nk;
+                gp.kfv_id[u] = L.kfvs[(size_t)u] + 1;               // (the kernel finds the S table and the first-window slot by it)
+                gp.N[u] = (int32_t)f.N;
+                gp.sumS2[u] = f.sumS2;
+                gp.inv_scale[u] = 2.0 * (double)k * (double)f.N * (double)f.N;
+                gp.chain_invN[u] = 1.0 / (double)f.N;
+                gp.chain_form[u] = f.ref_form;
+            }
             a.inter = g->d_inter;
             a.tiles = ctx->d_ctiles + L.t0;
             a.n_tiles = (int32_t)(L.t1 - L.t0);
-            a.Stab = ctx->d_Stab + (size_t)L.j * (size_t)NB;
+            a.Stab = ctx->d_Stab;
             if (k >= 7) {
-                // k = 7: the kernel gathers S from global memory, one int16 per k-mer (the scan's interleaved layout with one slot)
-                std::vector<int> key{L.j, -1};
+                // k = 7: the kernel gathers S from global memory, one row of int16 slots per k-mer (the scan's interleaved layout)
+                const int nv = nslots == 3 ? 4 : nslots;               // row width in int16 slots (the kernel variant's)
+                std::vector<int> key = L.kfvs;
+                key.push_back(-nv);
                 auto it = ctx->sinter.find(key);
                 if (it == ctx->sinter.end()) {
-                    std::vector<int16_t> tab((size_t)NB, 0);
-                    for (int64_t v = 0; v < NB; v++) tab[(size_t)device_index_of((uint32_t)v, k)] = (int16_t)f.S[(size_t)v];
+                    std::vector<int16_t> tab((size_t)NB * (size_t)nv, 0);
+                    for (int u = 0; u < nslots; u++)
+                        for (int64_t v = 0; v < NB; v++)
+                            tab[(size_t)device_index_of((uint32_t)v, k) * (size_t)nv + (size_t)u] = (int16_t)ctx->kfv[(size_t)L.kfvs[(size_t)u]].S[(size_t)v];
                     int16_t *d = nullptr;
                     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d), tab.size() * sizeof(int16_t)));
                     HIP_TRY(ctx, hipMemcpy(d, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice));
@@ -2583,7 +2661,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
                 }
                 a.Sinter = it->second;
             }
-            a.D0out = ctx->d_cD0 + L.t0;
+            a.D0out = ctx->d_cD0 + L.d0_off;                       // [KFV][stream of this launch]
             a.n_chunk_tiles = a.n_tiles;
             a.chain.chunks = ctx->d_cchunks;
             a.chain.pool = ctx->d_cpool;
@@ -2592,9 +2670,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
             a.chain.hot = ctx->d_chot;
             a.chain.hot_prefix = ctx->d_chot + hot_words;
             a.chain.hot_masks = ctx->d_chmask;
-            a.chain.invN = 1.0 / (double)f.N;
-            a.chain.Nd = (double)f.N;
-            a.chain.form = f.ref_form;
+            a.chain.chunk_stride = L.n_chunks;
             a.chain.SF = 1.0 / (double)k;                           // src/API.jl:86,204
             a.chain.guard = 1.862645149230957e-09;                  // 2^-29
             a.chain.status = ctx->d_cctl + 1;
@@ -2629,7 +2705,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
         else it->dw = std::max(it->dw, dw);
     }
     for (Rec &r : recs) { r.dw_off = first_dw; first_dw += r.dw + 2; }
-    const size_t off_D0 = 0, off_chunks = off_D0 + (size_t)n_tiles * 8, off_raw = off_chunks + (size_t)n_chunks * sizeof(ChainChunk),
+    const size_t off_D0 = 0, off_chunks = off_D0 + d0_total * 8, off_raw = off_chunks + (size_t)n_chunks * sizeof(ChainChunk),
                  off_first = off_raw + (size_t)pool_units * sizeof(ChainChunk), pin_need = off_first + first_dw * 4 + 64;
     if (pin_need > ctx->cpin_cap) {
         if (ctx->h_cpin) (void)hipHostFree(ctx->h_cpin);
@@ -2638,7 +2714,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
         if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_cpin), cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return KGMA_OK; }
         ctx->cpin_cap = cap;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_D0, ctx->d_cD0, (size_t)n_tiles * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_D0, ctx->d_cD0, d0_total * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_chunks, ctx->d_cchunks, (size_t)n_chunks * sizeof(ChainChunk), hipMemcpyDeviceToHost, ctx->stream));
     if (pool_units > 0)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_raw, ctx->d_cpool, (size_t)pool_units * sizeof(ChainChunk), hipMemcpyDeviceToHost, ctx->stream));
@@ -2648,7 +2724,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
     const double tw0 = now_ms();
     info.copy_ms += tw0 - tc0;
     const int64_t *h_D0 = reinterpret_cast<const int64_t *>(ctx->h_cpin + off_D0);
-    for (int64_t t = 0; t < n_tiles; t++) streams[(size_t)t].D0 = h_D0[t];
+    for (size_t t = 0; t < streams.size(); t++) streams[t].D0 = h_D0[stream_d0[t]];
 
     // the chain's value at window 1: kmer_count! + sqeuclidean of the first window (GenomeMiner.jl:42-47), on the host
     std::vector<double> first(el.size(), 0.0);
@@ -3462,7 +3538,7 @@ int kgma_chain_export(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int32
         if (src) return src;
     }
     const int k = ctx->k;
-    if (!chain_applies(k, (int)(f.W - k + 1), f.N, f.Smax <= 32767) || f.ref_form < 0 || chain_slots_per_cu(k, f.Smax <= 32767) < 1)
+    if (!chain_applies(k, (int)(f.W - k + 1), f.N, f.Smax <= 32767) || f.ref_form < 0 || chain_slots_per_cu(k, f.Smax <= 32767, 1) < 1)
         return fail(ctx, KGMA_E_UNSUPPORTED, "the chain kernel does not serve this KFV");
     std::vector<char> done(1, 0);
     ChainDevInfo info;

@@ -53,6 +53,11 @@ struct GroupParams {
     int64_t T_hi[KGMA_MAX_GROUP];        // T <= D <= T_hi: at threshold (ATT records); T_hi < T: no band
     int64_t sumS2[KGMA_MAX_GROUP];       // sum_x S[x]^2
     double inv_scale[KGMA_MAX_GROUP];    // 2 k N^2 as a double (distance = D / that)
+    // chain launches (kgma_device.h: ChainArgs), per KFV slot:
+    double chain_invN[4];                // RN(1 / N)
+    int32_t chain_form[4];               // how the KFV's Float64 entries follow from S (checked entry by entry on the host):
+                                         // 0: RN(S * invN) -- `answer .* (1/N)`, src/ReferenceGeneration.jl:35,40;
+                                         // 1: RN(S / N) -- `KFVs[i] ./= lens[i]`, src/ReferenceGeneration.jl:118
 };
 
 // Device record kinds.
@@ -109,12 +114,7 @@ struct ChainArgs {
     const uint32_t *hot;          // one bit per chunk: it has hot steps
     const uint32_t *hot_prefix;   // per word of `hot`: hot chunks before it
     const uint64_t *hot_masks;    // per hot chunk, in chunk order: its hot steps
-    double invN;                  // RN(1 / N)
-    double Nd;                    // N
-    int32_t form;                 // how the KFV's Float64 entries follow from S (checked entry by entry on the host):
-                                  // 0: RN(S * invN) -- `answer .* (1/N)`, src/ReferenceGeneration.jl:35,40;
-                                  // 1: RN(S / N) -- `KFVs[i] ./= lens[i]`, src/ReferenceGeneration.jl:118
-    int32_t pad;
+    int64_t chunk_stride;         // chunk records of KFV slot j of the launch: chunks[first chunk + j * chunk_stride] (hot bits alike)
     double SF;                    // ScaleFactor = 1 / k (src/API.jl:86,204)
     double guard;                 // relative guard band around the powers of two (2^-29)
     unsigned int *status;         // bit 0: the pool ran out

@@ -533,11 +533,11 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 #endif
 
 template <int K, bool S16, int NKFV, int ND = 0, bool CHAIN = false>
-__global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN_WAVES : 8) : (NKFV <= 4 ? 6 : 4))) void stream8_kernel(ScanArgs a, GroupParams gp)
+__global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN_WAVES : 8) : (CHAIN ? 4 : (NKFV <= 4 ? 6 : 4)))) void stream8_kernel(ScanArgs a, GroupParams gp)
 {
     // CHAIN: the same walk, but instead of testing thresholds the wave reproduces the reference's running Float64
     // value (kgma_device.h, ChainArgs): one KFV, no dips, no records -- chunk translations and raw increments.
-    static_assert(!CHAIN || (NKFV == 1 && ND == 0), "the chain variant walks one KFV");
+    static_assert(!CHAIN || (NKFV <= 4 && ND == 0), "the chain variant walks 1-4 KFVs of one window size");
     constexpr bool DERIVE = ND > 0;                                   // the LAST ND KFVs of the launch have a window one k-mer longer
     static_assert(!DERIVE || (NKFV >= 2 && NKFV <= 4 && ND < NKFV && S16), "derived windows: 2-4 KFVs with int16 S tables");
     // k = 7: a wave's table is 16 KiB, so the LDS holds 10 of them and nothing else; the S tables stay in global memory,
@@ -658,128 +658,146 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
     const uint32_t kbase = KBASED ? cbase : 0u;
     const uint32_t sbase = (uint32_t)uni((int)(uint32_t)(uintptr_t)(lds_u32 *)smem);   // LDS byte offset of the S tables (0: the kernel has no static LDS)
 
-    // ---- CHAIN state (wave-uniform except c_acc) ---------------------------------------------------------------
-    int64_t c_acc = 0;                                                // per lane: ulps its windows added in the current regular run (even-parity a's)
-    int32_t c_corr = 0, c_dA = 0;                                     // tie corrections for an even incoming value; A1 - A0
-    uint32_t c_P = 0;                                                 // parity of the running value (for an even incoming value)
+    // ---- CHAIN state, per KFV slot of the launch (wave-uniform except c_acc) ---------------------------------------
+    int64_t c_acc[NKFV];                                              // per lane: ulps its windows added in the current regular run (even-parity a's)
+    int32_t c_corr[NKFV], c_dA[NKFV];                                 // tie corrections for an even incoming value; A1 - A0
+    uint32_t c_P[NKFV];                                               // parity of the running value (for an even incoming value)
     // (flags kept in ONE integer that is read through readfirstlane where it steers the step: the compiler then branches
     //  on the scalar unit instead of masking lanes)
     constexpr int CS_SPLIT = 1, CS_DETAIL = 2, CS_FULL = 4;           // split: no tie yet in this run (an odd incoming value has the other parity);
-    int c_state = CS_SPLIT;                                           // detail: this chunk has a raw step, its runs go out as entries; full: the pool ran out
-    uint32_t c_ent = 0;                                               // pool unit of the next entry of a detailed chunk
-    int c_run_b0 = 0, c_chunk_b0 = 0;                                 // first step of the current regular run, of the chunk
-    int64_t c_gid = 0;
-    uint64_t c_hot = 0;                                               // steps of this chunk that hold a wanted window
-    int32_t c_Elo = 0x7FFFFFFF, c_Ehi = -0x7FFFFFFF - 1;              // E range (stream-relative) that stays inside the binade, guard band
+    int c_state[NKFV];                                                // detail: this chunk has a raw step, its runs go out as entries; full: the pool ran out
+    uint32_t c_ent[NKFV];                                             // pool unit of the next entry of a detailed chunk
+    int c_run_b0[NKFV];                                               // first step of the current regular run
+    int c_chunk_b0 = 0;                                               // ... of the chunk
+    int64_t c_gid[NKFV];
+    uint64_t c_hot[NKFV];                                             // steps of this chunk that hold a wanted window
+    int32_t c_Elo[NKFV], c_Ehi[NKFV];                                 // E range (stream-relative) that stays inside the binade, guard band
                                                                       // off; empty (lo > hi): no binade is known to hold
-    uint32_t c_XLhi = 0;                                              // high dword of 2^e
+    uint32_t c_XLhi[NKFV];                                            // high dword of 2^e
+#pragma unroll
+    for (int j = 0; j < NKFV; j++) {
+        c_acc[j] = 0; c_corr[j] = 0; c_dA[j] = 0; c_P[j] = 0; c_state[j] = CS_SPLIT; c_ent[j] = 0; c_run_b0[j] = 0; c_gid[j] = 0; c_hot[j] = 0;
+        c_Elo[j] = 0x7FFFFFFF; c_Ehi[j] = -0x7FFFFFFF - 1; c_XLhi[j] = 0;
+    }
+    // the slots whose chain this record needs (several KFVs of one window size share the count table of a launch; a record
+    // may be flagged for some of them only: the stream carries the slots' mask in TileDesc::first_test)
+    const uint32_t c_active = CHAIN && NKFV > 1 ? (uint32_t)uni((int)td.first_test) : 1u;
     // binade of the exact distance D / (2kN^2), with the E range in which the reference's value provably shares it
-    auto chain_binade = [&](const int64_t D) {
-        c_Elo = 0x7FFFFFFF; c_Ehi = -0x7FFFFFFF - 1;
+    auto chain_binade = [&](const int j, const int64_t D) __attribute__((always_inline)) {
+        c_Elo[j] = 0x7FFFFFFF; c_Ehi[j] = -0x7FFFFFFF - 1;
         if (D <= 0) return;
-        const double scale = gpp->inv_scale[0];                       // 2kN^2 (an integer)
+        const double scale = gpp->inv_scale[j];                       // 2kN^2 (an integer)
         const double Dd = (double)D;
         const int e = ilogb(Dd / scale);
         const double g = a.chain.guard;
         const double lo = ldexp(scale, e) * (1.0 + g), hi = ldexp(scale, e + 1) * (1.0 - g);
         if (!(Dd > lo && Dd < hi) || e < -900 || e > 900) return;
-        const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st_reg[ST_D0HI]) << 32) | (uint32_t)uni(st_reg[ST_D0LO]));
-        const double twoN = 2.0 * (double)gpp->N[0];
+        const int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
+        const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
+        const double twoN = 2.0 * (double)gpp->N[j];
         double el = ceil((lo - (double)D0) / twoN), eh = floor((hi - (double)D0) / twoN);
         el = el < -1073741824.0 ? -1073741824.0 : el;
         eh = eh > 1073741824.0 ? 1073741824.0 : eh;
         if (!(el <= eh)) return;
-        c_Elo = uni((int32_t)el); c_Ehi = uni((int32_t)eh);
-        c_XLhi = (uint32_t)uni((int32_t)((uint32_t)(e + 1023) << 20));
+        c_Elo[j] = uni((int32_t)el); c_Ehi[j] = uni((int32_t)eh);
+        c_XLhi[j] = (uint32_t)uni((int32_t)((uint32_t)(e + 1023) << 20));
     };
     // n units of the pool (16 bytes each); past its end nothing is written and the launch is repeated with a larger one
-    auto pool_alloc = [&](const unsigned int n) -> uint32_t {
+    auto pool_alloc = [&](const int j, const unsigned int n) __attribute__((always_inline)) -> uint32_t {
         unsigned int base = 0;
         if (lane == 0) base = atomicAdd(a.chain.pool_cursor, n);
         base = (unsigned int)uni((int)base);
         if ((uint64_t)base + (uint64_t)n > (uint64_t)a.chain.pool_cap) {
             if (lane == 0) atomicOr(a.chain.status, 1u);
-            c_state = uni(c_state | CS_FULL);
+            c_state[j] = uni(c_state[j] | CS_FULL);
         }
         return base;
     };
-    auto run_reset = [&](const int b_next) {
-        c_acc = 0; c_corr = 0; c_dA = 0; c_P = 0;
-        c_state = uni((c_state & ~CS_SPLIT) | CS_SPLIT);
-        c_run_b0 = b_next;
+    auto run_reset = [&](const int j, const int b_next) __attribute__((always_inline)) {
+        c_acc[j] = 0; c_corr[j] = 0; c_dA[j] = 0; c_P[j] = 0;
+        c_state[j] = uni((c_state[j] & ~CS_SPLIT) | CS_SPLIT);
+        c_run_b0[j] = b_next;
     };
     // closes the regular run [c_run_b0, b_end): the chunk's own record while it has no raw step, an entry afterwards
-    auto close_run = [&](const int b_end, const bool to_detail) {
-        const int n = b_end - c_run_b0;
-        const int st = uni(c_state);
+    auto close_run = [&](const int j, const int b_end, const bool to_detail) __attribute__((always_inline)) {
+        const int n = b_end - c_run_b0[j];
+        const int st = uni(c_state[j]);
         if (!(st & CS_DETAIL)) {
-            const int64_t total = wave_sum_i64(c_acc) + (int64_t)c_corr;
+            const int64_t total = wave_sum_i64(c_acc[j]) + (int64_t)c_corr[j];
             uint32_t base = 0;
             if (to_detail) {
                 int left = n_blocks - c_chunk_b0;                     // one entry per remaining step at most
                 left = (left > KGMA_CHAIN_STEPS ? KGMA_CHAIN_STEPS : left) - n;
-                base = pool_alloc((unsigned int)left);
-                c_ent = base;
-                c_state = uni(c_state | CS_DETAIL);
+                base = pool_alloc(j, (unsigned int)left);
+                c_ent[j] = base;
+                c_state[j] = uni(c_state[j] | CS_DETAIL);
             }
             if (lane == 0) {
                 ChainChunk cc;
                 cc.A0 = total;
-                cc.info = (uint32_t)(c_dA + 1) | ((uint32_t)n << 2) | (to_detail ? KGMA_CHAIN_DETAIL : 0u);
+                cc.info = (uint32_t)(c_dA[j] + 1) | ((uint32_t)n << 2) | (to_detail ? KGMA_CHAIN_DETAIL : 0u);
                 cc.raw = base;
-                a.chain.chunks[c_gid] = cc;
+                a.chain.chunks[c_gid[j]] = cc;
             }
         } else if (n > 0) {
-            const int64_t total = wave_sum_i64(c_acc) + (int64_t)c_corr;
+            const int64_t total = wave_sum_i64(c_acc[j]) + (int64_t)c_corr[j];
             if (lane == 0 && !(st & CS_FULL)) {
                 ChainChunk cc;
                 cc.A0 = total;
-                cc.info = (uint32_t)(c_dA + 1) | ((uint32_t)n << 2);
+                cc.info = (uint32_t)(c_dA[j] + 1) | ((uint32_t)n << 2);
                 cc.raw = 0;
-                a.chain.pool[c_ent] = cc;
+                a.chain.pool[c_ent[j]] = cc;
             }
-            c_ent += 1;
+            c_ent[j] += 1;
         }
     };
     // step b goes out as raw increments (it holds a wanted window, or a window of it may leave the binade)
-    auto raw_step = [&](const int b, const double inc) {
-        close_run(b, true);
-        const uint32_t slot = pool_alloc(32);                          // 64 doubles
-        if (!(uni(c_state) & CS_FULL)) {
+    auto raw_step = [&](const int j, const int b, const double inc) __attribute__((always_inline)) {
+        close_run(j, b, true);
+        const uint32_t slot = pool_alloc(j, 32);                       // 64 doubles
+        if (!(uni(c_state[j]) & CS_FULL)) {
             if (lane == 0) {
                 ChainChunk cc;
                 cc.A0 = 0;
                 cc.info = 1u | (1u << 2) | KGMA_CHAIN_RAW;
                 cc.raw = slot;
-                a.chain.pool[c_ent] = cc;
+                a.chain.pool[c_ent[j]] = cc;
             }
             reinterpret_cast<double *>(a.chain.pool)[(size_t)slot * 2 + (size_t)lane] = inc;
         }
-        c_ent += 1;
-        run_reset(b + 1);
-        c_Elo = 0x7FFFFFFF; c_Ehi = -0x7FFFFFFF - 1;                  // the binade is looked up again at the next step
+        c_ent[j] += 1;
+        run_reset(j, b + 1);
+        c_Elo[j] = 0x7FFFFFFF; c_Ehi[j] = -0x7FFFFFFF - 1;            // the binade is looked up again at the next step
     };
-    auto chain_begin = [&](const int b) {
+    auto chain_begin = [&](const int b) __attribute__((always_inline)) {
         c_chunk_b0 = b;
-        c_state = uni(c_state & CS_FULL);
-        run_reset(b);
-        c_gid = td.dist_base + (b >> KGMA_CHAIN_STEPS_LOG2);
-        const uint32_t hw = (uint32_t)uni((int)a.chain.hot[c_gid >> 5]);
-        c_hot = 0;
-        if ((hw >> (c_gid & 31)) & 1u) {
-            const uint32_t ord = (uint32_t)uni((int)a.chain.hot_prefix[c_gid >> 5]) + (uint32_t)__builtin_popcount(hw & ((1u << (c_gid & 31)) - 1u));
-            const uint64_t m = a.chain.hot_masks[ord];
-            c_hot = ((uint64_t)(uint32_t)uni((int)(uint32_t)(m >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)m);
+#pragma unroll
+        for (int j = 0; j < NKFV; j++) {
+            if (!((c_active >> j) & 1u)) continue;
+            c_state[j] = uni(c_state[j] & CS_FULL);
+            run_reset(j, b);
+            c_gid[j] = td.dist_base + (b >> KGMA_CHAIN_STEPS_LOG2) + (int64_t)j * a.chain.chunk_stride;
+            const uint32_t hw = (uint32_t)uni((int)a.chain.hot[c_gid[j] >> 5]);
+            c_hot[j] = 0;
+            if ((hw >> (c_gid[j] & 31)) & 1u) {
+                const uint32_t ord = (uint32_t)uni((int)a.chain.hot_prefix[c_gid[j] >> 5]) + (uint32_t)__builtin_popcount(hw & ((1u << (c_gid[j] & 31)) - 1u));
+                const uint64_t m = a.chain.hot_masks[ord];
+                c_hot[j] = ((uint64_t)(uint32_t)uni((int)(uint32_t)(m >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)m);
+            }
         }
     };
-    auto chain_end = [&](const int b) { close_run(b + 1, false); };
+    auto chain_end = [&](const int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NKFV; j++)
+            if ((c_active >> j) & 1u) close_run(j, b + 1, false);
+    };
 
     // the stream's first window of KFV j has distance D0: thresholds in E units
     auto set_first_window = [&](const int j, int32_t *st, const int64_t D0) {
         const int64_t twoN = 2 * (int64_t)gpp->N[j];
         st[ST_D0LO] = (int32_t)(uint32_t)D0;
         st[ST_D0HI] = (int32_t)(uint32_t)((uint64_t)D0 >> 32);
-        if constexpr (CHAIN) { chain_binade(D0); return; }
+        if constexpr (CHAIN) { if ((c_active >> j) & 1u) chain_binade(j, D0); return; }
         // E_q < TE  <=>  D0 + 2N E_q < T; windows with TE <= E_q < TE + natt are at threshold
         const int64_t Tj = gpp->T[j], Thj = gpp->T_hi[j];
         const int64_t num = Tj - D0;
@@ -1030,83 +1048,93 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
 #pragma unroll
         for (int j = 0; j < NKFV; j++) asm volatile("" : "+v"(sc[j]));   // (the last stage stays one DPP add; the carry is one more add)
         if constexpr (CHAIN) {
-            // ---- the reference's Float64 update of this lane's window (GenomeMiner.jl:70-72, same operation order) ----
-            const int32_t carry_prev = h_carry[0];
-            const int32_t Ecur = sc[0] + carry_prev;                  // (D - D0) / 2N after this lane's transition
-            h_carry[0] = __builtin_amdgcn_readlane(Ecur, 63);
+            // ---- the reference's Float64 update of this lane's window (GenomeMiner.jl:70-72, same operation order), for every
+            //      KFV slot this record needs ---------------------------------------------------------------------------
             uint64_t ACT = AE;                                        // lanes whose transition belongs to this stream
             bool act = differ;
             if constexpr (GENERIC) { act = actL && p - nk + 1 < n_valid; ACT = __ballot(act); }
-            double inc = 0.0;
-            if (ACT != 0) {
-                // (plain operators: this file is compiled with fp contract off, see the pragma at its top -- the __dmul_rn /
-                //  __dadd_rn helpers of the HIP headers carry their own contraction flags and DO fuse)
-                double rl = (double)(uint32_t)Sl[0] * a.chain.invN;   // refVec[left] as RN(S * (1/N))
-                double rr = (double)(uint32_t)Sr[0] * a.chain.invN;   // refVec[right]
-                if (uni(a.chain.form) != 0) {
-                    asm volatile("");                                 // (a real branch: not both forms and a select)
-                    // ... as RN(S / N): the product above is within an ulp of the quotient, its residual S - q N is exact
-                    // in one fused multiply-add, and q + residual * RN(1/N) then rounds to the correctly rounded quotient
-                    // (Markstein's division step; the host has checked the KFV's entries against exactly this sequence)
-                    const double el = __builtin_fma(-rl, a.chain.Nd, (double)(uint32_t)Sl[0]);
-                    const double er = __builtin_fma(-rr, a.chain.Nd, (double)(uint32_t)Sr[0]);
-                    rl = __builtin_fma(el, a.chain.invN, rl);
-                    rr = __builtin_fma(er, a.chain.invN, rr);
-                }
-                double t = (double)(1 + cP);                          // 1 + curr_kmer_freq[right]: integer
-                t = t + rl;
-                t = t - rr;
-                t = t - (double)cS;                                   // - curr_kmer_freq[left]
-                inc = a.chain.SF * t;
-                inc = act ? inc : 0.0;
-            }
-            // hot step (the host wants a window of it): raw.  Otherwise every value of the step must stay inside the
-            // binade (E of a lane without a transition is its lower neighbour's); where no binade is known to hold (after
-            // a raw step, at a stream's start) it is looked up from the value the step starts on
-            bool raw = ((c_hot >> (b & (KGMA_CHAIN_STEPS - 1))) & 1u) != 0;
-            if (!raw && ACT != 0) {
-                if (uni((int)(c_Elo > c_Ehi)) && (b << 6) >= nk) {
-                    const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st_reg[ST_D0HI]) << 32) | (uint32_t)uni(st_reg[ST_D0LO]));
-                    chain_binade(D0 + 2 * (int64_t)gpp->N[0] * (int64_t)carry_prev);
-                }
-                const uint64_t inl = __builtin_amdgcn_sicmp(Ecur, c_Elo, 39 /* sge */) & __builtin_amdgcn_sicmp(Ecur, c_Ehi, 41 /* sle */);
-                raw = (inl | ~ACT) != ~(uint64_t)0;
-            }
-            if (raw) {
-                raw_step(b, inc);
-            } else if (ACT != 0) {
-                // RN(v + inc) for an even and an odd v of this binade, as hardware additions: anchors at the end of the
-                // binade the increment moves away from (2^e, or 2^(e+1) - 2 ulp), so that the sums stay inside
-                const uint64_t ib = (uint64_t)__double_as_longlong(inc);
-                const bool neg = (int32_t)(uint32_t)(ib >> 32) < 0;
-                const uint32_t x0hi = neg ? (c_XLhi | 0xFFFFFu) : c_XLhi;
-                const uint32_t x0lo = neg ? 0xFFFFFFFEu : 0u;
-                const uint64_t x0b = ((uint64_t)x0hi << 32) | x0lo;
-                const double R0 = __longlong_as_double((long long)x0b) + inc;
-                const double R1 = __longlong_as_double((long long)(x0b | 1u)) + inc;
-                const uint64_t r0b = (uint64_t)__double_as_longlong(R0), r1b = (uint64_t)__double_as_longlong(R1);
-                const int64_t av = (int64_t)(r0b - x0b);              // ulps added to an even value
-                const int32_t delta = (int32_t)((uint32_t)r1b - (uint32_t)r0b) - 1;   // ... to an odd value: av + delta (a tie: +-1)
-                c_acc += av;
-                const uint64_t T = __builtin_amdgcn_uicmp((uint32_t)delta, 0u, 33 /* ne */);
-                uint64_t O = __builtin_amdgcn_uicmp((uint32_t)av & 1u, 0u, 33 /* ne */) & ~T;
-                // parity of the running value, lane by lane: it flips at odd a's and is EVEN after a tie
-                if (__builtin_expect(T != 0, 0)) {
-                    uint64_t Trem = T;
-                    while (Trem != 0) {
-                        const int u = __builtin_ctzll(Trem);
-                        const uint64_t below = ((uint64_t)1 << u) - 1;
-                        c_P ^= (uint32_t)__builtin_popcountll(O & below) & 1u;
-                        const int32_t du = __builtin_amdgcn_readlane(delta, u);
-                        const int32_t c0 = c_P ? du : 0;
-                        if (uni(c_state) & CS_SPLIT) { c_dA = (c_P ? 0 : du) - c0; c_state = uni(c_state & ~CS_SPLIT); }
-                        c_corr += c0;
-                        c_P = 0;
-                        O &= ~below;
-                        Trem &= Trem - 1;
+            double tc = 0.0, tl = 0.0;
+            if (ACT != 0) { tc = (double)(1 + cP); tl = (double)cS; }  // 1 + curr_kmer_freq[right] (integer), curr_kmer_freq[left]
+#pragma unroll
+            for (int j = 0; j < NKFV; j++) {
+                if (NKFV > 1 && !((c_active >> j) & 1u)) continue;
+                const int32_t carry_prev = h_carry[j];
+                const int32_t Ecur = sc[j] + carry_prev;              // (D - D0) / 2N after this lane's transition
+                h_carry[j] = __builtin_amdgcn_readlane(Ecur, 63);
+                double inc = 0.0;
+                if (ACT != 0) {
+                    // (plain operators: this file is compiled with fp contract off, see the pragma at its top -- the __dmul_rn /
+                    //  __dadd_rn helpers of the HIP headers carry their own contraction flags and DO fuse)
+                    const double invN = NKFV == 1 ? gp.chain_invN[0] : gpp->chain_invN[j];   // (one KFV: held in scalar registers)
+                    double rl = (double)(uint32_t)Sl[j] * invN;       // refVec[left] as RN(S * (1/N))
+                    double rr = (double)(uint32_t)Sr[j] * invN;       // refVec[right]
+                    if (uni(NKFV == 1 ? gp.chain_form[0] : gpp->chain_form[j]) != 0) {
+                        asm volatile("");                             // (a real branch: not both forms and a select)
+                        // ... as RN(S / N): the product above is within an ulp of the quotient, its residual S - q N is exact
+                        // in one fused multiply-add, and q + residual * RN(1/N) then rounds to the correctly rounded quotient
+                        // (Markstein's division step; the host has checked the KFV's entries against exactly this sequence)
+                        const double Nd = (double)(NKFV == 1 ? gp.N[0] : gpp->N[j]);
+                        const double el = __builtin_fma(-rl, Nd, (double)(uint32_t)Sl[j]);
+                        const double er = __builtin_fma(-rr, Nd, (double)(uint32_t)Sr[j]);
+                        rl = __builtin_fma(el, invN, rl);
+                        rr = __builtin_fma(er, invN, rr);
                     }
+                    double t = tc;
+                    t = t + rl;
+                    t = t - rr;
+                    t = t - tl;
+                    inc = a.chain.SF * t;
+                    inc = act ? inc : 0.0;
                 }
-                c_P ^= (uint32_t)__builtin_popcountll(O) & 1u;
+                // hot step (the host wants a window of it): raw.  Otherwise every value of the step must stay inside the
+                // binade (E of a lane without a transition is its lower neighbour's); where no binade is known to hold (after
+                // a raw step, at a stream's start) it is looked up from the value the step starts on
+                bool raw = ((c_hot[j] >> (b & (KGMA_CHAIN_STEPS - 1))) & 1u) != 0;
+                if (!raw && ACT != 0) {
+                    if (uni((int)(c_Elo[j] > c_Ehi[j])) && (b << 6) >= nk) {
+                        const int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
+                        const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
+                        chain_binade(j, D0 + 2 * (int64_t)gpp->N[j] * (int64_t)carry_prev);
+                    }
+                    const uint64_t inl = __builtin_amdgcn_sicmp(Ecur, c_Elo[j], 39 /* sge */) & __builtin_amdgcn_sicmp(Ecur, c_Ehi[j], 41 /* sle */);
+                    raw = (inl | ~ACT) != ~(uint64_t)0;
+                }
+                if (raw) {
+                    raw_step(j, b, inc);
+                } else if (ACT != 0) {
+                    // RN(v + inc) for an even and an odd v of this binade, as hardware additions: anchors at the end of the
+                    // binade the increment moves away from (2^e, or 2^(e+1) - 2 ulp), so that the sums stay inside
+                    const uint64_t ib = (uint64_t)__double_as_longlong(inc);
+                    const bool neg = (int32_t)(uint32_t)(ib >> 32) < 0;
+                    const uint32_t x0hi = neg ? (c_XLhi[j] | 0xFFFFFu) : c_XLhi[j];
+                    const uint32_t x0lo = neg ? 0xFFFFFFFEu : 0u;
+                    const uint64_t x0b = ((uint64_t)x0hi << 32) | x0lo;
+                    const double R0 = __longlong_as_double((long long)x0b) + inc;
+                    const double R1 = __longlong_as_double((long long)(x0b | 1u)) + inc;
+                    const uint64_t r0b = (uint64_t)__double_as_longlong(R0), r1b = (uint64_t)__double_as_longlong(R1);
+                    const int64_t av = (int64_t)(r0b - x0b);          // ulps added to an even value
+                    const int32_t delta = (int32_t)((uint32_t)r1b - (uint32_t)r0b) - 1;   // ... to an odd value: av + delta (a tie: +-1)
+                    c_acc[j] += av;
+                    const uint64_t T = __builtin_amdgcn_uicmp((uint32_t)delta, 0u, 33 /* ne */);
+                    uint64_t O = __builtin_amdgcn_uicmp((uint32_t)av & 1u, 0u, 33 /* ne */) & ~T;
+                    // parity of the running value, lane by lane: it flips at odd a's and is EVEN after a tie
+                    if (__builtin_expect(T != 0, 0)) {
+                        uint64_t Trem = T;
+                        while (Trem != 0) {
+                            const int u = __builtin_ctzll(Trem);
+                            const uint64_t below = ((uint64_t)1 << u) - 1;
+                            c_P[j] ^= (uint32_t)__builtin_popcountll(O & below) & 1u;
+                            const int32_t du = __builtin_amdgcn_readlane(delta, u);
+                            const int32_t c0 = c_P[j] ? du : 0;
+                            if (uni(c_state[j]) & CS_SPLIT) { c_dA[j] = (c_P[j] ? 0 : du) - c0; c_state[j] = uni(c_state[j] & ~CS_SPLIT); }
+                            c_corr[j] += c0;
+                            c_P[j] = 0;
+                            O &= ~below;
+                            Trem &= Trem - 1;
+                        }
+                    }
+                    c_P[j] ^= (uint32_t)__builtin_popcountll(O) & 1u;
+                }
             }
             return;
         }
@@ -1410,11 +1438,38 @@ static const void *stream8_fn_of(int k, bool s16, int nkfv, int nd = 0)       //
 
 // waves per workgroup and workgroups per CU that keep the most streams resident (asked of the runtime, which knows
 // the LDS allocation granule and the kernel's registers); one KFV: two 16-wave workgroups = 32 waves per CU
-static const void *chain_fn_of(int k, bool s16)
+// chain variants: one KFV (either table width), or 2-4 KFVs of one window size with int16 tables (rows in LDS at k <= 6,
+// gathered from global memory at k = 7) sharing the count table of the pass
+template <int K>
+static const void *chain_fn_k(bool s16, int nkfv)
 {
-    if (k == 7) return reinterpret_cast<const void *>(&stream8_kernel<7, true, 1, 0, true>);
-    if (k == 5) return s16 ? reinterpret_cast<const void *>(&stream8_kernel<5, true, 1, 0, true>) : reinterpret_cast<const void *>(&stream8_kernel<5, false, 1, 0, true>);
-    return s16 ? reinterpret_cast<const void *>(&stream8_kernel<6, true, 1, 0, true>) : reinterpret_cast<const void *>(&stream8_kernel<6, false, 1, 0, true>);
+    switch (nkfv) {
+    case 2: return reinterpret_cast<const void *>(&stream8_kernel<K, true, 2, 0, true>);
+    case 3: return reinterpret_cast<const void *>(&stream8_kernel<K, true, 3, 0, true>);
+    case 4: return reinterpret_cast<const void *>(&stream8_kernel<K, true, 4, 0, true>);
+    default:
+        if constexpr (K >= 7) return reinterpret_cast<const void *>(&stream8_kernel<K, true, 1, 0, true>);
+        else return s16 ? reinterpret_cast<const void *>(&stream8_kernel<K, true, 1, 0, true>) : reinterpret_cast<const void *>(&stream8_kernel<K, false, 1, 0, true>);
+    }
+}
+
+static const void *chain_fn_of(int k, bool s16, int nkfv)
+{
+    return k == 7 ? chain_fn_k<7>(s16, nkfv) : k == 5 ? chain_fn_k<5>(s16, nkfv) : chain_fn_k<6>(s16, nkfv);
+}
+
+template <int K>
+static void chain_launch_k(bool s16, int nkfv, unsigned grid, unsigned threads, size_t lds, hipStream_t st, const ScanArgs &a, const GroupParams &gp)
+{
+    switch (nkfv) {
+    case 2: hipLaunchKernelGGL((stream8_kernel<K, true, 2, 0, true>), dim3(grid), dim3(threads), lds, st, a, gp); break;
+    case 3: hipLaunchKernelGGL((stream8_kernel<K, true, 3, 0, true>), dim3(grid), dim3(threads), lds, st, a, gp); break;
+    case 4: hipLaunchKernelGGL((stream8_kernel<K, true, 4, 0, true>), dim3(grid), dim3(threads), lds, st, a, gp); break;
+    default:
+        if constexpr (K >= 7) hipLaunchKernelGGL((stream8_kernel<K, true, 1, 0, true>), dim3(grid), dim3(threads), lds, st, a, gp);
+        else if (s16) hipLaunchKernelGGL((stream8_kernel<K, true, 1, 0, true>), dim3(grid), dim3(threads), lds, st, a, gp);
+        else hipLaunchKernelGGL((stream8_kernel<K, false, 1, 0, true>), dim3(grid), dim3(threads), lds, st, a, gp);
+    }
 }
 
 // Residency of one kernel variant on one device, asked of the runtime once: guarded (one context per host thread is the
@@ -1443,7 +1498,7 @@ static GeomVal stream8_geometry_of(int k, bool s16, int nkfv, int nd, bool chain
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
-    const void *fn = chain ? chain_fn_of(k, s16) : stream8_fn_of(k, s16, nkfv, nd);
+    const void *fn = chain ? chain_fn_of(k, s16, nkfv) : stream8_fn_of(k, s16, nkfv, nd);
     if (getenv("KGMA_GEOM_DEBUG")) {
         int rv = 0, dv = 0;
         (void)hipRuntimeGetVersion(&rv); (void)hipDriverGetVersion(&dv);
@@ -1505,37 +1560,36 @@ void stream8_geometry(int k, bool s16, int nkfv, int nd, int *nw_out, int *block
     *nw_out = v.nw; *blocks_out = v.blocks;
 }
 
-// ---- chain variant (one KFV, k = 5, 6 or 7): streams resident per CU, launch
+// ---- chain variants (1-4 KFVs of one window size, k = 5, 6 or 7): streams resident per CU, launch
 bool chain_applies(int k, int nk, int64_t n_ref, bool s16)
 {
     return (k == 5 || k == 6 || (k == 7 && s16)) && nk <= KGMA_STREAM8_MAX_NK && n_ref < ((int64_t)1 << 22);
 }
 
-int chain_slots_per_cu(int k, bool s16)
+int chain_slots_per_cu(int k, bool s16, int nkfv)
 {
-    const GeomVal v = stream8_geometry_of(k, s16, 1, 0, true);
+    if (nkfv < 1 || nkfv > 4 || (nkfv > 1 && !s16)) return 0;
+    const GeomVal v = stream8_geometry_of(k, s16, nkfv, 0, true);
     return v.nw < 1 ? 0 : v.nw * v.blocks;
 }
 
 hipError_t launch_chain(const ScanArgs &a, const GroupParams &gp, hipStream_t st)
 {
     const bool s16 = gp.s_fits_i16 != 0;
-    const GeomVal v = stream8_geometry_of(gp.k, s16, 1, 0, true);
-    if (v.nw < 1 || gp.n_kfv != 1 || !chain_applies(gp.k, gp.nk, gp.N[0], s16)) return hipErrorInvalidConfiguration;
+    const int nkfv = gp.n_kfv;
+    if (nkfv < 1 || nkfv > 4 || (nkfv > 1 && !s16)) return hipErrorInvalidConfiguration;
+    const GeomVal v = stream8_geometry_of(gp.k, s16, nkfv, 0, true);
+    for (int j = 0; j < nkfv; j++)
+        if (!chain_applies(gp.k, gp.nk, gp.N[j], s16)) return hipErrorInvalidConfiguration;
+    if (v.nw < 1) return hipErrorInvalidConfiguration;
     const int nw = v.nw;
-    const size_t lds = stream8_lds(gp.k, s16, 1, nw);
+    const size_t lds = stream8_lds(gp.k, s16, nkfv, nw);
     const unsigned grid = (unsigned)((a.n_tiles + nw - 1) / nw);
-    hipError_t e = hipFuncSetAttribute(chain_fn_of(gp.k, s16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(chain_fn_of(gp.k, s16, nkfv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (gp.k == 7) {
-        hipLaunchKernelGGL((stream8_kernel<7, true, 1, 0, true>), dim3(grid), dim3(64u * nw), lds, st, a, gp);
-    } else if (gp.k == 5) {
-        if (s16) hipLaunchKernelGGL((stream8_kernel<5, true, 1, 0, true>), dim3(grid), dim3(64u * nw), lds, st, a, gp);
-        else hipLaunchKernelGGL((stream8_kernel<5, false, 1, 0, true>), dim3(grid), dim3(64u * nw), lds, st, a, gp);
-    } else {
-        if (s16) hipLaunchKernelGGL((stream8_kernel<6, true, 1, 0, true>), dim3(grid), dim3(64u * nw), lds, st, a, gp);
-        else hipLaunchKernelGGL((stream8_kernel<6, false, 1, 0, true>), dim3(grid), dim3(64u * nw), lds, st, a, gp);
-    }
+    if (gp.k == 7) chain_launch_k<7>(s16, nkfv, grid, 64u * nw, lds, st, a, gp);
+    else if (gp.k == 5) chain_launch_k<5>(s16, nkfv, grid, 64u * nw, lds, st, a, gp);
+    else chain_launch_k<6>(s16, nkfv, grid, 64u * nw, lds, st, a, gp);
     return hipGetLastError();
 }
 

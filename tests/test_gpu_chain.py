@@ -177,3 +177,27 @@ def test_chain_values_where_the_distance_hovers_on_a_power_of_two(ctx, alp_ref):
         assert np.array_equal(g.chain_values(0, 1, [(1, nwin)]), chain)
     finally:
         g.free()
+
+
+@pytest.mark.parametrize("group", ["2", "4"])
+def test_chain_replay_with_grouped_launches(ctx, alp_clusters, genes, group, monkeypatch):
+    """KGMA_CHAIN_GROUP: the KFVs of one window size share one chain launch (slots; a record's streams carry the mask of the
+    slots it is flagged for).  Off by default (measured slower on sparse flags), but the same hits as the oracle."""
+    monkeypatch.setenv("KGMA_CHAIN_GROUP", group)
+    rng = np.random.default_rng(27)
+    c = alp_clusters
+    contigs, _ = make_genome(rng, [300_000, 120_000, 40_000], genes, n_plants_per_mb=60)
+    thr = [37, 33, 38, 34, 28]
+    ohits, _ = orc.omn_scan(contigs, c["KFVs"], 6, c["ws"], thr, 100, 0)
+    ctx.set_refs(6, c["KFVs"], c["ws"], thr, c["N"])
+    g = ctx.genome_from_host(contigs)
+    try:
+        ctx.scan(g, _lib.MODE_OMN, 100, 0, _lib.F_CHAIN_REPLAY, None)
+        hits, st = ctx.hits(), ctx.stats()
+        assert st["n_chain_pairs"] >= 3 and st["chain_device_pairs"] == st["n_chain_pairs"]
+        assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohits]
+        for a, b in zip(hits, ohits):
+            if a["flags"] & _lib.HIT_CHAIN:
+                assert a["dist"] == b["dist"]
+    finally:
+        g.free()
