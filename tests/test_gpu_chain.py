@@ -201,3 +201,22 @@ def test_chain_replay_with_grouped_launches(ctx, alp_clusters, genes, group, mon
                 assert a["dist"] == b["dist"]
     finally:
         g.free()
+
+
+def test_chain_replay_in_small_batches(ctx, alp_ref, genes, monkeypatch):
+    """The pairs of a scan are chained in batches of bounded size (2^36 windows by default); forced down to 10^5 windows here,
+    so that three records become three batches: same hits as the oracle."""
+    monkeypatch.setenv("KGMA_CHAIN_BATCH_WINDOWS", "100000")
+    rng = np.random.default_rng(28)
+    contigs, _ = make_genome(rng, [900_000, 700_000, 400_000], genes, n_plants_per_mb=20)
+    k, W, RV, N = 6, alp_ref["ws"], alp_ref["RV"], alp_ref["N"]
+    ohits, _ = orc.single_scan(contigs, RV, k, W, 37.0, 50)
+    ctx.set_refs(k, [RV], [W], [37.0], [N])
+    g = ctx.genome_from_host(contigs)
+    try:
+        ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_CHAIN_REPLAY, None)
+        hits, st = ctx.hits(), ctx.stats()
+        assert st["n_chain_pairs"] == 3 and st["chain_device_pairs"] == 3
+        assert [(hit_key(h), h["dist"]) for h in hits] == [(hit_key(h), h["dist"]) for h in ohits]
+    finally:
+        g.free()
