@@ -37,8 +37,9 @@ hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int
 hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 int stream_waves(int k, int nk, int n_kfv, int n_sizes);
-int stream_slots_per_cu(int k, int nk, int nk_min, int n_longer, int n_kfv, int n_sizes, bool s16, int64_t n_ref);
+int stream_slots_per_cu(int k, int nk, int nk_min, int n_longer, int n_kfv, int n_sizes, bool s16, int64_t n_ref, bool u8, int n_plus2);
 bool stream8_derive_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool s16);
+bool stream8_wide_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool u8);
 bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16);
 int stream8_variant(int n_kfv);
 hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
@@ -429,6 +430,22 @@ std::vector<Group> make_groups(const kgma_ctx *ctx, int mode, bool s8 = false)
         }
         if (!placed) gs.push_back(Group{W, {j}});
     }
+    // Two neighbouring launches with FIVE KFVs between them, windows within two k-mers of each other and every S below 256:
+    // one launch of the five-KFV variant (stream8_wide_applies; BASELINE configs[3] is {288, 288, 288, 289} + {290})
+    if (s8)
+        for (size_t i = 0; i + 1 < gs.size(); i++) {
+            Group &g0 = gs[i];
+            const Group &g1 = gs[i + 1];
+            if (g0.kfvs.size() + g1.kfvs.size() != 5) continue;
+            int64_t nmax = 0, smax = 0;
+            for (const Group *gp : {static_cast<const Group *>(&g0), &g1})
+                for (int u : gp->kfvs) { nmax = std::max(nmax, ctx->kfv[(size_t)u].N); smax = std::max(smax, ctx->kfv[(size_t)u].Smax); }
+            const int nk0 = (int)(ctx->kfv[(size_t)g0.kfvs.front()].W - ctx->k + 1), nk1 = (int)(g1.W - ctx->k + 1);
+            if (!stream8_wide_applies(ctx->k, nk0, nk1, 5, nmax, smax < 256)) continue;
+            g0.kfvs.insert(g0.kfvs.end(), g1.kfvs.begin(), g1.kfvs.end());
+            g0.W = g1.W;
+            gs.erase(gs.begin() + (long)i + 1);
+        }
     return gs;
 }
 
@@ -1512,7 +1529,12 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     auto group_one_size = [&](const Group &gr) { return ctx->kfv[(size_t)gr.kfvs.front()].W == ctx->kfv[(size_t)gr.kfvs.back()].W; };
     auto group_s16 = [&](const Group &gr) { bool ok = true; for (int j : gr.kfvs) ok = ok && ctx->kfv[(size_t)j].Smax <= 32767; return ok; };
     auto group_nk_min = [&](const Group &gr) { return (int)(ctx->kfv[(size_t)gr.kfvs.front()].W - k + 1); };
+    auto group_u8 = [&](const Group &gr) { bool ok = true; for (int j : gr.kfvs) ok = ok && ctx->kfv[(size_t)j].Smax < 256; return ok; };
+    auto group_wide = [&](const Group &gr) {
+        return stream8_wide_applies(k, group_nk_min(gr), (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_u8(gr));
+    };
     auto group_s8 = [&](const Group &gr) {
+        if (group_wide(gr)) return true;
         if (group_one_size(gr)) return stream8_applies(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr));
         return stream8_derive_applies(k, group_nk_min(gr), (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr));
     };
@@ -1535,7 +1557,10 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             for (int j : gr.kfvs) s16 = s16 && ctx->kfv[(size_t)j].Smax <= 32767;
             int n_longer = 0;                  // KFVs whose window is longer than the launch's shortest
             for (int j : gr.kfvs) n_longer += ctx->kfv[(size_t)j].W != ctx->kfv[(size_t)gr.kfvs.front()].W ? 1 : 0;
-            const int nw = stream_slots_per_cu(k, (int)(gr.W - k + 1), group_nk_min(gr), n_longer, (int)gr.kfvs.size(), n_sizes, s16, group_nmax(gr));
+            int n_plus2 = 0;                   // ... two k-mers longer (five-KFV launches)
+            for (int j : gr.kfvs) n_plus2 += ctx->kfv[(size_t)j].W == ctx->kfv[(size_t)gr.kfvs.front()].W + 2 ? 1 : 0;
+            const int nw = stream_slots_per_cu(k, (int)(gr.W - k + 1), group_nk_min(gr), n_longer, (int)gr.kfvs.size(), n_sizes, s16, group_nmax(gr),
+                                               group_u8(gr), n_plus2);
             if (nw < 1) use_stream = false;
             stream_nw = std::min(stream_nw, nw);
             launch_slots.push_back(nw);
@@ -1817,8 +1842,9 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
                 gp.T_hi[u] = f.T_hi;
                 gp.sumS2[u] = f.sumS2;
                 gp.inv_scale[u] = 2.0 * (double)k * (double)f.N * (double)f.N;
-                if (u == 0) gp.s_fits_i16 = 1;
+                if (u == 0) gp.s_fits_i16 = gp.s_fits_u8 = 1;
                 if (f.Smax > 32767) gp.s_fits_i16 = 0;
+                if (f.Smax > 255) gp.s_fits_u8 = 0;
                 a.dist[u] = want_dists ? ctx->d_dist[(size_t)j] : nullptr;
             }
             a.planes = g->d_planes;

@@ -45,7 +45,7 @@ struct GroupParams {
     int32_t nblocks;                     // 16-offset blocks of the match loop
     int32_t debug_skip;                  // timing experiments only (bit 0: no match loop, bit 1: no position phase); 0 in product use
     int32_t stream_slots;                // stream kernels: streams resident per CU the tile table was sized for (all launches of a scan share it)
-    int32_t pad1;
+    int32_t s_fits_u8;                   // every S entry of the launch's KFVs is below 256 (the five-KFV stream8_kernel keeps rows of bytes)
     int32_t s_fits_i16;                  // every S entry of the launch's KFVs fits int16 (stream8_kernel keeps the table as int16)
     int32_t kfv_id[KGMA_MAX_GROUP];      // 1-based KFV index reported in records
     int32_t N[KGMA_MAX_GROUP];           // reference count of each KFV

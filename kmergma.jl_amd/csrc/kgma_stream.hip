@@ -532,14 +532,21 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 #define KGMA_CHAIN_WAVES 6
 #endif
 
-template <int K, bool S16, int NKFV, int ND = 0, bool CHAIN = false>
-__global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN_WAVES : 8) : (CHAIN ? 4 : (NKFV <= 4 ? 6 : 4)))) void stream8_kernel(ScanArgs a, GroupParams gp)
+template <int K, bool S16, int NKFV, int ND = 0, bool CHAIN = false, int ND2 = 0>
+__global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN_WAVES : 8) : (CHAIN ? 4 : (NKFV <= 5 ? 6 : 4)))) void stream8_kernel(ScanArgs a, GroupParams gp)
 {
     // CHAIN: the same walk, but instead of testing thresholds the wave reproduces the reference's running Float64
     // value (kgma_device.h, ChainArgs): one KFV, no dips, no records -- chunk translations and raw increments.
-    static_assert(!CHAIN || (NKFV <= 4 && ND == 0), "the chain variant walks 1-4 KFVs of one window size");
-    constexpr bool DERIVE = ND > 0;                                   // the LAST ND KFVs of the launch have a window one k-mer longer
-    static_assert(!DERIVE || (NKFV >= 2 && NKFV <= 4 && ND < NKFV && S16), "derived windows: 2-4 KFVs with int16 S tables");
+    static_assert(!CHAIN || (NKFV <= 4 && ND == 0 && ND2 == 0), "the chain variant walks 1-4 KFVs of one window size");
+    // The KFVs of a launch are sorted by window size: NKFV - ND - ND2 of n k-mers (the count table's), then ND of n + 1,
+    // then ND2 of n + 2 (five-KFV variant only).
+    constexpr bool DERIVE = ND + ND2 > 0;
+    static_assert(!DERIVE || (NKFV >= 2 && NKFV <= 5 && ND + ND2 < NKFV && S16), "derived windows: 2-5 KFVs with 16-bit (or 8-bit) S tables");
+    static_assert(ND2 == 0 || NKFV == 5, "windows two k-mers longer: the five-KFV variant");
+    // NKFV = 5: S rows of eight BYTES (every S of the launch < 256, checked on the host): the rows of five KFVs take the
+    // 32 KiB that four int16 KFVs take, so the launch keeps the residency of a four-KFV launch
+    constexpr bool SBYTE = NKFV == 5;
+    static_assert(!SBYTE || (S16 && K <= 6), "byte rows: k <= 6");
     // k = 7: a wave's table is 16 KiB, so the LDS holds 10 of them and nothing else; the S tables stay in global memory,
     // interleaved per k-mer ([k-mer][NKFV] int16: ONE gather per k-mer serves every KFV of the launch; 32-256 KiB, L2-resident)
     constexpr bool SGLOBAL = K >= 7;
@@ -566,8 +573,8 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
     // (measured at k = 6 too, for the residency it would buy -- 3 KFVs, 400 Mb: 1.45 ms with the rows in global memory
     // against 1.15 ms in LDS)
     constexpr bool SROWS = S16 && NKFV >= 2;
-    constexpr int NV = NKFV >= 5 ? 8 : (NKFV >= 3 ? 4 : NKFV);          // int16 slots per row
-    constexpr size_t tab_words = SROWS ? (size_t)NB * NV / 2 : (S16 ? NB / 2 : NB) * (size_t)NKFV;
+    constexpr int NV = NKFV >= 5 ? 8 : (NKFV >= 3 ? 4 : NKFV);          // int16 (SBYTE: byte) slots per row
+    constexpr size_t tab_words = SROWS ? (size_t)NB * NV / (SBYTE ? 4 : 2) : (S16 ? NB / 2 : NB) * (size_t)NKFV;
     constexpr size_t per_wave_words = NB / 4 + (NKFV > 1 ? NKFV * ST_WORDS : 0);
     int32_t *sTab32 = reinterpret_cast<int32_t *>(smem);
     uint16_t *sTab16 = reinterpret_cast<uint16_t *>(smem);          // S >= 0 (sums of counts): read zero-extended
@@ -579,7 +586,8 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
             if (j >= n_kfv) continue;
             const int32_t *Sg = a.Stab + (size_t)(gp.kfv_id[j] - 1) * NB;
             for (int i = threadIdx.x; i < NB; i += blockDim.x) {
-                if constexpr (SROWS) sTab16[(size_t)i * NV + j] = (uint16_t)Sg[i];
+                if constexpr (SBYTE) reinterpret_cast<uint8_t *>(smem)[(size_t)i * NV + j] = (uint8_t)Sg[i];
+                else if constexpr (SROWS) sTab16[(size_t)i * NV + j] = (uint16_t)Sg[i];
                 else if constexpr (S16) sTab16[(size_t)j * NB + i] = (uint16_t)Sg[i];
                 else sTab32[(size_t)j * NB + i] = Sg[i];
             }
@@ -605,7 +613,14 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
     // -- the count and the S value the step has anyway.  In E units: E' = E_before + (N c[y] - S[y]) - K0, K0 fixed by
     // the first such window (whose D becomes the stream's D0 for that KFV; K0 is taken off the running prefix carry
     // once, at that window).  Such a KFV's window index is q - 1.
-    constexpr uint32_t dm1 = DERIVE ? ((1u << NKFV) - 1u) & ~((1u << (NKFV - ND)) - 1u) : 0u;
+    constexpr uint32_t dm2 = ND2 > 0 ? ((1u << NKFV) - 1u) & ~((1u << (NKFV - ND2)) - 1u) : 0u;              // windows of n + 2
+    constexpr uint32_t dm1 = DERIVE ? ((1u << NKFV) - 1u) & ~((1u << (NKFV - ND - ND2)) - 1u) & ~dm2 : 0u;    // ... of n + 1
+    constexpr int DEXTRA = ND2 > 0 ? 2 : (DERIVE ? 1 : 0);            // positions the longest window of the launch ends later
+    // windows of n + 2 k-mers: from the n + 1 window of the lane BELOW (lane 0: of the previous step's lane 63, kept here)
+    int32_t d2_prevX[ND2 > 0 ? ND2 : 1];
+    uint32_t d2_prev_ks = 0;
+#pragma unroll
+    for (int j = 0; j < (ND2 > 0 ? ND2 : 1); j++) d2_prevX[j] = 0;
 #pragma unroll
     for (int j = 0; j < NKFV; j++)
         if (j < n_kfv && a.dist[j] != nullptr) dist_mask |= 1u << j;
@@ -618,7 +633,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
     const int nk = gp.nk;
     // the stream reads the 2-bit interleaved genome (16 bases per dword): its first base is bit 0 of gi[0]
     const uint32_t *gi = a.inter + 2 * td.word_base;
-    const int n_pos = n_valid + nk - 1 + (DERIVE ? 1 : 0);        // (a derived window ends one position later)
+    const int n_pos = n_valid + nk - 1 + DEXTRA;                  // (a derived window ends one or two positions later)
     const int n_blocks = (n_pos + 63) >> 6;
 
     // k-mer at position p = 64 b + lane: bits 2 (p & 15) ... of the dword pair starting at dword p >> 4.
@@ -809,7 +824,10 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
         if (na > 0x3FFFFFFF) na = 0x3FFFFFFF;
         if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; na = 0; }
         if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; na = 0; }
-        h_TE[j] = uni((int32_t)TE64);
+        // (the step compares against TE + natt: "below or at the threshold" is ONE test on its fast path; the cold path
+        //  takes the two apart with TE from the KFV's state)
+        h_TE[j] = uni((int32_t)(TE64 + na));
+        st[ST_TE] = (int32_t)TE64;
         st[ST_NATT] = (int32_t)na;
         att_mask = (att_mask & ~(1u << j)) | (uni((int32_t)na) != 0 ? 1u << j : 0u);
     };
@@ -851,7 +869,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
         if constexpr (SGLOBAL || SROWS) {
             // one read per k-mer for all KFVs of the launch (k = 7: a gather from global memory, issued first: the longest
             // latency of the step; k <= 6: a row of the LDS table)
-            constexpr int NW = NKFV >= 2 ? NV / 2 : 1;               // dwords per table row (NKFV = 3: a 4-slot row)
+            constexpr int NW = NKFV >= 2 ? (SBYTE ? NV / 4 : NV / 2) : 1;   // dwords per table row (NKFV = 3: a 4-slot row)
             uint32_t vr[NW], vl[NW];
             if constexpr (NKFV == 1) {
                 vr[0] = (uint32_t)(uint16_t)a.Sinter[kp]; vl[0] = (uint32_t)(uint16_t)a.Sinter[ks];
@@ -875,8 +893,13 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
             }
 #pragma unroll
             for (int j = 0; j < NKFV; j++) {
-                Sr[j] = (int32_t)(uint16_t)(vr[j / 2] >> (16 * (j & 1)));   // S >= 0: zero-extended
-                Sl[j] = (int32_t)(uint16_t)(vl[j / 2] >> (16 * (j & 1)));
+                if constexpr (SBYTE) {
+                    Sr[j] = (int32_t)((vr[j / 4] >> (8 * (j & 3))) & 0xFFu);
+                    Sl[j] = (int32_t)((vl[j / 4] >> (8 * (j & 3))) & 0xFFu);
+                } else {
+                    Sr[j] = (int32_t)(uint16_t)(vr[j / 2] >> (16 * (j & 1)));   // S >= 0: zero-extended
+                    Sl[j] = (int32_t)(uint16_t)(vl[j / 2] >> (16 * (j & 1)));
+                }
             }
         } else {
 #pragma unroll
@@ -1147,11 +1170,18 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
             if constexpr (GENERIC) return q;
             else { int bb = b; asm volatile("" : "+s"(bb)); return (bb << 6) + lane - nk + 1; }
         };
-        bool tested = true, tested_d = true;                           // (tested_d: KFVs with a derived window, index q - 1)
-        uint64_t TESTED = ~(uint64_t)0, TESTED_D = ~(uint64_t)0;
+        bool tested = true, tested_d = true, tested_d2 = true;         // (tested_d / _d2: KFVs with a derived window, index q - 1 / q - 2)
+        uint64_t TESTED = ~(uint64_t)0, TESTED_D = ~(uint64_t)0, TESTED_D2 = ~(uint64_t)0;
         if constexpr (GENERIC) {
             tested = q >= first_test && q < n_valid; TESTED = __ballot(tested);
             if constexpr (DERIVE) { tested_d = q - 1 >= first_test && q - 1 < n_valid; TESTED_D = __ballot(tested_d); }
+            if constexpr (ND2 > 0) { tested_d2 = q - 2 >= first_test && q - 2 < n_valid; TESTED_D2 = __ballot(tested_d2); }
+        }
+        // ks of the lane below (the k-mer that leaves one position earlier): the n + 2 windows need it
+        uint32_t ks_below = 0;
+        if constexpr (ND2 > 0) {
+            ks_below = (uint32_t)__builtin_amdgcn_update_dpp((int)d2_prev_ks, (int)ks, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+            d2_prev_ks = (uint32_t)__builtin_amdgcn_readlane((int)ks, 63);
         }
         int32_t E[NKFV];
         uint64_t Um[NKFV];
@@ -1162,7 +1192,34 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
             if (NKFV == 8 && j >= n_kfv) continue;
             E[j] = sc[j] + h_carry[j];
             h_carry[j] = __builtin_amdgcn_readlane(E[j], 63);
-            if (DERIVE && ((dm1 >> j) & 1u)) {
+            if (ND2 > 0 && ((dm2 >> j) & 1u)) {
+                // The window of n + 2 k-mers that ends with this lane's entering k-mer y is the n + 1 window of the lane
+                // below (which ends one position earlier) plus y:  D(n+2) = D(n+1)' + N (N (2 c + 1) - 2 S[y]), c = y's count
+                // in that n + 1 window = this lane's count of y before its transition + [the k-mer that left at the lane
+                // below is y].  In E units: X2 = X1' + N c - S[y]; the constant N^2 per added k-mer goes into the first window's D.
+                const int jj = ND2 > 0 ? j - (NKFV - ND2) : 0;
+                int32_t X1 = E[j] - ev[j] + (__mul24(gp.N[j], cP) - Sr[j]);
+                const int32_t X1b = __builtin_amdgcn_update_dpp(d2_prevX[jj], X1, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+                const int32_t c2 = cP + (ks_below == kp ? 1 : 0);
+                int32_t X = X1b + (__mul24(gp.N[j], c2) - Sr[j]);
+                if constexpr (GENERIC) {
+                    if (b == ((nk + 1) >> 6)) {                       // position nk + 1 is in this step: the KFV's first window
+                        int32_t *st = sState + j * ST_WORDS;
+                        const int32_t K0 = __builtin_amdgcn_readlane(X, (nk + 1) & 63);
+                        const int64_t Nj = gpp->N[j];
+                        const int64_t D0b = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
+                        const int64_t D0 = D0b + 2 * Nj * (int64_t)K0 + 2 * Nj * Nj;
+                        if (lane == 0) a.D0out[(size_t)(gpp->kfv_id[j] - 1) * a.n_tiles + tile] = D0;
+                        set_first_window(j, st, D0);
+                        X -= K0;                                      // from here on E is relative to this window
+                        X1 -= K0;
+                        h_carry[j] -= K0;
+                    }
+                }
+                d2_prevX[jj] = __builtin_amdgcn_readlane(X1, 63);
+                E[j] = X;
+                Um[j] = __builtin_amdgcn_sicmp(E[j], h_TE[j], 40 /* slt */) & TESTED_D2;
+            } else if (DERIVE && ((dm1 >> j) & 1u)) {
                 // E of this lane's pre-transition window, plus the entering k-mer's term
                 int32_t X = E[j] - ev[j] + (__mul24(gp.N[j], cP) - Sr[j]);
                 if constexpr (GENERIC) {
@@ -1188,31 +1245,30 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
         if (dist_mask != 0) {
 #pragma unroll
             for (int j = 0; j < NKFV; j++) {
-                const int dj = DERIVE ? (int)((dm1 >> j) & 1u) : 0;
-                if (!((dist_mask >> j) & 1u) || !(dj ? tested_d : tested)) continue;
+                const int dj = DERIVE ? (int)((dm1 >> j) & 1u) + 2 * (int)((dm2 >> j) & 1u) : 0;
+                if (!((dist_mask >> j) & 1u) || !(dj == 2 ? tested_d2 : dj ? tested_d : tested)) continue;
                 const int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
                 const int64_t twoN = 2 * (int64_t)gp.N[j];
                 const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
                 a.dist[j][td.dist_base + q_cold() - dj] = (double)(D0 + twoN * (int64_t)E[j]) / gpp->inv_scale[j];
             }
         }
-        if (anyU == 0 && inrun_mask == 0 && att_mask == 0) return;    // fast path: nothing near any threshold
+        if (anyU == 0 && inrun_mask == 0) return;                     // fast path: nothing below or at any threshold
 
 #pragma unroll
         for (int j = 0; j < NKFV; j++) {
             if (NKFV == 8 && j >= n_kfv) continue;
             int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
             const int32_t Ej = E[j];
-            const int32_t TE = h_TE[j];
-            const uint64_t U = Um[j];
-            const bool under = (U >> lane) & 1u;
-            const int dj = DERIVE ? (int)((dm1 >> j) & 1u) : 0;
-            bool att = false;
+            uint64_t U = Um[j];                                        // tested windows below TE + natt
+            const int dj = DERIVE ? (int)((dm1 >> j) & 1u) + 2 * (int)((dm2 >> j) & 1u) : 0;
             uint64_t A = 0;
-            if ((att_mask >> j) & 1u) {                                // (only when the threshold sits on the distance lattice)
-                att = (dj ? tested_d : tested) && !under && Ej - TE < uni(st[ST_NATT]);
-                A = __ballot(att);
+            if (((att_mask >> j) & 1u) && U != 0) {                    // (only when the threshold sits on the distance lattice)
+                const uint64_t below = __builtin_amdgcn_sicmp(Ej, uni(st[ST_TE]), 40 /* slt */);
+                A = U & ~below;                                        // TE <= E < TE + natt: at the threshold
+                U &= below;
             }
+            const bool att = (A >> lane) & 1u;
             int in_run = (int)((inrun_mask >> j) & 1u);
             if ((U | A) == 0 && !in_run) continue;
             const int32_t E = Ej;
@@ -1273,7 +1329,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
         }
     };
 
-    int b_warm = (nk + (DERIVE ? 64 : 63)) >> 6;                      // (DERIVE: position nk, the first derived window, is in a generic step)
+    int b_warm = (nk + 63 + DEXTRA) >> 6;                             // (DERIVE: positions nk / nk + 1, the first derived windows, are in generic steps)
     if (b_warm > n_blocks) b_warm = n_blocks;
     int b_tail = n_valid + nk - 65;                                   // steps b <= b_tail/64 have all windows < n_valid
     b_tail = b_tail >= 0 ? (b_tail >> 6) + 1 : 0;
@@ -1384,7 +1440,7 @@ static size_t stream8_lds(int k, bool s16, int nkfv, int nw)
 {
     const size_t NB = (size_t)1 << (2 * k);
     const size_t slots = s16 && nkfv >= 2 ? (nkfv >= 5 ? 8 : nkfv >= 3 ? 4 : 2) : (size_t)nkfv;   // int16 tables of several KFVs: rows of 2 / 4 / 8 slots
-    const size_t tabs = k >= 7 ? 0 : NB * (s16 ? 2 : 4) * slots;                  // k = 7: the S tables stay in global memory
+    const size_t tabs = k >= 7 ? 0 : nkfv == 5 ? NB * 8 : NB * (s16 ? 2 : 4) * slots;   // k = 7: the S tables stay in global memory; 5: rows of 8 bytes
     return tabs + (size_t)nw * (NB + (nkfv > 1 ? (size_t)nkfv * ST_WORDS * 4 : 0));
 }
 
@@ -1401,6 +1457,33 @@ static bool stream8_derive_env_on()                  // KGMA_STREAM8_DERIVE=0 (t
 bool stream8_derive_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool s16)
 {
     return stream8_derive_env_on() && nk_max == nk_min + 1 && n_kfv >= 2 && n_kfv <= 4 && s16 && stream8_applies(k, nk_max, n_kfv, n_ref, s16);
+}
+
+// FIVE KFVs in one launch (k = 5, 6): windows of n, n + 1 and n + 2 k-mers off one count table, S rows of eight bytes (every S
+// of the launch below 256) -- the LDS footprint and residency of a four-KFV launch.  BASELINE configs[3] (288 x 3, 289, 290)
+// is one such launch.  KGMA_STREAM8_WIDE=0 (testing): off.
+static bool stream8_wide_env_on()
+{
+    const char *e = getenv("KGMA_STREAM8_WIDE");
+    return !(e && atoi(e) == 0);
+}
+bool stream8_wide_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool u8)
+{
+    return stream8_wide_env_on() && n_kfv == 5 && u8 && (k == 5 || k == 6) && nk_max - nk_min <= 2 && (nk_max == nk_min || stream8_derive_env_on()) &&
+           stream8_applies(k, nk_max, n_kfv, n_ref, true);
+}
+
+template <int K>
+static const void *stream8_fn_wide(int nd, int nd2)
+{
+#define KGMA_WIDE(D1, D2) case (D2) * 8 + (D1): return reinterpret_cast<const void *>(&stream8_kernel<K, true, 5, D1, false, D2>);
+    switch (nd2 * 8 + nd) {
+    KGMA_WIDE(0, 0) KGMA_WIDE(1, 0) KGMA_WIDE(2, 0) KGMA_WIDE(3, 0) KGMA_WIDE(4, 0)
+    KGMA_WIDE(0, 1) KGMA_WIDE(1, 1) KGMA_WIDE(2, 1) KGMA_WIDE(3, 1)
+    KGMA_WIDE(0, 2) KGMA_WIDE(1, 2) KGMA_WIDE(2, 2)
+    default: return nullptr;
+    }
+#undef KGMA_WIDE
 }
 
 template <int K>
@@ -1428,8 +1511,9 @@ static const void *stream8_fn_k(int nkfv)
     }
 }
 
-static const void *stream8_fn_of(int k, bool s16, int nkfv, int nd = 0)       // nd: KFVs with a derived window
+static const void *stream8_fn_of(int k, bool s16, int nkfv, int nd = 0, int nd2 = 0)       // nd / nd2: KFVs with a window one / two k-mers longer
 {
+    if (nkfv == 5) return k == 5 ? stream8_fn_wide<5>(nd, nd2) : stream8_fn_wide<6>(nd, nd2);
     if (nd > 0) return k == 5 ? stream8_fn_derive<5>(nkfv, nd) : k == 7 ? stream8_fn_derive<7>(nkfv, nd) : stream8_fn_derive<6>(nkfv, nd);
     if (k == 5) return s16 ? stream8_fn_k<5, true>(nkfv) : stream8_fn_k<5, false>(nkfv);
     if (k == 7) return stream8_fn_k<7, true>(nkfv);
@@ -1475,10 +1559,11 @@ static void chain_launch_k(bool s16, int nkfv, unsigned grid, unsigned threads, 
 // Residency of one kernel variant on one device, asked of the runtime once: guarded (one context per host thread is the
 // documented use) and keyed by the device too (partitioned modes expose different CUs).
 struct GeomKey {
-    int device, k, s16, nkfv, nd, chain;
+    int device, k, s16, nkfv, nd, chain, nd2;
     bool operator<(const GeomKey &o) const
     {
         if (device != o.device) return device < o.device;
+        if (nd2 != o.nd2) return nd2 < o.nd2;
         if (k != o.k) return k < o.k;
         if (s16 != o.s16) return s16 < o.s16;
         if (nkfv != o.nkfv) return nkfv < o.nkfv;
@@ -1488,17 +1573,18 @@ struct GeomKey {
 };
 struct GeomVal { int nw, blocks; };
 
-static GeomVal stream8_geometry_of(int k, bool s16, int nkfv, int nd, bool chain)
+static GeomVal stream8_geometry_of(int k, bool s16, int nkfv, int nd, bool chain, int nd2 = 0)
 {
     static std::mutex mu;
     static std::map<GeomKey, GeomVal> cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const GeomKey key{dev, k, s16 ? 1 : 0, nkfv, nd, chain ? 1 : 0};
+    const GeomKey key{dev, k, s16 ? 1 : 0, nkfv, nd, chain ? 1 : 0, nd2};
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
-    const void *fn = chain ? chain_fn_of(k, s16, nkfv) : stream8_fn_of(k, s16, nkfv, nd);
+    const void *fn = chain ? chain_fn_of(k, s16, nkfv) : stream8_fn_of(k, s16, nkfv, nd, nd2);
+    if (fn == nullptr) return GeomVal{-1, 1};
     if (getenv("KGMA_GEOM_DEBUG")) {
         int rv = 0, dv = 0;
         (void)hipRuntimeGetVersion(&rv); (void)hipDriverGetVersion(&dv);
@@ -1554,9 +1640,9 @@ static GeomVal stream8_geometry_of(int k, bool s16, int nkfv, int nd, bool chain
 
 // waves per workgroup and workgroups per CU that keep the most streams resident (asked of the runtime, which knows
 // the LDS allocation granule and the kernel's registers); one KFV: two 16-wave workgroups = 32 waves per CU
-void stream8_geometry(int k, bool s16, int nkfv, int nd, int *nw_out, int *blocks_out)
+void stream8_geometry(int k, bool s16, int nkfv, int nd, int *nw_out, int *blocks_out, int nd2 = 0)
 {
-    const GeomVal v = stream8_geometry_of(k, s16, nkfv, nd, false);
+    const GeomVal v = stream8_geometry_of(k, s16, nkfv, nd, false, nd2);
     *nw_out = v.nw; *blocks_out = v.blocks;
 }
 
@@ -1626,15 +1712,19 @@ static int derived_kfvs(const GroupParams &gp)
     return nd;
 }
 
-static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp_in, hipStream_t st, bool derive_launch)
+static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp_in, hipStream_t st, bool derive_launch, bool wide = false)
 {
     GroupParams gp = gp_in;
-    const int derive = derive_launch ? derived_kfvs(gp) : 0;
-    if (derive) gp.nk = gp.nk_min;                  // the count table is kept for the SHORTER window
+    int derive = derive_launch ? derived_kfvs(gp) : 0, derive2 = 0;
+    if (wide) {
+        derive = derive2 = 0;
+        for (int j = 0; j < gp.n_kfv; j++) { derive += gp.nk_of[j] == gp.nk_min + 1 ? 1 : 0; derive2 += gp.nk_of[j] == gp.nk_min + 2 ? 1 : 0; }
+    }
+    if (derive + derive2) gp.nk = gp.nk_min;        // the count table is kept for the SHORTEST window
     const bool s16 = gp.s_fits_i16 != 0;
-    const int nkfv = stream8_variant(gp.n_kfv);
+    const int nkfv = wide ? 5 : stream8_variant(gp.n_kfv);
     int nw = 16, blocks = 1;
-    stream8_geometry(gp.k, s16, nkfv, derive, &nw, &blocks);
+    stream8_geometry(gp.k, s16, nkfv, derive, &nw, &blocks, derive2);
     if (nw < 1) return hipErrorInvalidConfiguration;                  // (static LDS in the kernel: see stream8_geometry)
     // all launches of a scan share one stream table, sized for the launch that keeps the fewest streams resident:
     // use workgroups that fill exactly that many wave slots per CU, so that every CU gets the same number of streams
@@ -1645,8 +1735,13 @@ static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp_in, hi
     }
     const size_t lds = stream8_lds(gp.k, s16, nkfv, nw);
     const unsigned grid = (unsigned)((a.n_tiles + nw - 1) / nw);
-    hipError_t e = hipFuncSetAttribute(stream8_fn_of(gp.k, s16, nkfv, derive), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(stream8_fn_of(gp.k, s16, nkfv, derive, derive2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    if (wide) {
+        ScanArgs a_copy = a;
+        void *args[2] = {&a_copy, &gp};
+        return hipLaunchKernel(stream8_fn_of(gp.k, s16, nkfv, derive, derive2), dim3(grid), dim3(64u * nw), args, lds, st);
+    }
     if (derive) {
         if (gp.k == 5) stream8_launch_derive<5>(nkfv, derive, grid, 64u * nw, lds, st, a, gp);
         else if (gp.k == 7) stream8_launch_derive<7>(nkfv, derive, grid, 64u * nw, lds, st, a, gp);
@@ -1659,8 +1754,13 @@ static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp_in, hi
 }
 
 // streams resident per CU (what the host sizes the streams for); n_ref = largest reference count of the launch's KFVs
-int stream_slots_per_cu(int k, int nk, int nk_min, int n_longer, int n_kfv, int n_sizes, bool s16, int64_t n_ref)
+int stream_slots_per_cu(int k, int nk, int nk_min, int n_longer, int n_kfv, int n_sizes, bool s16, int64_t n_ref, bool u8, int n_plus2)
 {
+    if (stream8_wide_applies(k, nk_min, nk, n_kfv, n_ref, u8)) {      // (n_plus2: KFVs whose window is two k-mers longer than the shortest)
+        int nw = 16, blocks = 1;
+        stream8_geometry(k, true, 5, n_longer - n_plus2, &nw, &blocks, n_plus2);
+        return nw * blocks;
+    }
     const bool derive = n_sizes == 2 && stream8_derive_applies(k, nk_min, nk, n_kfv, n_ref, s16);
     if ((n_sizes == 1 && stream8_applies(k, nk, n_kfv, n_ref, s16)) || derive) {
         int nw = 16, blocks = 1;
@@ -1675,6 +1775,7 @@ hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t s
     {
         int64_t nmax = 0;
         for (int j = 0; j < gp.n_kfv; j++) nmax = gp.N[j] > nmax ? gp.N[j] : nmax;
+        if (gp.s_fits_u8 != 0 && stream8_wide_applies(gp.k, gp.nk_min, gp.nk, gp.n_kfv, nmax, true)) return launch_stream8(a, gp, st, false, true);
         if (gp.n_sizes == 1 && stream8_applies(gp.k, gp.nk, gp.n_kfv, nmax, gp.s_fits_i16 != 0)) return launch_stream8(a, gp, st, false);
         if (gp.n_sizes == 2 && stream8_derive_applies(gp.k, gp.nk_min, gp.nk, gp.n_kfv, nmax, gp.s_fits_i16 != 0)) return launch_stream8(a, gp, st, true);
     }

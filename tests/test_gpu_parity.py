@@ -870,7 +870,67 @@ def test_stream8_derived_windows(ctx, k, lens, monkeypatch):
             assert np.array_equal(dists[j], oD[j] / (2.0 * k * N[j] ** 2)), (derive, j)
         res[derive] = (hits, dips, st["n_launches"])
     assert res["1"][0] == res["0"][0] and res["1"][1] == res["0"][1]
-    assert res["1"][2] < res["0"][2]                                   # fewer launches with derived windows
+    assert res["1"][2] <= res["0"][2] and (res["1"][2] < res["0"][2] or len(lens) == 6)   # fewer launches with derived windows (six KFVs: 4 + 2 either way)
+
+
+@pytest.mark.parametrize("k,lens", [
+    (6, [288, 288, 288, 289, 290]),        # BASELINE configs[3]: one launch instead of {288 x 3, 289} + {290}
+    (6, [288] * 5), (6, [288, 288, 288, 288, 289]), (6, [288, 288, 288, 289, 289]), (6, [120, 120, 121, 121, 121]), (5, [150, 151, 151, 151, 151]),
+    (6, [260, 260, 260, 260, 262]),        # 255 k-mers: the first n + 2 window is lane 0 of the next step
+    (6, [261, 261, 262, 262, 263]),        # 256 k-mers: the first n + 1 window is lane 0 of a step
+    (6, [259, 260, 260, 260, 261]),        # 254 k-mers
+    (6, [100, 100, 100, 102, 102]), (5, [200, 200, 201, 202, 202]), (6, [386, 387, 387, 388, 388]),   # (388: 383 k-mers, the largest window)
+    (5, [131, 131, 131, 132, 133]),        # k = 5, 127 k-mers
+])
+def test_stream8_five_kfv_launch(ctx, k, lens, monkeypatch):
+    """Five KFVs whose windows are within two k-mers of each other, every S below 256: ONE launch of the five-KFV variant
+    of the 8-bit stream kernel (S rows of bytes; windows of n + 1 k-mers from the entering k-mer's count, windows of
+    n + 2 from the n + 1 window of the lane below).  Every distance of every KFV against the integer oracle, hits and
+    dips equal to the launches of at most four (KGMA_STREAM8_WIDE=0)."""
+    from kmergma_amd.fasta import Record
+    from tests.helpers import mutate
+    rng = np.random.default_rng(91 * k + sum(lens) + 7 * lens[3])
+    KFVs, ws, S, N = [], [], [], []
+    genes = []
+    for i, L in enumerate(lens):
+        base = random_dna(rng, L)
+        genes.append(base)
+        refs = [Record(f"g{i}_{u}", mutate(rng, base, 0.03)) for u in range(3 + i)]
+        RV, w, cons, (s, n) = refprep.gen_ref_ws_cons(refs, k, return_int=True)
+        assert w == L and int(np.max(s)) < 256
+        KFVs.append(RV); ws.append(w); S.append(s); N.append(n)
+    maxws = max(ws)
+    g1 = bytearray(_low_complexity_genome(rng, 150_000, maxws))
+    for i, gene in enumerate(genes):                                  # each gene planted a few times (true dips)
+        for pos in (5000 + 9000 * i, 90_000 + 7000 * i):
+            g1[pos:pos + len(gene)] = mutate(rng, gene, 0.05)[:len(gene)]
+    g2 = b"A" * 3000 + random_dna(rng, 3000) + b"AC" * 2000 + random_dna(rng, 40_000) + b"N" * 1000
+    contigs = [bytes(g1), g2, random_dna(rng, maxws + k - 2), random_dna(rng, maxws + k - 1), random_dna(rng, maxws + k), random_dna(rng, maxws + k + 1),
+               genes[-1] + random_dna(rng, 700), genes[0] + genes[3] + genes[4]]
+    thr = [float(np.median([orc.kmer_dist_kfv(random_dna(rng, w), RV, k) for _ in range(10)])) * 0.8 for RV, w in zip(KFVs, ws)]
+    T = [orc.int_threshold(t, k, n) for t, n in zip(thr, N)]
+    ohi, oD = orc.omn_scan_int(contigs, S, N, k, ws, T, 100, 55, return_D=True)
+    assert len(ohi) > 0
+    res = {}
+    for wide in ("1", "0"):
+        monkeypatch.setenv("KGMA_STREAM8_WIDE", wide)
+        ctx.set_refs(k, KFVs, ws, thr, N)
+        gen = ctx.genome_from_host(contigs)
+        ctx.scan(gen, _lib.MODE_OMN, 100, 55, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
+        assert ctx.kernel_name().startswith("stream8_kernel")
+        hits, dips, st = ctx.hits(), ctx.dips(), ctx.stats()
+        dists = [ctx.dists(j + 1) for j in range(len(ws))]
+        # ... and without the distance arrays (the scan's usual form)
+        ctx.scan(gen, _lib.MODE_OMN, 100, 55, _lib.F_NO_TIE_RESOLVE, None)
+        assert ctx.hits() == hits and ctx.dips() == dips
+        gen.free()
+        assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi]
+        assert [h["D"] for h in hits] == [h["D"] for h in ohi]
+        for j in range(len(ws)):
+            assert np.array_equal(dists[j], oD[j] / (2.0 * k * N[j] ** 2)), (wide, j)
+        res[wide] = (hits, dips, st["n_launches"])
+    assert res["1"][0] == res["0"][0] and res["1"][1] == res["0"][1]
+    assert res["1"][2] == 1 and res["0"][2] >= 2
 
 
 def test_lazy_bit_planes_follow_pokes_and_repacks(ctx, alp_ref, genes, monkeypatch):
