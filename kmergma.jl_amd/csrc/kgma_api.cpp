@@ -39,7 +39,7 @@ hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t s
 int stream_waves(int k, int nk, int n_kfv, int n_sizes);
 int stream_slots_per_cu(int k, int nk, int nk_min, int n_longer, int n_kfv, int n_sizes, bool s16, int64_t n_ref, bool u8, int n_plus2);
 bool stream8_derive_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool s16);
-bool stream8_wide_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool u8);
+bool stream8_wide_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool u8, bool s16, int n_plus1, int n_plus2);
 bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16);
 int stream8_variant(int n_kfv);
 hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
@@ -430,18 +430,25 @@ std::vector<Group> make_groups(const kgma_ctx *ctx, int mode, bool s8 = false)
         }
         if (!placed) gs.push_back(Group{W, {j}});
     }
-    // Two neighbouring launches with FIVE KFVs between them, windows within two k-mers of each other and every S below 256:
-    // one launch of the five-KFV variant (stream8_wide_applies; BASELINE configs[3] is {288, 288, 288, 289} + {290})
+    // Two neighbouring launches with FIVE KFVs between them (k = 7: EIGHT), windows within two k-mers of each other (k <= 6: every
+    // S below 256): one launch of the five- / eight-KFV variant (stream8_wide_applies; BASELINE configs[3] is {288, 288, 288, 289} +
+    // {290}, configs[4] {288 x 4} + {289 x 3, 290})
     if (s8)
         for (size_t i = 0; i + 1 < gs.size(); i++) {
             Group &g0 = gs[i];
             const Group &g1 = gs[i + 1];
-            if (g0.kfvs.size() + g1.kfvs.size() != 5) continue;
+            const size_t total = g0.kfvs.size() + g1.kfvs.size();
+            if (total != (ctx->k >= 7 ? 8u : 5u)) continue;
             int64_t nmax = 0, smax = 0;
+            const int64_t w0 = ctx->kfv[(size_t)g0.kfvs.front()].W;
+            int n1 = 0, n2 = 0;
             for (const Group *gp : {static_cast<const Group *>(&g0), &g1})
-                for (int u : gp->kfvs) { nmax = std::max(nmax, ctx->kfv[(size_t)u].N); smax = std::max(smax, ctx->kfv[(size_t)u].Smax); }
-            const int nk0 = (int)(ctx->kfv[(size_t)g0.kfvs.front()].W - ctx->k + 1), nk1 = (int)(g1.W - ctx->k + 1);
-            if (!stream8_wide_applies(ctx->k, nk0, nk1, 5, nmax, smax < 256)) continue;
+                for (int u : gp->kfvs) {
+                    nmax = std::max(nmax, ctx->kfv[(size_t)u].N); smax = std::max(smax, ctx->kfv[(size_t)u].Smax);
+                    n1 += ctx->kfv[(size_t)u].W == w0 + 1 ? 1 : 0; n2 += ctx->kfv[(size_t)u].W == w0 + 2 ? 1 : 0;
+                }
+            const int nk0 = (int)(w0 - ctx->k + 1), nk1 = (int)(g1.W - ctx->k + 1);
+            if (!stream8_wide_applies(ctx->k, nk0, nk1, (int)total, nmax, smax < 256, smax <= 32767, n1, n2)) continue;
             g0.kfvs.insert(g0.kfvs.end(), g1.kfvs.begin(), g1.kfvs.end());
             g0.W = g1.W;
             gs.erase(gs.begin() + (long)i + 1);
@@ -1531,7 +1538,10 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     auto group_nk_min = [&](const Group &gr) { return (int)(ctx->kfv[(size_t)gr.kfvs.front()].W - k + 1); };
     auto group_u8 = [&](const Group &gr) { bool ok = true; for (int j : gr.kfvs) ok = ok && ctx->kfv[(size_t)j].Smax < 256; return ok; };
     auto group_wide = [&](const Group &gr) {
-        return stream8_wide_applies(k, group_nk_min(gr), (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_u8(gr));
+        const int64_t w0 = ctx->kfv[(size_t)gr.kfvs.front()].W;
+        int n1 = 0, n2 = 0;
+        for (int j : gr.kfvs) { n1 += ctx->kfv[(size_t)j].W == w0 + 1 ? 1 : 0; n2 += ctx->kfv[(size_t)j].W == w0 + 2 ? 1 : 0; }
+        return stream8_wide_applies(k, group_nk_min(gr), (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_u8(gr), group_s16(gr), n1, n2);
     };
     auto group_s8 = [&](const Group &gr) {
         if (group_wide(gr)) return true;

@@ -541,8 +541,9 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
     // The KFVs of a launch are sorted by window size: NKFV - ND - ND2 of n k-mers (the count table's), then ND of n + 1,
     // then ND2 of n + 2 (five-KFV variant only).
     constexpr bool DERIVE = ND + ND2 > 0;
-    static_assert(!DERIVE || (NKFV >= 2 && NKFV <= 5 && ND + ND2 < NKFV && S16), "derived windows: 2-5 KFVs with 16-bit (or 8-bit) S tables");
-    static_assert(ND2 == 0 || NKFV == 5, "windows two k-mers longer: the five-KFV variant");
+    static_assert(!DERIVE || (((NKFV >= 2 && NKFV <= 5) || (NKFV == 8 && K >= 7)) && ND + ND2 < NKFV && S16),
+                  "derived windows: 2-5 KFVs (k = 7: also 8, launched full) with 16-bit (or 8-bit) S tables");
+    static_assert(ND2 == 0 || NKFV == 5 || NKFV == 8, "windows two k-mers longer: the five- and eight-KFV variants");
     // NKFV = 5: S rows of eight BYTES (every S of the launch < 256, checked on the host): the rows of five KFVs take the
     // 32 KiB that four int16 KFVs take, so the launch keeps the residency of a four-KFV launch
     constexpr bool SBYTE = NKFV == 5;
@@ -560,7 +561,10 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
         asm volatile("" : "+s"(ka));
         gpp = reinterpret_cast<const GroupParams *>(ka);
     }
-    const int n_kfv = NKFV < 8 ? NKFV : gp.n_kfv;                      // KFVs of this launch, all of ONE window size (variants 1-4 are launched full)
+    // KFVs of this launch (variants 1-5 are launched full; the eight-KFV variant takes 5-8 KFVs of ONE window size, or -- with
+    // derived windows -- exactly eight)
+    constexpr bool FULL = NKFV < 8 || ND + ND2 > 0;
+    const int n_kfv = FULL ? NKFV : gp.n_kfv;
     constexpr int NB = 1 << (2 * K);
     extern __shared__ uint32_t smem[];
 
@@ -1026,7 +1030,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
         for (int j = 0; j < NKFV; j++) {
             sc[j] = 0;
             if constexpr (DERIVE) ev[j] = 0;
-            if (NKFV == 8 && j >= n_kfv) continue;                    // (smaller variants are launched full)
+            if (!FULL && j >= n_kfv) continue;                        // (smaller variants are launched full)
             int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
             const int32_t Nj = gp.N[j];
             // GenomeMiner.jl:67-68 times 2kN^2 / 2N.  Without a transition the two k-mers are equal (Sl == Sr,
@@ -1184,12 +1188,11 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
             d2_prev_ks = (uint32_t)__builtin_amdgcn_readlane((int)ks, 63);
         }
         int32_t E[NKFV];
-        uint64_t Um[NKFV];
-        uint64_t anyU = 0;
+        uint64_t anyU = 0;                                            // (the KFVs' masks are formed again on the cold path: not kept in scalar registers)
 #pragma unroll
         for (int j = 0; j < NKFV; j++) {
-            E[j] = 0; Um[j] = 0;
-            if (NKFV == 8 && j >= n_kfv) continue;
+            E[j] = 0;
+            if (!FULL && j >= n_kfv) continue;
             E[j] = sc[j] + h_carry[j];
             h_carry[j] = __builtin_amdgcn_readlane(E[j], 63);
             if (ND2 > 0 && ((dm2 >> j) & 1u)) {
@@ -1218,7 +1221,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
                 }
                 d2_prevX[jj] = __builtin_amdgcn_readlane(X1, 63);
                 E[j] = X;
-                Um[j] = __builtin_amdgcn_sicmp(E[j], h_TE[j], 40 /* slt */) & TESTED_D2;
+                anyU |= __builtin_amdgcn_sicmp(E[j], h_TE[j], 40 /* slt */) & TESTED_D2;
             } else if (DERIVE && ((dm1 >> j) & 1u)) {
                 // E of this lane's pre-transition window, plus the entering k-mer's term
                 int32_t X = E[j] - ev[j] + (__mul24(gp.N[j], cP) - Sr[j]);
@@ -1236,11 +1239,10 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
                     }
                 }
                 E[j] = X;
-                Um[j] = __builtin_amdgcn_sicmp(E[j], h_TE[j], 40 /* slt */) & TESTED_D;
+                anyU |= __builtin_amdgcn_sicmp(E[j], h_TE[j], 40 /* slt */) & TESTED_D;
             } else {
-                Um[j] = __builtin_amdgcn_sicmp(E[j], h_TE[j], 40 /* slt */) & TESTED;
+                anyU |= __builtin_amdgcn_sicmp(E[j], h_TE[j], 40 /* slt */) & TESTED;
             }
-            anyU |= Um[j];
         }
         if (dist_mask != 0) {
 #pragma unroll
@@ -1257,11 +1259,11 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
 
 #pragma unroll
         for (int j = 0; j < NKFV; j++) {
-            if (NKFV == 8 && j >= n_kfv) continue;
+            if (!FULL && j >= n_kfv) continue;
             int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
             const int32_t Ej = E[j];
-            uint64_t U = Um[j];                                        // tested windows below TE + natt
             const int dj = DERIVE ? (int)((dm1 >> j) & 1u) + 2 * (int)((dm2 >> j) & 1u) : 0;
+            uint64_t U = __builtin_amdgcn_sicmp(Ej, h_TE[j], 40 /* slt */) & (dj == 2 ? TESTED_D2 : dj ? TESTED_D : TESTED);   // tested windows below TE + natt
             uint64_t A = 0;
             if (((att_mask >> j) & 1u) && U != 0) {                    // (only when the threshold sits on the distance lattice)
                 const uint64_t below = __builtin_amdgcn_sicmp(Ej, uni(st[ST_TE]), 40 /* slt */);
@@ -1467,10 +1469,19 @@ static bool stream8_wide_env_on()
     const char *e = getenv("KGMA_STREAM8_WIDE");
     return !(e && atoi(e) == 0);
 }
-bool stream8_wide_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool u8)
+static const void *stream8_fn_of(int k, bool s16, int nkfv, int nd, int nd2);
+// (n_plus1 / n_plus2: KFVs whose window is one / two k-mers longer than the launch's shortest; u8: every S below 256.)
+// k = 7: EIGHT KFVs in one launch the same way (int16 rows in global memory as in every k = 7 launch) -- BASELINE
+// configs[4] (288 x 4, 289 x 3, 290) in one pass over the genome instead of two.
+bool stream8_wide_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool u8, bool s16, int n_plus1, int n_plus2)
 {
-    return stream8_wide_env_on() && n_kfv == 5 && u8 && (k == 5 || k == 6) && nk_max - nk_min <= 2 && (nk_max == nk_min || stream8_derive_env_on()) &&
-           stream8_applies(k, nk_max, n_kfv, n_ref, true);
+    if (!stream8_wide_env_on() || nk_max - nk_min > 2 || n_plus1 < 0 || n_plus2 < 0) return false;
+    if (nk_max != nk_min && !stream8_derive_env_on()) return false;
+    if ((k == 5 || k == 6) && n_kfv == 5 && u8)
+        return stream8_applies(k, nk_max, n_kfv, n_ref, true) && stream8_fn_of(k, true, 5, n_plus1, n_plus2) != nullptr;
+    if (k == 7 && n_kfv == 8 && s16 && n_plus1 + n_plus2 > 0)         // (one window size: the plain eight-KFV variant)
+        return stream8_applies(k, nk_max, n_kfv, n_ref, true) && stream8_fn_of(k, true, 8, n_plus1, n_plus2) != nullptr;
+    return false;
 }
 
 template <int K>
@@ -1481,6 +1492,17 @@ static const void *stream8_fn_wide(int nd, int nd2)
     KGMA_WIDE(0, 0) KGMA_WIDE(1, 0) KGMA_WIDE(2, 0) KGMA_WIDE(3, 0) KGMA_WIDE(4, 0)
     KGMA_WIDE(0, 1) KGMA_WIDE(1, 1) KGMA_WIDE(2, 1) KGMA_WIDE(3, 1)
     KGMA_WIDE(0, 2) KGMA_WIDE(1, 2) KGMA_WIDE(2, 2)
+    default: return nullptr;
+    }
+#undef KGMA_WIDE
+}
+
+static const void *stream8_fn_wide8(int nd, int nd2)                  // k = 7, eight KFVs
+{
+#define KGMA_WIDE(D1, D2) case (D2) * 8 + (D1): return reinterpret_cast<const void *>(&stream8_kernel<7, true, 8, D1, false, D2>);
+    switch (nd2 * 8 + nd) {
+    KGMA_WIDE(1, 0) KGMA_WIDE(2, 0) KGMA_WIDE(3, 0) KGMA_WIDE(4, 0)
+    KGMA_WIDE(0, 1) KGMA_WIDE(1, 1) KGMA_WIDE(2, 1) KGMA_WIDE(3, 1) KGMA_WIDE(4, 1)
     default: return nullptr;
     }
 #undef KGMA_WIDE
@@ -1513,7 +1535,8 @@ static const void *stream8_fn_k(int nkfv)
 
 static const void *stream8_fn_of(int k, bool s16, int nkfv, int nd = 0, int nd2 = 0)       // nd / nd2: KFVs with a window one / two k-mers longer
 {
-    if (nkfv == 5) return k == 5 ? stream8_fn_wide<5>(nd, nd2) : stream8_fn_wide<6>(nd, nd2);
+    if (nkfv == 5) return k == 5 ? stream8_fn_wide<5>(nd, nd2) : k == 6 ? stream8_fn_wide<6>(nd, nd2) : nullptr;
+    if (nkfv == 8 && nd + nd2 > 0) return k == 7 ? stream8_fn_wide8(nd, nd2) : nullptr;
     if (nd > 0) return k == 5 ? stream8_fn_derive<5>(nkfv, nd) : k == 7 ? stream8_fn_derive<7>(nkfv, nd) : stream8_fn_derive<6>(nkfv, nd);
     if (k == 5) return s16 ? stream8_fn_k<5, true>(nkfv) : stream8_fn_k<5, false>(nkfv);
     if (k == 7) return stream8_fn_k<7, true>(nkfv);
@@ -1722,7 +1745,7 @@ static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp_in, hi
     }
     if (derive + derive2) gp.nk = gp.nk_min;        // the count table is kept for the SHORTEST window
     const bool s16 = gp.s_fits_i16 != 0;
-    const int nkfv = wide ? 5 : stream8_variant(gp.n_kfv);
+    const int nkfv = wide ? gp.n_kfv : stream8_variant(gp.n_kfv);   // (wide: five KFVs at k <= 6, eight at k = 7)
     int nw = 16, blocks = 1;
     stream8_geometry(gp.k, s16, nkfv, derive, &nw, &blocks, derive2);
     if (nw < 1) return hipErrorInvalidConfiguration;                  // (static LDS in the kernel: see stream8_geometry)
@@ -1756,9 +1779,9 @@ static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp_in, hi
 // streams resident per CU (what the host sizes the streams for); n_ref = largest reference count of the launch's KFVs
 int stream_slots_per_cu(int k, int nk, int nk_min, int n_longer, int n_kfv, int n_sizes, bool s16, int64_t n_ref, bool u8, int n_plus2)
 {
-    if (stream8_wide_applies(k, nk_min, nk, n_kfv, n_ref, u8)) {      // (n_plus2: KFVs whose window is two k-mers longer than the shortest)
+    if (stream8_wide_applies(k, nk_min, nk, n_kfv, n_ref, u8, s16, n_longer - n_plus2, n_plus2)) {   // (n_plus2: KFVs whose window is two k-mers longer than the shortest)
         int nw = 16, blocks = 1;
-        stream8_geometry(k, true, 5, n_longer - n_plus2, &nw, &blocks, n_plus2);
+        stream8_geometry(k, true, n_kfv, n_longer - n_plus2, &nw, &blocks, n_plus2);
         return nw * blocks;
     }
     const bool derive = n_sizes == 2 && stream8_derive_applies(k, nk_min, nk, n_kfv, n_ref, s16);
@@ -1775,7 +1798,9 @@ hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t s
     {
         int64_t nmax = 0;
         for (int j = 0; j < gp.n_kfv; j++) nmax = gp.N[j] > nmax ? gp.N[j] : nmax;
-        if (gp.s_fits_u8 != 0 && stream8_wide_applies(gp.k, gp.nk_min, gp.nk, gp.n_kfv, nmax, true)) return launch_stream8(a, gp, st, false, true);
+        int n1 = 0, n2 = 0;
+        for (int j = 0; j < gp.n_kfv; j++) { n1 += gp.nk_of[j] == gp.nk_min + 1 ? 1 : 0; n2 += gp.nk_of[j] == gp.nk_min + 2 ? 1 : 0; }
+        if (stream8_wide_applies(gp.k, gp.nk_min, gp.nk, gp.n_kfv, nmax, gp.s_fits_u8 != 0, gp.s_fits_i16 != 0, n1, n2)) return launch_stream8(a, gp, st, false, true);
         if (gp.n_sizes == 1 && stream8_applies(gp.k, gp.nk, gp.n_kfv, nmax, gp.s_fits_i16 != 0)) return launch_stream8(a, gp, st, false);
         if (gp.n_sizes == 2 && stream8_derive_applies(gp.k, gp.nk_min, gp.nk, gp.n_kfv, nmax, gp.s_fits_i16 != 0)) return launch_stream8(a, gp, st, true);
     }

@@ -881,12 +881,15 @@ def test_stream8_derived_windows(ctx, k, lens, monkeypatch):
     (6, [259, 260, 260, 260, 261]),        # 254 k-mers
     (6, [100, 100, 100, 102, 102]), (5, [200, 200, 201, 202, 202]), (6, [386, 387, 387, 388, 388]),   # (388: 383 k-mers, the largest window)
     (5, [131, 131, 131, 132, 133]),        # k = 5, 127 k-mers
+    (7, [288, 288, 288, 288, 289, 289, 289, 290]),   # BASELINE configs[4]: eight KFVs at k = 7, one launch instead of {288 x 4} + {289 x 3, 290}
+    (7, [134, 134, 134, 135, 135, 135, 135, 136]), (7, [133, 133, 133, 133, 133, 133, 133, 135]), (7, [200, 200, 200, 200, 200, 200, 201, 201]),
+    (7, [261, 261, 261, 261, 262, 262, 262, 262]),   # 255 k-mers
 ])
 def test_stream8_five_kfv_launch(ctx, k, lens, monkeypatch):
-    """Five KFVs whose windows are within two k-mers of each other, every S below 256: ONE launch of the five-KFV variant
-    of the 8-bit stream kernel (S rows of bytes; windows of n + 1 k-mers from the entering k-mer's count, windows of
-    n + 2 from the n + 1 window of the lane below).  Every distance of every KFV against the integer oracle, hits and
-    dips equal to the launches of at most four (KGMA_STREAM8_WIDE=0)."""
+    """Five KFVs (k = 7: eight) whose windows are within two k-mers of each other (k <= 6: every S below 256): ONE launch of
+    the five- / eight-KFV variant of the 8-bit stream kernel (k <= 6: S rows of bytes; windows of n + 1 k-mers from the
+    entering k-mer's count, windows of n + 2 from the n + 1 window of the lane below).  Every distance of every KFV
+    against the integer oracle, hits and dips equal to the launches of at most four (KGMA_STREAM8_WIDE=0)."""
     from kmergma_amd.fasta import Record
     from tests.helpers import mutate
     rng = np.random.default_rng(91 * k + sum(lens) + 7 * lens[3])
@@ -897,7 +900,7 @@ def test_stream8_five_kfv_launch(ctx, k, lens, monkeypatch):
         genes.append(base)
         refs = [Record(f"g{i}_{u}", mutate(rng, base, 0.03)) for u in range(3 + i)]
         RV, w, cons, (s, n) = refprep.gen_ref_ws_cons(refs, k, return_int=True)
-        assert w == L and int(np.max(s)) < 256
+        assert w == L and (k == 7 or int(np.max(s)) < 256)
         KFVs.append(RV); ws.append(w); S.append(s); N.append(n)
     maxws = max(ws)
     g1 = bytearray(_low_complexity_genome(rng, 150_000, maxws))
@@ -906,7 +909,7 @@ def test_stream8_five_kfv_launch(ctx, k, lens, monkeypatch):
             g1[pos:pos + len(gene)] = mutate(rng, gene, 0.05)[:len(gene)]
     g2 = b"A" * 3000 + random_dna(rng, 3000) + b"AC" * 2000 + random_dna(rng, 40_000) + b"N" * 1000
     contigs = [bytes(g1), g2, random_dna(rng, maxws + k - 2), random_dna(rng, maxws + k - 1), random_dna(rng, maxws + k), random_dna(rng, maxws + k + 1),
-               genes[-1] + random_dna(rng, 700), genes[0] + genes[3] + genes[4]]
+               genes[-1] + random_dna(rng, 700), genes[0] + genes[3] + genes[-1]]
     thr = [float(np.median([orc.kmer_dist_kfv(random_dna(rng, w), RV, k) for _ in range(10)])) * 0.8 for RV, w in zip(KFVs, ws)]
     T = [orc.int_threshold(t, k, n) for t, n in zip(thr, N)]
     ohi, oD = orc.omn_scan_int(contigs, S, N, k, ws, T, 100, 55, return_D=True)
