@@ -20,6 +20,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <functional>
 #include <thread>
 #include <string>
 #include <vector>
@@ -201,12 +202,17 @@ struct kgma_ctx {
     TileDesc *d_ctiles = nullptr; int64_t ctiles_cap = 0;
     ChainChunk *d_cchunks = nullptr; int64_t cchunks_cap = 0;
     ChainChunk *d_cpool = nullptr; int64_t cpool_cap = 0;                // units of 16 bytes
+    ChainChunk *d_cchunks2 = nullptr; int64_t cchunks2_cap = 0;          // second output set: batch i comes down (copy stream) while batch i + 1 runs
+    ChainChunk *d_cpool2 = nullptr; int64_t cpool2_cap = 0;
+    int64_t *d_cD02 = nullptr; int64_t cD02_cap = 0;
+    hipStream_t chain_copy_stream = nullptr;
     uint32_t *d_chot = nullptr; int64_t chot_cap = 0;                    // [hot bit words | prefix per word]
     uint64_t *d_chmask = nullptr; int64_t chmask_cap = 0;                // hot steps of each hot chunk
     double cpool_per_step = 0;                                           // pool units per step the last chain launches needed beyond their hot steps
     int64_t *d_cD0 = nullptr; int64_t cD0_cap = 0;
     unsigned int *d_cctl = nullptr;
     uint8_t *h_cpin = nullptr; size_t cpin_cap = 0;
+    uint8_t *h_cpin2 = nullptr; size_t cpin2_cap = 0;      // second download buffer: batch i + 1 comes down while the host walks batch i
     uint64_t next_uid = 1;
     // key of the tile table currently on the device
     uint64_t tk_uid = 0, tk_version = 0; int tk_mode = -1, tk_k = 0; int64_t tk_maxws = 0;
@@ -566,11 +572,16 @@ void kgma_destroy(kgma_ctx *ctx)
     if (ctx->d_ctiles) (void)hipFree(ctx->d_ctiles);
     if (ctx->d_cchunks) (void)hipFree(ctx->d_cchunks);
     if (ctx->d_cpool) (void)hipFree(ctx->d_cpool);
+    if (ctx->d_cchunks2) (void)hipFree(ctx->d_cchunks2);
+    if (ctx->d_cpool2) (void)hipFree(ctx->d_cpool2);
+    if (ctx->d_cD02) (void)hipFree(ctx->d_cD02);
+    if (ctx->chain_copy_stream) (void)hipStreamDestroy(ctx->chain_copy_stream);
     if (ctx->d_chmask) (void)hipFree(ctx->d_chmask);
     if (ctx->d_chot) (void)hipFree(ctx->d_chot);
     if (ctx->d_cD0) (void)hipFree(ctx->d_cD0);
     if (ctx->d_cctl) (void)hipFree(ctx->d_cctl);
     if (ctx->h_cpin) (void)hipHostFree(ctx->h_cpin);
+    if (ctx->h_cpin2) (void)hipHostFree(ctx->h_cpin2);
     if (ctx->d_gath) (void)hipFree(ctx->d_gath);
     if (ctx->evp0) (void)hipEventDestroy(ctx->evp0);
     if (ctx->evp1) (void)hipEventDestroy(ctx->evp1);
@@ -2421,7 +2432,7 @@ static bool chain_device_enabled()
 }
 
 static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vector<ChainPair> &pairs, std::vector<size_t> el, std::vector<char> &done,
-                                 ChainDevInfo &info, bool export_only = false);
+                                 ChainDevInfo &info, bool export_only = false, int pin_sel = 0, std::function<int()> *deferred = nullptr);
 
 static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<ChainPair> &pairs, std::vector<char> &done, ChainDevInfo &info)
 {
@@ -2437,22 +2448,50 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
     }
     if (el.empty()) return KGMA_OK;
     (void)hipSetDevice(ctx->device);
-    // batches of bounded size (2^36 windows: a chunk array of 256 MiB), in record order
-    int64_t BATCH_WINDOWS = (int64_t)1 << 36;
+    // batches of bounded size (2^35 windows: a chunk array of 128 MiB), in record order; the host part of a batch overlaps
+    // the device part of the next, so what stays exposed is the LAST batch's host part: smaller batches, shorter tail
+    // (config 5, 2.5e11 windows, 1.31 s of kernels: 1577 ms with 2^36, 1499 ms with 2^35, 1542 ms with 2^34)
+    int64_t BATCH_WINDOWS = (int64_t)1 << 35;
     if (const char *e = getenv("KGMA_CHAIN_BATCH_WINDOWS")) BATCH_WINDOWS = std::max<int64_t>(1, atoll(e));   // tests
+    // The host part of a batch (first windows, chunk walks) runs on a worker while the device works on the next batch;
+    // two pinned download buffers alternate.  (At most one worker at a time: it is joined before the next one starts.)
+    struct Worker {
+        std::thread th;
+        int rc = KGMA_OK;
+        int join() { if (th.joinable()) th.join(); const int r = rc; rc = KGMA_OK; return r; }
+        ~Worker() { if (th.joinable()) th.join(); }
+    } worker;
+    int sel = 0;
     for (size_t u0 = 0; u0 < el.size();) {
         size_t u1 = u0;
         int64_t w = 0;
         while (u1 < el.size() && (u1 == u0 || w + pairs[el[u1]].last <= BATCH_WINDOWS)) w += pairs[el[u1++]].last;
-        const int rc = chain_on_device_batch(ctx, g, pairs, std::vector<size_t>(el.begin() + (long)u0, el.begin() + (long)u1), done, info);
+        std::function<int()> fin;
+        const bool more = u1 < el.size() || worker.th.joinable();
+        const double tb0 = now_ms();
+        const int rc = chain_on_device_batch(ctx, g, pairs, std::vector<size_t>(el.begin() + (long)u0, el.begin() + (long)u1), done, info, false, sel,
+                                             more ? &fin : nullptr);
+        const double tb1 = now_ms();
+        const int wrc = worker.join();
+        if (getenv("KGMA_CHAIN_DEBUG")) fprintf(stderr, "  chain batch: device part %.2f ms, then %.2f ms waiting for the previous batch's host part\n", tb1 - tb0, now_ms() - tb1);
         if (rc) return rc;
+        if (wrc) return fail(ctx, wrc, "internal: first window of a chained record");
+        if (fin) {
+            Worker *wk = &worker;
+            worker.th = std::thread([wk, fin = std::move(fin)]() mutable { wk->rc = fin(); });
+        }
+        sel ^= 1;
         u0 = u1;
     }
+    const double tj0 = now_ms();
+    const int wrc = worker.join();
+    if (getenv("KGMA_CHAIN_DEBUG")) fprintf(stderr, "  chain: %.2f ms waiting for the last batch's host part\n", now_ms() - tj0);
+    if (wrc) return fail(ctx, wrc, "internal: first window of a chained record");
     return KGMA_OK;
 }
 
 static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vector<ChainPair> &pairs, std::vector<size_t> el, std::vector<char> &done,
-                                 ChainDevInfo &info, bool export_only)
+                                 ChainDevInfo &info, bool export_only, int pin_sel, std::function<int()> *deferred)
 {
     const int k = ctx->k;
     const int64_t NB = (int64_t)1 << (2 * k);
@@ -2618,13 +2657,21 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
 
     int rc = dev_reserve(ctx, ctx->d_ctiles, ctx->ctiles_cap, n_tiles);
     if (rc) return rc;
-    rc = dev_reserve(ctx, ctx->d_cchunks, ctx->cchunks_cap, n_chunks);
+    // (output buffers and download buffer number pin_sel: the other set may still be on its way to the host)
+    ChainChunk *&d_cchunks = pin_sel ? ctx->d_cchunks2 : ctx->d_cchunks;
+    int64_t &cchunks_cap = pin_sel ? ctx->cchunks2_cap : ctx->cchunks_cap;
+    ChainChunk *&d_cpool = pin_sel ? ctx->d_cpool2 : ctx->d_cpool;
+    int64_t &cpool_cap = pin_sel ? ctx->cpool2_cap : ctx->cpool_cap;
+    int64_t *&d_cD0 = pin_sel ? ctx->d_cD02 : ctx->d_cD0;
+    int64_t &cD0_cap = pin_sel ? ctx->cD02_cap : ctx->cD0_cap;
+    if (!ctx->chain_copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->chain_copy_stream, hipStreamNonBlocking));
+    rc = dev_reserve(ctx, d_cchunks, cchunks_cap, n_chunks);
     if (rc) return rc;
     rc = dev_reserve(ctx, ctx->d_chot, ctx->chot_cap, (int64_t)hot.size());
     if (rc) return rc;
     rc = dev_reserve(ctx, ctx->d_chmask, ctx->chmask_cap, (int64_t)hot_masks.size());
     if (rc) return rc;
-    rc = dev_reserve(ctx, ctx->d_cD0, ctx->cD0_cap, (int64_t)d0_total);
+    rc = dev_reserve(ctx, d_cD0, cD0_cap, (int64_t)d0_total);
     if (rc) return rc;
     if (!ctx->d_cctl) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_cctl), 16));
 
@@ -2635,7 +2682,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
     info.chunks += n_chunks;
     const int64_t full_units = total_steps * 33 + n_chunks + 64;       // every step raw
     const int64_t hot_units = hot_steps * 32 + hot_chunks * KGMA_CHAIN_STEPS;
-    int64_t pool_units = hot_units + std::max<int64_t>(1 << 18, std::min<int64_t>(total_steps / 8, (int64_t)1 << 28));
+    int64_t pool_units = hot_units + std::max<int64_t>(1 << 18, std::min<int64_t>(total_steps / 3, (int64_t)1 << 29));
     if (ctx->cpool_per_step > 0)                                       // (what the previous scans of this context needed, with a margin)
         pool_units = std::max(pool_units, hot_units + (int64_t)(1.25 * ctx->cpool_per_step * (double)total_steps) + (1 << 16));
     if (const char *e = getenv("KGMA_CHAIN_POOL_UNITS")) pool_units = std::max<int64_t>(1, atoll(e));   // tests: force the regrowth
@@ -2643,12 +2690,12 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
         info.attempts = std::max(info.attempts, attempt + 1);
         pool_units = std::min<int64_t>(pool_units, full_units);
         if (pool_units > 0xFFFFFFF0ll) return KGMA_OK;
-        if (ctx->cpool_cap < pool_units) {
+        if (cpool_cap < pool_units) {
             ChainChunk *fresh = nullptr;
             int64_t cap = 0;
             if (dev_reserve(ctx, fresh, cap, pool_units) != KGMA_OK) { ctx->err.clear(); (void)hipGetLastError(); return KGMA_OK; }   // no room: host chain
-            if (ctx->d_cpool) { (void)hipFree(ctx->d_cpool); ctx->device_bytes -= ctx->cpool_cap * (int64_t)sizeof(ChainChunk); }
-            ctx->d_cpool = fresh; ctx->cpool_cap = cap;
+            if (d_cpool) { (void)hipFree(d_cpool); ctx->device_bytes -= cpool_cap * (int64_t)sizeof(ChainChunk); }
+            d_cpool = fresh; cpool_cap = cap;
         }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ctiles, tiles.data(), (size_t)n_tiles * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_chot, hot.data(), hot.size() * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -2697,10 +2744,10 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
                 }
                 a.Sinter = it->second;
             }
-            a.D0out = ctx->d_cD0 + L.d0_off;                       // [KFV][stream of this launch]
+            a.D0out = d_cD0 + L.d0_off;                       // [KFV][stream of this launch]
             a.n_chunk_tiles = a.n_tiles;
-            a.chain.chunks = ctx->d_cchunks;
-            a.chain.pool = ctx->d_cpool;
+            a.chain.chunks = d_cchunks;
+            a.chain.pool = d_cpool;
             a.chain.pool_cursor = ctx->d_cctl;
             a.chain.pool_cap = (unsigned int)pool_units;
             a.chain.hot = ctx->d_chot;
@@ -2719,9 +2766,13 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
         float ms = 0;
         (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
         info.kernel_ms += ms;
+        if (getenv("KGMA_CHAIN_DEBUG"))
+            fprintf(stderr, "  chain batch: %zu pairs, %lld steps, %lld hot units, pool of %lld units, %u asked for%s, attempt %d, kernels %.2f ms\n", el.size(),
+                    (long long)total_steps, (long long)hot_units, (long long)pool_units, ctl[0], (ctl[1] & 1u) ? " (ran out)" : "", attempt, ms);
         if (!(ctl[1] & 1u)) {
             pool_units = std::min<int64_t>(pool_units, (int64_t)ctl[0]);
-            ctx->cpool_per_step = std::max(0.0, (double)(pool_units - hot_units)) / (double)std::max<int64_t>(1, total_steps);
+            // (the densest batch this context has seen: a launch that runs out of pool is a launch repeated)
+            ctx->cpool_per_step = std::max(ctx->cpool_per_step, std::max(0.0, (double)(pool_units - hot_units)) / (double)std::max<int64_t>(1, total_steps));
             break;
         }
         if (attempt >= 1 || pool_units >= full_units) return KGMA_OK;                 // (cannot happen: the second pool is what the first launch asked for)
@@ -2743,23 +2794,34 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
     for (Rec &r : recs) { r.dw_off = first_dw; first_dw += r.dw + 2; }
     const size_t off_D0 = 0, off_chunks = off_D0 + d0_total * 8, off_raw = off_chunks + (size_t)n_chunks * sizeof(ChainChunk),
                  off_first = off_raw + (size_t)pool_units * sizeof(ChainChunk), pin_need = off_first + first_dw * 4 + 64;
-    if (pin_need > ctx->cpin_cap) {
-        if (ctx->h_cpin) (void)hipHostFree(ctx->h_cpin);
-        ctx->h_cpin = nullptr; ctx->cpin_cap = 0;
+    uint8_t *&pin_buf = pin_sel ? ctx->h_cpin2 : ctx->h_cpin;        // (its previous user, two batches ago, has been joined)
+    size_t &pin_cap = pin_sel ? ctx->cpin2_cap : ctx->cpin_cap;
+    if (pin_need > pin_cap) {
+        if (pin_buf) (void)hipHostFree(pin_buf);
+        pin_buf = nullptr; pin_cap = 0;
         const size_t cap = pin_need + (pin_need >> 2);
-        if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_cpin), cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return KGMA_OK; }
-        ctx->cpin_cap = cap;
+        if (hipHostMalloc(reinterpret_cast<void **>(&pin_buf), cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return KGMA_OK; }
+        pin_cap = cap;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_D0, ctx->d_cD0, d0_total * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_chunks, ctx->d_cchunks, (size_t)n_chunks * sizeof(ChainChunk), hipMemcpyDeviceToHost, ctx->stream));
+    uint8_t *const pin = pin_buf;
+    // (the launches have finished: the copies go to their own stream, and the worker below waits for them, so that the next
+    //  batch's launches -- into the other set of buffers -- run while this batch comes down)
+    hipStream_t cs = ctx->chain_copy_stream;
+    HIP_TRY(ctx, hipMemcpyAsync(pin + off_D0, d_cD0, d0_total * 8, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(ctx, hipMemcpyAsync(pin + off_chunks, d_cchunks, (size_t)n_chunks * sizeof(ChainChunk), hipMemcpyDeviceToHost, cs));
     if (pool_units > 0)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_raw, ctx->d_cpool, (size_t)pool_units * sizeof(ChainChunk), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(pin + off_raw, d_cpool, (size_t)pool_units * sizeof(ChainChunk), hipMemcpyDeviceToHost, cs));
     for (const Rec &r : recs)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cpin + off_first + r.dw_off * 4, g->d_inter + 2 * g->cd[(size_t)r.c].word_off, r.dw * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, sync_spin(ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(pin + off_first + r.dw_off * 4, g->d_inter + 2 * g->cd[(size_t)r.c].word_off, r.dw * 4, hipMemcpyDeviceToHost, cs));
+    const int device = ctx->device;
+    // ---- host part: first windows and chunk walks (on a worker when more batches follow) ----
+    auto finish = [=, &pairs, &done, &info, streams = std::move(streams), stream_d0 = std::move(stream_d0), el = std::move(el), ps = std::move(ps),
+                   recs = std::move(recs)]() mutable -> int {
+    (void)hipSetDevice(device);
+    if (hipStreamSynchronize(cs) != hipSuccess) return (int)KGMA_E_HIP;
+    info.copy_ms += now_ms() - tc0;
     const double tw0 = now_ms();
-    info.copy_ms += tw0 - tc0;
-    const int64_t *h_D0 = reinterpret_cast<const int64_t *>(ctx->h_cpin + off_D0);
+    const int64_t *h_D0 = reinterpret_cast<const int64_t *>(pin + off_D0);
     for (size_t t = 0; t < streams.size(); t++) streams[t].D0 = h_D0[stream_d0[t]];
 
     // the chain's value at window 1: kmer_count! + sqeuclidean of the first window (GenomeMiner.jl:42-47), on the host
@@ -2773,17 +2835,17 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
             size_t off = 0;
             for (const Rec &r : recs) if (r.c == p.c) off = r.dw_off;
             ChainJob &J = jobs[u];
-            J.seq = nullptr; J.packed = reinterpret_cast<const uint32_t *>(ctx->h_cpin + off_first) + off; J.n_res = f.W; J.ref = f.ref.data();
+            J.seq = nullptr; J.packed = reinterpret_cast<const uint32_t *>(pin + off_first) + off; J.n_res = f.W; J.ref = f.ref.data();
             J.k = k; J.W = f.W; J.last_window = 1; J.iv = &one; J.n_iv = 1; J.out = &first[u]; J.n_out = 0; J.ok = false;
         }
         run_chain_jobs(jobs.data(), jobs.size(), 1);
         for (size_t u = 0; u < el.size(); u++)
-            if (!jobs[u].ok) return fail(ctx, KGMA_E_HIP, "internal: first window of record %d KFV %d", pairs[el[u]].c, pairs[el[u]].j + 1);
+            if (!jobs[u].ok) return (int)KGMA_E_HIP;
     }
     if (export_only) {
         // (kgma_chain_export: one pair; its material goes to the caller, who walks it where the whole record's pieces meet)
         ctx->cx_streams.assign(streams.begin(), streams.end());
-        const ChainChunk *hc = reinterpret_cast<const ChainChunk *>(ctx->h_cpin + off_chunks), *hp = reinterpret_cast<const ChainChunk *>(ctx->h_cpin + off_raw);
+        const ChainChunk *hc = reinterpret_cast<const ChainChunk *>(pin + off_chunks), *hp = reinterpret_cast<const ChainChunk *>(pin + off_raw);
         ctx->cx_chunks.assign(hc, hc + n_chunks);
         ctx->cx_pool.assign(hp, hp + pool_units);
         ctx->cx_first = first.empty() ? 0.0 : first[0];
@@ -2805,8 +2867,8 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
         J.scale = 2.0 * (double)k * (double)f.N * (double)f.N;
         J.nk = (int)(f.W - k + 1);
         J.streams = streams.data() + ps[u].s0; J.n_streams = ps[u].s1 - ps[u].s0;
-        J.chunks = reinterpret_cast<const ChainChunk *>(ctx->h_cpin + off_chunks);
-        J.pool = reinterpret_cast<const ChainChunk *>(ctx->h_cpin + off_raw);
+        J.chunks = reinterpret_cast<const ChainChunk *>(pin + off_chunks);
+        J.pool = reinterpret_cast<const ChainChunk *>(pin + off_raw);
         J.pool_units = pool_units;
         J.iv = p.iv.data(); J.n_iv = p.iv.size(); J.out = p.val.data();
     }
@@ -2827,6 +2889,11 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
     }
     info.streams += n_tiles;
     info.walk_ms += now_ms() - tw0;
+    return KGMA_OK;
+    };
+    if (deferred && !export_only) { *deferred = std::move(finish); return KGMA_OK; }
+    const int frc = finish();
+    if (frc) return fail(ctx, frc, "internal: first window of a chained record");
     return KGMA_OK;
 }
 
@@ -2977,6 +3044,7 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64
     // ---- the chains: on the device where its kernel applies, the rest (and whatever failed a check there) on the host ----
     std::vector<char> on_device(pairs.size(), 0);
     ChainDevInfo dev;
+    const double t_selected = now_ms();
     if (!g) {
         // kgma_replay_dips: the residues are with the ranks that scanned them; the caller's source runs the chain there
         // (kgma_chain_export per slice) and hands back the values at the wanted windows
@@ -3009,6 +3077,8 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64
     ctx->stats.chain_device_ms = dev.kernel_ms;
     ctx->stats.chain_raw_steps = dev.raw_steps;
     ctx->stats.chain_max_drift = dev.max_drift;
+    if (getenv("KGMA_CHAIN_DEBUG"))
+        fprintf(stderr, "chain replay: local tie pass + pair selection %.2f ms, device chains %.2f ms (wall)\n", t_selected - t0, now_ms() - t_selected);
     if (getenv("KGMA_CHAIN_DEBUG"))
         fprintf(stderr, "chain on the device: %lld of %zu pairs, %lld windows in %lld streams / %lld chunks, setup %.2f ms, kernels %.2f ms (%d attempt(s)), download %.2f ms, host walk %.2f ms, %lld raw steps, drift <= %.3g\n",
                 (long long)dev.pairs, pairs.size(), (long long)dev.windows, (long long)dev.streams, (long long)dev.chunks, dev.setup_ms, dev.kernel_ms, dev.attempts,
@@ -3181,6 +3251,7 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64
     ctx->stats.n_chain_pairs = (int64_t)pairs.size();
     ctx->stats.chain_windows = windows;
     ctx->stats.chain_ms = now_ms() - t0;
+    if (getenv("KGMA_CHAIN_DEBUG")) fprintf(stderr, "chain replay: %.2f ms in all\n", ctx->stats.chain_ms);
     return KGMA_OK;
 }
 

@@ -218,6 +218,36 @@ void chain_walk_one(ChainWalkJob &J)
         const int64_t n_blocks = (n_pos + 63) >> 6;
         const int64_t n_chunks = (n_blocks + KGMA_CHAIN_STEPS - 1) / KGMA_CHAIN_STEPS;
         for (int64_t c = 0; c < n_chunks; c++) {
+            // The entries and raw increments of a detailed chunk lie where the device's waves happened to allocate them: a
+            // cache (and TLB) miss each for a walk that is otherwise a few additions per chunk.  Two look-aheads: the entry
+            // list of the chunk 16 ahead, the raw increments of the chunk 8 ahead (whose entries have arrived by then).
+            if (c + 16 < n_chunks) {
+                const ChainChunk &f = J.chunks[S.chunk_base + c + 16];
+                if ((f.info & KGMA_CHAIN_DETAIL) && (int64_t)f.raw + 4 <= J.pool_units) {
+                    __builtin_prefetch(&J.pool[f.raw]);
+                    __builtin_prefetch(&J.pool[f.raw + 4]);
+                }
+            }
+            if (c + 8 < n_chunks) {
+                const ChainChunk &f = J.chunks[S.chunk_base + c + 8];
+                if (f.info & KGMA_CHAIN_DETAIL) {
+                    int64_t cov = (f.info >> 2) & 255;
+                    for (int64_t e = f.raw, n = 0; n < 8 && cov < KGMA_CHAIN_STEPS && e >= 0 && e < J.pool_units; e++, n++) {
+                        const ChainChunk &ent = J.pool[e];
+                        if (ent.info & KGMA_CHAIN_RAW) {
+                            if ((int64_t)ent.raw + 32 <= J.pool_units) {
+                                const char *r = reinterpret_cast<const char *>(J.pool) + (size_t)ent.raw * 16;
+                                for (int l = 0; l < 512; l += 64) __builtin_prefetch(r + l);
+                            }
+                            cov += 1;
+                        } else {
+                            const int64_t m = (ent.info >> 2) & 255;
+                            if (m < 1) break;
+                            cov += m;
+                        }
+                    }
+                }
+            }
             const ChainChunk cc = J.chunks[S.chunk_base + c];
             const int64_t steps = std::min<int64_t>(KGMA_CHAIN_STEPS, n_blocks - c * KGMA_CHAIN_STEPS);
             auto apply = [&](const ChainChunk &r) {
