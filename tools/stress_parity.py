@@ -51,8 +51,11 @@ def one_case(ctx, rng, case):
     # reference sets: m clusters of mutated copies of related genes, lengths spread by up to +-6
     root = rdna(rng, base_len + 8)
     KFVs, ws, Ss, Ns, genes = [], [], [], [], []
+    narrow = rng.random() < 0.4       # window sizes within two of each other: the five- / eight-KFV launches of the 8-bit stream kernel
     for j in range(m):
         L = max(k + 1, base_len + int(rng.integers(-3, 4)) + (int(rng.integers(0, 3)) if rng.random() < 0.3 else 0))
+        if narrow:
+            L = max(k + 1, base_len + int(rng.integers(0, 3)))
         g = mutate(rng, root[:L], 0.05)
         n = int(rng.integers(1, 9))
         recs = [Record(f"r{j}_{i}", mutate(rng, g, 0.03)) for i in range(n)]
