@@ -936,6 +936,41 @@ def test_stream8_five_kfv_launch(ctx, k, lens, monkeypatch):
     assert res["1"][2] == 1 and res["0"][2] >= 2
 
 
+def test_stream8_five_kfvs_with_a_large_s_keep_two_launches(ctx):
+    """The five-KFV launch keeps its S rows as bytes: a KFV set with an S entry of 256 or more (300 reference sequences
+    here) must stay on the launches of at most four -- and give the integer oracle's distances."""
+    from kmergma_amd.fasta import Record
+    from tests.helpers import mutate
+    k, lens = 6, [200, 200, 200, 201, 202]
+    rng = np.random.default_rng(4242)
+    KFVs, ws, S, N = [], [], [], []
+    genes = []
+    for i, L in enumerate(lens):
+        base = random_dna(rng, L)
+        genes.append(base)
+        refs = [Record(f"g{i}_{u}", mutate(rng, base, 0.01)) for u in range(300 if i == 2 else 4)]
+        RV, w, cons, (s, n) = refprep.gen_ref_ws_cons(refs, k, return_int=True)
+        KFVs.append(RV); ws.append(w); S.append(s); N.append(n)
+    assert max(int(np.max(s)) for s in S) >= 256
+    g1 = bytearray(random_dna(rng, 120_000))
+    for i, gene in enumerate(genes):
+        g1[4000 + 9000 * i:4000 + 9000 * i + len(gene)] = mutate(rng, gene, 0.05)[:len(gene)]
+    contigs = [bytes(g1), b"A" * 2000 + random_dna(rng, 20_000) + b"N" * 500]
+    thr = [float(np.median([orc.kmer_dist_kfv(random_dna(rng, w), RV, k) for _ in range(10)])) * 0.8 for RV, w in zip(KFVs, ws)]
+    T = [orc.int_threshold(t, k, n) for t, n in zip(thr, N)]
+    ohi, oD = orc.omn_scan_int(contigs, S, N, k, ws, T, 100, 55, return_D=True)
+    ctx.set_refs(k, KFVs, ws, thr, N)
+    gen = ctx.genome_from_host(contigs)
+    ctx.scan(gen, _lib.MODE_OMN, 100, 55, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
+    hits, st = ctx.hits(), ctx.stats()
+    dists = [ctx.dists(j + 1) for j in range(len(ws))]
+    gen.free()
+    assert ctx.kernel_name().startswith("stream8_kernel") and st["n_launches"] == 2
+    assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi] and len(ohi) > 0
+    for j in range(len(ws)):
+        assert np.array_equal(dists[j], oD[j] / (2.0 * k * N[j] ** 2)), j
+
+
 def test_lazy_bit_planes_follow_pokes_and_repacks(ctx, alp_ref, genes, monkeypatch):
     """The bit-plane copy of a genome is made by the first scan whose kernel reads it and must then track the
     residue text like the 2-bit copy does: ONE genome object scanned by the 8-bit stream kernel (no planes yet),
