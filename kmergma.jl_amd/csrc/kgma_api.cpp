@@ -43,6 +43,7 @@ bool stream8_derive_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_
 bool stream8_wide_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool u8, bool s16, int n_plus1, int n_plus2);
 bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16);
 int stream8_variant(int n_kfv);
+int stream8_state_words(int k, int n_kfv);
 hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
 bool chain_applies(int k, int nk, int64_t n_ref, bool s16);
 int chain_slots_per_cu(int k, bool s16, int nkfv);
@@ -206,6 +207,7 @@ struct kgma_ctx {
     ChainChunk *d_cpool2 = nullptr; int64_t cpool2_cap = 0;
     int64_t *d_cD02 = nullptr; int64_t cD02_cap = 0;
     hipStream_t chain_copy_stream = nullptr;
+    int32_t *d_wstate = nullptr; int64_t wstate_cap = 0;                 // k = 7 multi-KFV launches: per-stream state (ScanArgs::wave_state)
     uint32_t *d_chot = nullptr; int64_t chot_cap = 0;                    // [hot bit words | prefix per word]
     uint64_t *d_chmask = nullptr; int64_t chmask_cap = 0;                // hot steps of each hot chunk
     double cpool_per_step = 0;                                           // pool units per step the last chain launches needed beyond their hot steps
@@ -576,6 +578,7 @@ void kgma_destroy(kgma_ctx *ctx)
     if (ctx->d_cpool2) (void)hipFree(ctx->d_cpool2);
     if (ctx->d_cD02) (void)hipFree(ctx->d_cD02);
     if (ctx->chain_copy_stream) (void)hipStreamDestroy(ctx->chain_copy_stream);
+    if (ctx->d_wstate) (void)hipFree(ctx->d_wstate);
     if (ctx->d_chmask) (void)hipFree(ctx->d_chmask);
     if (ctx->d_chot) (void)hipFree(ctx->d_chot);
     if (ctx->d_cD0) (void)hipFree(ctx->d_cD0);
@@ -1895,6 +1898,11 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
                 }
                 a.Sinter = it->second;
             }
+            if (use_stream && stream8_state_words(k, (int)gr.kfvs.size()) > 0) {
+                rc = dev_reserve(ctx, ctx->d_wstate, ctx->wstate_cap, n_tiles * stream8_state_words(k, (int)gr.kfvs.size()));
+                if (rc) return rc;
+                a.wave_state = ctx->d_wstate;
+            }
             a.D0out = d_D0;                        // [KFV id - 1][tile]
             a.recs = d_recs;
             a.rec_count = reinterpret_cast<unsigned int *>(d_cnt);
@@ -2743,6 +2751,11 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
                     it = ctx->sinter.emplace(key, d).first;
                 }
                 a.Sinter = it->second;
+            }
+            if (stream8_state_words(k, nslots) > 0) {
+                rc = dev_reserve(ctx, ctx->d_wstate, ctx->wstate_cap, (int64_t)(L.t1 - L.t0) * stream8_state_words(k, nslots));
+                if (rc) return rc;
+                a.wave_state = ctx->d_wstate;
             }
             a.D0out = d_cD0 + L.d0_off;                       // [KFV][stream of this launch]
             a.n_chunk_tiles = a.n_tiles;

@@ -139,6 +139,7 @@ struct ScanArgs {
     int32_t tile0, n_chunk_tiles;
     int64_t tile_windows;
     int16_t *diff[KGMA_MAX_SIZES];
+    int32_t *wave_state;            // stream8_kernel at k = 7 with several KFVs: per-stream cold state (stream8_state_words() words each)
     ChainArgs chain;                // chain launches only (no other kernel reads it)
 };
 

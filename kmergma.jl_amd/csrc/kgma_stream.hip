@@ -579,11 +579,14 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
     constexpr bool SROWS = S16 && NKFV >= 2;
     constexpr int NV = NKFV >= 5 ? 8 : (NKFV >= 3 ? 4 : NKFV);          // int16 (SBYTE: byte) slots per row
     constexpr size_t tab_words = SROWS ? (size_t)NB * NV / (SBYTE ? 4 : 2) : (S16 ? NB / 2 : NB) * (size_t)NKFV;
-    constexpr size_t per_wave_words = NB / 4 + (NKFV > 1 ? NKFV * ST_WORDS : 0);
+    // (k = 7: the ten 16 KiB count tables ARE the LDS; the cold per-KFV state of a multi-KFV launch lives in global memory, one
+    //  block per stream -- it is touched at the first windows and inside dips only)
+    constexpr bool STATE_GLOBAL = SGLOBAL && NKFV > 1;
+    constexpr size_t per_wave_words = NB / 4 + (NKFV > 1 && !STATE_GLOBAL ? NKFV * ST_WORDS : 0);
     int32_t *sTab32 = reinterpret_cast<int32_t *>(smem);
     uint16_t *sTab16 = reinterpret_cast<uint16_t *>(smem);          // S >= 0 (sums of counts): read zero-extended
     uint32_t *C = smem + (SGLOBAL ? 0 : tab_words) + (size_t)wave * per_wave_words;
-    int32_t *sState = reinterpret_cast<int32_t *>(C + NB / 4);
+    int32_t *sState = reinterpret_cast<int32_t *>(C + NB / 4);      // (STATE_GLOBAL: set below, once the wave knows its stream)
     if constexpr (!SGLOBAL) {
 #pragma unroll
         for (int j = 0; j < NKFV; j++) {
@@ -600,6 +603,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
     __syncthreads();
     const int tile = wave * (int)gridDim.x + (int)blockIdx.x;         // streams are dealt to workgroups round-robin
     if (tile >= a.n_tiles) return;                                    // (after the only workgroup barrier)
+    if constexpr (STATE_GLOBAL) sState = a.wave_state + (size_t)tile * (size_t)(NKFV * ST_WORDS);
 
     for (int i = lane; i < NB / 4; i += 64) C[i] = 0;
     if constexpr (NKFV > 1) { for (int i = lane; i < NKFV * ST_WORDS; i += 64) sState[i] = 0; }
@@ -1420,6 +1424,9 @@ static hipError_t launch_stream_k(const ScanArgs &a, const GroupParams &gp, hipS
     return hipGetLastError();
 }
 
+// int32 words of per-stream state a k = 7 multi-KFV launch keeps in global memory (ScanArgs::wave_state), per stream
+int stream8_state_words(int k, int n_kfv) { return k >= 7 && n_kfv > 1 ? KGMA_MAX_GROUP * ST_WORDS : 0; }
+
 // ---- 8-bit counter kernel: 1 ... 8 KFVs of ONE window size, k = 5 or 6, at most 383 k-mers per window
 constexpr int KGMA_STREAM8_MAX_NK = 383;
 
@@ -1443,7 +1450,7 @@ static size_t stream8_lds(int k, bool s16, int nkfv, int nw)
     const size_t NB = (size_t)1 << (2 * k);
     const size_t slots = s16 && nkfv >= 2 ? (nkfv >= 5 ? 8 : nkfv >= 3 ? 4 : 2) : (size_t)nkfv;   // int16 tables of several KFVs: rows of 2 / 4 / 8 slots
     const size_t tabs = k >= 7 ? 0 : nkfv == 5 ? NB * 8 : NB * (s16 ? 2 : 4) * slots;   // k = 7: the S tables stay in global memory; 5: rows of 8 bytes
-    return tabs + (size_t)nw * (NB + (nkfv > 1 ? (size_t)nkfv * ST_WORDS * 4 : 0));
+    return tabs + (size_t)nw * (NB + (nkfv > 1 && k < 7 ? (size_t)nkfv * ST_WORDS * 4 : 0));   // (k = 7: the per-KFV state is in global memory)
 }
 
 static bool stream8_derive_env_on()                  // KGMA_STREAM8_DERIVE=0 (testing): one window size per launch only
