@@ -44,9 +44,10 @@ bool stream8_wide_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_re
 bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16);
 int stream8_variant(int n_kfv);
 int stream8_state_words(int k, int n_kfv);
+bool stream8_c16_applies(int k, int nk, int n_kfv, int64_t n_ref);
 hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
 bool chain_applies(int k, int nk, int64_t n_ref, bool s16);
-int chain_slots_per_cu(int k, bool s16, int nkfv);
+int chain_slots_per_cu(int k, bool s16, int nkfv, int nk);
 hipError_t launch_chain(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 int pos_tables_per_pass(int k);
 int64_t align_trace_bytes(int m, int n);
@@ -1545,6 +1546,10 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     bool s8_all = k >= 5 && k <= 7 && !(kenv && !strcmp(kenv, "bitslice"));
     for (int j = 0; j < m_used && s8_all; j++)
         s8_all = stream8_applies(k, (int)(ctx->kfv[(size_t)j].W - k + 1), 1, ctx->kfv[(size_t)j].N, ctx->kfv[(size_t)j].Smax <= 32767);
+    // one KFV with a window of 384 ... 2031 k-mers at k = 5, 6: the 16-bit counter form of the same kernel
+    const bool c16_scan = m_used == 1 && !(kenv && !strcmp(kenv, "bitslice")) &&
+                          stream8_c16_applies(k, (int)(ctx->kfv[0].W - k + 1), 1, ctx->kfv[0].N);
+    if (c16_scan) s8_all = true;
     const std::vector<Group> groups = make_groups(ctx, mode, s8_all);
     auto group_nmax = [&](const Group &gr) { int64_t n = 0; for (int j : gr.kfvs) n = std::max(n, ctx->kfv[(size_t)j].N); return n; };
     auto group_one_size = [&](const Group &gr) { return ctx->kfv[(size_t)gr.kfvs.front()].W == ctx->kfv[(size_t)gr.kfvs.back()].W; };
@@ -1558,6 +1563,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         return stream8_wide_applies(k, group_nk_min(gr), (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_u8(gr), group_s16(gr), n1, n2);
     };
     auto group_s8 = [&](const Group &gr) {
+        if (c16_scan) return true;
         if (group_wide(gr)) return true;
         if (group_one_size(gr)) return stream8_applies(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr));
         return stream8_derive_applies(k, group_nk_min(gr), (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr));
@@ -2451,7 +2457,7 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
         const KfvInfo &f = ctx->kfv[(size_t)p.j];
         const int nk = (int)(f.W - k + 1);
         if (!chain_applies(k, nk, f.N, f.Smax <= 32767) || f.ref_form < 0 || p.last < 2) continue;
-        if (chain_slots_per_cu(k, f.Smax <= 32767, 1) < 1) continue;
+        if (chain_slots_per_cu(k, f.Smax <= 32767, 1, nk) < 1) continue;
         el.push_back(i);
     }
     if (el.empty()) return KGMA_OK;
@@ -2538,7 +2544,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
             const bool s16 = f0.Smax <= 32767;
             size_t e = i + 1;
             while (e < kf.size() && (int)(e - i) < (s16 ? maxg : 1) && ctx->kfv[(size_t)kf[e]].W == f0.W && (ctx->kfv[(size_t)kf[e]].Smax <= 32767) == s16 &&
-                   chain_slots_per_cu(k, s16, (int)(e - i) + 1) > 0)
+                   chain_slots_per_cu(k, s16, (int)(e - i) + 1, (int)(f0.W - k + 1)) > 0)
                 e++;
             Launch L;
             L.kfvs.assign(kf.begin() + (long)i, kf.begin() + (long)e);
@@ -2569,7 +2575,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
         // 2^18 (the drift a stream may add stays far below the guard band)
         int64_t T;
         {
-            const int64_t slots = (int64_t)std::max(1, ctx->n_cus) * chain_slots_per_cu(k, L.s16, nslots);
+            const int64_t slots = (int64_t)std::max(1, ctx->n_cus) * chain_slots_per_cu(k, L.s16, nslots, nk);
             T = (windows + slots * 3 - 1) / (slots * 3);
             if (const char *e = getenv("KGMA_CHAIN_STREAM")) T = atoll(e);                     // experiments / tests
             T = std::min<int64_t>(std::max<int64_t>(((T + 63) / 64) * 64, 1024), (int64_t)1 << 18);
@@ -3658,7 +3664,7 @@ int kgma_chain_export(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int32
         if (src) return src;
     }
     const int k = ctx->k;
-    if (!chain_applies(k, (int)(f.W - k + 1), f.N, f.Smax <= 32767) || f.ref_form < 0 || chain_slots_per_cu(k, f.Smax <= 32767, 1) < 1)
+    if (!chain_applies(k, (int)(f.W - k + 1), f.N, f.Smax <= 32767) || f.ref_form < 0 || chain_slots_per_cu(k, f.Smax <= 32767, 1, (int)(f.W - k + 1)) < 1)
         return fail(ctx, KGMA_E_UNSUPPORTED, "the chain kernel does not serve this KFV");
     std::vector<char> done(1, 0);
     ChainDevInfo info;

@@ -532,9 +532,12 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 #define KGMA_CHAIN_WAVES 6
 #endif
 
-template <int K, bool S16, int NKFV, int ND = 0, bool CHAIN = false, int ND2 = 0>
-__global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN_WAVES : 8) : (CHAIN ? 4 : (NKFV <= 5 ? 6 : 4)))) void stream8_kernel(ScanArgs a, GroupParams gp)
+template <int K, bool S16, int NKFV, int ND = 0, bool CHAIN = false, int ND2 = 0, bool C16 = false>
+__global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN_WAVES : 8) : (CHAIN ? 4 : (NKFV <= 5 ? 6 : 4))))) void stream8_kernel(ScanArgs a, GroupParams gp)
 {
+    // C16: 16-BIT counters (two per dword) for windows of 384 ... 2031 k-mers -- one KFV, k <= 6; a wave's table is 2 * 4^k bytes
+    // (16 waves per CU at k = 6), no count can leave its field, so the heavy-k-mer bookkeeping of the 8-bit form is compiled out.
+    static_assert(!C16 || (NKFV == 1 && K <= 6 && ND == 0 && ND2 == 0), "16-bit counters: one KFV, k <= 6");
     // CHAIN: the same walk, but instead of testing thresholds the wave reproduces the reference's running Float64
     // value (kgma_device.h, ChainArgs): one KFV, no dips, no records -- chunk translations and raw increments.
     static_assert(!CHAIN || (NKFV <= 4 && ND == 0 && ND2 == 0), "the chain variant walks 1-4 KFVs of one window size");
@@ -582,11 +585,12 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
     // (k = 7: the ten 16 KiB count tables ARE the LDS; the cold per-KFV state of a multi-KFV launch lives in global memory, one
     //  block per stream -- it is touched at the first windows and inside dips only)
     constexpr bool STATE_GLOBAL = SGLOBAL && NKFV > 1;
-    constexpr size_t per_wave_words = NB / 4 + (NKFV > 1 && !STATE_GLOBAL ? NKFV * ST_WORDS : 0);
+    constexpr int CW = C16 ? NB / 2 : NB / 4;                          // dwords of a wave's count table
+    constexpr size_t per_wave_words = CW + (NKFV > 1 && !STATE_GLOBAL ? NKFV * ST_WORDS : 0);
     int32_t *sTab32 = reinterpret_cast<int32_t *>(smem);
     uint16_t *sTab16 = reinterpret_cast<uint16_t *>(smem);          // S >= 0 (sums of counts): read zero-extended
     uint32_t *C = smem + (SGLOBAL ? 0 : tab_words) + (size_t)wave * per_wave_words;
-    int32_t *sState = reinterpret_cast<int32_t *>(C + NB / 4);      // (STATE_GLOBAL: set below, once the wave knows its stream)
+    int32_t *sState = reinterpret_cast<int32_t *>(C + CW);      // (STATE_GLOBAL: set below, once the wave knows its stream)
     if constexpr (!SGLOBAL) {
 #pragma unroll
         for (int j = 0; j < NKFV; j++) {
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
     if (tile >= a.n_tiles) return;                                    // (after the only workgroup barrier)
     if constexpr (STATE_GLOBAL) sState = a.wave_state + (size_t)tile * (size_t)(NKFV * ST_WORDS);
 
-    for (int i = lane; i < NB / 4; i += 64) C[i] = 0;
+    for (int i = lane; i < CW; i += 64) C[i] = 0;
     if constexpr (NKFV > 1) { for (int i = lane; i < NKFV * ST_WORDS; i += 64) sState[i] = 0; }
     int32_t st_reg[ST_WORDS];                                         // NKFV == 1: the dip state stays in registers
 #pragma unroll
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
     asm volatile("" : "+v"(one), "+v"(mone));
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     const uint32_t cbase = (uint32_t)uni((int)(uint32_t)(uintptr_t)(lds_u32 *)C);   // LDS byte offset of this wave's count table
-    constexpr bool KBASED = NKFV == 1 && !SGLOBAL;                    // (per-wave stride = table size, tables in front: aligned)
+    constexpr bool KBASED = NKFV == 1 && !SGLOBAL && !C16;            // (per-wave stride = table size, tables in front: aligned)
     uint32_t kmask = (uint32_t)(NB - 1);
     asm volatile("" : "+v"(kmask));                                   // (a vector register: the and-or has one scalar operand left for the base)
     const uint32_t kbase = KBASED ? cbase : 0u;
@@ -932,14 +936,15 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
         }
         // LDS byte addresses of the two counters (explicit LDS pointers: the dword address of the atomic is the byte
         // address with its low bits cleared -- one instruction instead of a second address calculation)
-        const uint32_t ap = KBASED ? kp : cbase + kp, as = KBASED ? ks : cbase + ks;
+        const uint32_t ap = KBASED ? kp : (C16 ? cbase + (kp << 1) : cbase + kp), as = KBASED ? ks : (C16 ? cbase + (ks << 1) : cbase + ks);
         // counts at the start of the step (raw bytes).  Issued in assembly: the compiler masks the result of a byte load it
         // issues itself (two v_and per step); the LDS returns in order, so the wait for the atomics below covers these.
         uint32_t cp, cs;
-        asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %3" : "=&v"(cp), "=&v"(cs) : "v"(ap), "v"(as));
+        if constexpr (C16) asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %3" : "=&v"(cp), "=&v"(cs) : "v"(ap), "v"(as));
+        else asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %3" : "=&v"(cp), "=&v"(cs) : "v"(ap), "v"(as));
         // shift amounts 8 * (k-mer & 3): the shifter and the bit-field extract read the low five bits of their amount, so
         // the k-mer times 8 serves unmasked -- in assembly, because C would have the mask back
-        const uint32_t shp = kp << 3, shs = ks << 3;
+        const uint32_t shp = C16 ? kp << 4 : kp << 3, shs = C16 ? ks << 4 : ks << 3;   // (16-bit fields: 16 * (k-mer & 1))
         uint32_t addv, subv;
         asm("v_lshlrev_b32 %0, %1, %2" : "=v"(addv) : "v"(shp), "v"(one));
         asm("v_lshlrev_b32 %0, %1, %2" : "=v"(subv) : "v"(shs), "v"(mone));
@@ -959,12 +964,17 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN
         int32_t cP, cS;
         {
             uint32_t oldp, olds;
-            asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(oldp) : "v"(wop), "v"(shp));
-            asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(olds) : "v"(wos), "v"(shs));
+            if constexpr (C16) {
+                asm("v_bfe_u32 %0, %1, %2, 16" : "=v"(oldp) : "v"(wop), "v"(shp));
+                asm("v_bfe_u32 %0, %1, %2, 16" : "=v"(olds) : "v"(wos), "v"(shs));
+            } else {
+                asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(oldp) : "v"(wop), "v"(shp));
+                asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(olds) : "v"(wos), "v"(shs));
+            }
             uint64_t pendE = __builtin_amdgcn_uicmp(oldp, cp, 33 /* ne */) & AE;
             uint64_t pendL = __builtin_amdgcn_uicmp(olds, cs, 33 /* ne */) & AL;
             const uint64_t cand0 = __builtin_amdgcn_uicmp(cp, 127u, 34 /* ugt */);
-            if (__builtin_expect(heavy || cand0 != 0, 0)) {
+            if (!C16 && __builtin_expect(heavy || cand0 != 0, 0)) {
                 uint32_t best_key = 0, best_end = 0;
                 if (heavy) {
                     const bool isHp = kp == Hkey, isHs = ks == Hkey;
@@ -1443,11 +1453,21 @@ bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16)
            n_ref < ((int64_t)1 << 22);
 }
 
+// 16-bit counter form of the same kernel (C16): one KFV, k = 5, 6, windows of 384 ... 2031 k-mers.  KGMA_STREAM8_C16=0 (testing):
+// off -- such windows then take the older 16-bit stream kernel, and their chains the host.
+bool stream8_c16_applies(int k, int nk, int n_kfv, int64_t n_ref)
+{
+    const char *e = getenv("KGMA_STREAM8_C16");
+    return stream8_env_on() && !(e && atoi(e) == 0) && n_kfv == 1 && (k == 5 || k == 6) && nk > KGMA_STREAM8_MAX_NK && nk <= KGMA_MAX_NK &&
+           n_ref < ((int64_t)1 << 22);
+}
+
 int stream8_variant(int n_kfv) { return n_kfv <= 4 ? (n_kfv < 1 ? 1 : n_kfv) : 8; }   // instantiated NKFV: 1-4 are launched full, 8 takes 5-8 KFVs
 
-static size_t stream8_lds(int k, bool s16, int nkfv, int nw)
+static size_t stream8_lds(int k, bool s16, int nkfv, int nw, bool c16 = false)
 {
     const size_t NB = (size_t)1 << (2 * k);
+    if (c16) return NB * (s16 ? 2 : 4) + (size_t)nw * NB * 2;         // (one KFV: its S table + 16-bit count tables)
     const size_t slots = s16 && nkfv >= 2 ? (nkfv >= 5 ? 8 : nkfv >= 3 ? 4 : 2) : (size_t)nkfv;   // int16 tables of several KFVs: rows of 2 / 4 / 8 slots
     const size_t tabs = k >= 7 ? 0 : nkfv == 5 ? NB * 8 : NB * (s16 ? 2 : 4) * slots;   // k = 7: the S tables stay in global memory; 5: rows of 8 bytes
     return tabs + (size_t)nw * (NB + (nkfv > 1 && k < 7 ? (size_t)nkfv * ST_WORDS * 4 : 0));   // (k = 7: the per-KFV state is in global memory)
@@ -1540,6 +1560,16 @@ static const void *stream8_fn_k(int nkfv)
     }
 }
 
+static const void *stream8_fn_c16(int k, bool s16, bool chain)
+{
+    if (k == 5) {
+        if (chain) return s16 ? reinterpret_cast<const void *>(&stream8_kernel<5, true, 1, 0, true, 0, true>) : reinterpret_cast<const void *>(&stream8_kernel<5, false, 1, 0, true, 0, true>);
+        return s16 ? reinterpret_cast<const void *>(&stream8_kernel<5, true, 1, 0, false, 0, true>) : reinterpret_cast<const void *>(&stream8_kernel<5, false, 1, 0, false, 0, true>);
+    }
+    if (chain) return s16 ? reinterpret_cast<const void *>(&stream8_kernel<6, true, 1, 0, true, 0, true>) : reinterpret_cast<const void *>(&stream8_kernel<6, false, 1, 0, true, 0, true>);
+    return s16 ? reinterpret_cast<const void *>(&stream8_kernel<6, true, 1, 0, false, 0, true>) : reinterpret_cast<const void *>(&stream8_kernel<6, false, 1, 0, false, 0, true>);
+}
+
 static const void *stream8_fn_of(int k, bool s16, int nkfv, int nd = 0, int nd2 = 0)       // nd / nd2: KFVs with a window one / two k-mers longer
 {
     if (nkfv == 5) return k == 5 ? stream8_fn_wide<5>(nd, nd2) : k == 6 ? stream8_fn_wide<6>(nd, nd2) : nullptr;
@@ -1589,11 +1619,12 @@ static void chain_launch_k(bool s16, int nkfv, unsigned grid, unsigned threads, 
 // Residency of one kernel variant on one device, asked of the runtime once: guarded (one context per host thread is the
 // documented use) and keyed by the device too (partitioned modes expose different CUs).
 struct GeomKey {
-    int device, k, s16, nkfv, nd, chain, nd2;
+    int device, k, s16, nkfv, nd, chain, nd2, c16;
     bool operator<(const GeomKey &o) const
     {
         if (device != o.device) return device < o.device;
         if (nd2 != o.nd2) return nd2 < o.nd2;
+        if (c16 != o.c16) return c16 < o.c16;
         if (k != o.k) return k < o.k;
         if (s16 != o.s16) return s16 < o.s16;
         if (nkfv != o.nkfv) return nkfv < o.nkfv;
@@ -1603,17 +1634,17 @@ struct GeomKey {
 };
 struct GeomVal { int nw, blocks; };
 
-static GeomVal stream8_geometry_of(int k, bool s16, int nkfv, int nd, bool chain, int nd2 = 0)
+static GeomVal stream8_geometry_of(int k, bool s16, int nkfv, int nd, bool chain, int nd2 = 0, bool c16 = false)
 {
     static std::mutex mu;
     static std::map<GeomKey, GeomVal> cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const GeomKey key{dev, k, s16 ? 1 : 0, nkfv, nd, chain ? 1 : 0, nd2};
+    const GeomKey key{dev, k, s16 ? 1 : 0, nkfv, nd, chain ? 1 : 0, nd2, c16 ? 1 : 0};
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
-    const void *fn = chain ? chain_fn_of(k, s16, nkfv) : stream8_fn_of(k, s16, nkfv, nd, nd2);
+    const void *fn = c16 ? stream8_fn_c16(k, s16, chain) : chain ? chain_fn_of(k, s16, nkfv) : stream8_fn_of(k, s16, nkfv, nd, nd2);
     if (fn == nullptr) return GeomVal{-1, 1};
     if (getenv("KGMA_GEOM_DEBUG")) {
         int rv = 0, dv = 0;
@@ -1634,14 +1665,14 @@ static GeomVal stream8_geometry_of(int k, bool s16, int nkfv, int nd, bool chain
         if (hipFuncGetAttributes(&fa0, fn) == hipSuccess) regs = fa0.numRegs;
     }
     for (int nw = 16; nw >= 4; nw--) {
-        const size_t lds = stream8_lds(k, s16, nkfv, nw);
+        const size_t lds = stream8_lds(k, s16, nkfv, nw, c16);
         if (lds > ((size_t)160 << 10)) continue;
         int blocks = 0;
         const hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const hipError_t e2 = e1 == hipSuccess ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64 * nw, lds) : e1;
         if (getenv("KGMA_GEOM_DEBUG"))
-            fprintf(stderr, "  geometry k=%d s16=%d nkfv=%d nd=%d chain=%d: %d waves, %zu B of LDS -> %d workgroups per CU (%s / %s)\n", k, (int)s16, nkfv, nd,
-                    (int)chain, nw, lds, blocks, hipGetErrorString(e1), hipGetErrorString(e2));
+            fprintf(stderr, "  geometry k=%d s16=%d nkfv=%d nd=%d chain=%d%s: %d waves, %zu B of LDS -> %d workgroups per CU (%s / %s)\n", k, (int)s16, nkfv, nd,
+                    (int)chain, c16 ? " c16" : "", nw, lds, blocks, hipGetErrorString(e1), hipGetErrorString(e2));
         if (e1 != hipSuccess || e2 != hipSuccess) continue;
         // The runtime's answer is a lower bound here: with another HIP user in the process (PyTorch loaded after this
         // library) it was seen to report half the residency for a kernel with a 12-byte private segment.  What the hardware
@@ -1679,13 +1710,16 @@ void stream8_geometry(int k, bool s16, int nkfv, int nd, int *nw_out, int *block
 // ---- chain variants (1-4 KFVs of one window size, k = 5, 6 or 7): streams resident per CU, launch
 bool chain_applies(int k, int nk, int64_t n_ref, bool s16)
 {
-    return (k == 5 || k == 6 || (k == 7 && s16)) && nk <= KGMA_STREAM8_MAX_NK && n_ref < ((int64_t)1 << 22);
+    if (nk > KGMA_STREAM8_MAX_NK) return stream8_c16_applies(k, nk, 1, n_ref);       // (the 16-bit counter form: k = 5, 6)
+    return (k == 5 || k == 6 || (k == 7 && s16)) && n_ref < ((int64_t)1 << 22);
 }
 
-int chain_slots_per_cu(int k, bool s16, int nkfv)
+int chain_slots_per_cu(int k, bool s16, int nkfv, int nk)
 {
     if (nkfv < 1 || nkfv > 4 || (nkfv > 1 && !s16)) return 0;
-    const GeomVal v = stream8_geometry_of(k, s16, nkfv, 0, true);
+    const bool c16 = nk > KGMA_STREAM8_MAX_NK;
+    if (c16 && nkfv != 1) return 0;
+    const GeomVal v = stream8_geometry_of(k, s16, nkfv, 0, true, 0, c16);
     return v.nw < 1 ? 0 : v.nw * v.blocks;
 }
 
@@ -1694,15 +1728,24 @@ hipError_t launch_chain(const ScanArgs &a, const GroupParams &gp, hipStream_t st
     const bool s16 = gp.s_fits_i16 != 0;
     const int nkfv = gp.n_kfv;
     if (nkfv < 1 || nkfv > 4 || (nkfv > 1 && !s16)) return hipErrorInvalidConfiguration;
-    const GeomVal v = stream8_geometry_of(gp.k, s16, nkfv, 0, true);
+    const bool c16 = gp.nk > KGMA_STREAM8_MAX_NK;
+    if (c16 && nkfv != 1) return hipErrorInvalidConfiguration;
+    const GeomVal v = stream8_geometry_of(gp.k, s16, nkfv, 0, true, 0, c16);
     for (int j = 0; j < nkfv; j++)
         if (!chain_applies(gp.k, gp.nk, gp.N[j], s16)) return hipErrorInvalidConfiguration;
     if (v.nw < 1) return hipErrorInvalidConfiguration;
     const int nw = v.nw;
-    const size_t lds = stream8_lds(gp.k, s16, nkfv, nw);
+    const size_t lds = stream8_lds(gp.k, s16, nkfv, nw, c16);
     const unsigned grid = (unsigned)((a.n_tiles + nw - 1) / nw);
-    hipError_t e = hipFuncSetAttribute(chain_fn_of(gp.k, s16, nkfv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void *cfn = c16 ? stream8_fn_c16(gp.k, s16, true) : chain_fn_of(gp.k, s16, nkfv);
+    hipError_t e = hipFuncSetAttribute(cfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    if (c16) {
+        ScanArgs a_copy = a;
+        GroupParams gp_copy = gp;
+        void *args[2] = {&a_copy, &gp_copy};
+        return hipLaunchKernel(cfn, dim3(grid), dim3(64u * nw), args, lds, st);
+    }
     if (gp.k == 7) chain_launch_k<7>(s16, nkfv, grid, 64u * nw, lds, st, a, gp);
     else if (gp.k == 5) chain_launch_k<5>(s16, nkfv, grid, 64u * nw, lds, st, a, gp);
     else chain_launch_k<6>(s16, nkfv, grid, 64u * nw, lds, st, a, gp);
@@ -1742,9 +1785,24 @@ static int derived_kfvs(const GroupParams &gp)
     return nd;
 }
 
-static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp_in, hipStream_t st, bool derive_launch, bool wide = false)
+static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp_in, hipStream_t st, bool derive_launch, bool wide = false, bool c16 = false)
 {
     GroupParams gp = gp_in;
+    if (c16) {                                      // one KFV, 16-bit counters
+        const bool s16c = gp.s_fits_i16 != 0;
+        const GeomVal v = stream8_geometry_of(gp.k, s16c, 1, 0, false, 0, true);
+        if (v.nw < 1) return hipErrorInvalidConfiguration;
+        int nw = v.nw;
+        if (gp.stream_slots > 0 && gp.stream_slots < v.nw * v.blocks && gp.stream_slots <= 16) nw = gp.stream_slots;
+        const size_t lds = stream8_lds(gp.k, s16c, 1, nw, true);
+        const unsigned grid = (unsigned)((a.n_tiles + nw - 1) / nw);
+        const void *fn = stream8_fn_c16(gp.k, s16c, false);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        ScanArgs a_copy = a;
+        void *args[2] = {&a_copy, &gp};
+        return hipLaunchKernel(fn, dim3(grid), dim3(64u * nw), args, lds, st);
+    }
     int derive = derive_launch ? derived_kfvs(gp) : 0, derive2 = 0;
     if (wide) {
         derive = derive2 = 0;
@@ -1786,6 +1844,10 @@ static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp_in, hi
 // streams resident per CU (what the host sizes the streams for); n_ref = largest reference count of the launch's KFVs
 int stream_slots_per_cu(int k, int nk, int nk_min, int n_longer, int n_kfv, int n_sizes, bool s16, int64_t n_ref, bool u8, int n_plus2)
 {
+    if (n_sizes == 1 && stream8_c16_applies(k, nk, n_kfv, n_ref)) {
+        const GeomVal v = stream8_geometry_of(k, s16, 1, 0, false, 0, true);
+        return v.nw < 1 ? 0 : v.nw * v.blocks;
+    }
     if (stream8_wide_applies(k, nk_min, nk, n_kfv, n_ref, u8, s16, n_longer - n_plus2, n_plus2)) {   // (n_plus2: KFVs whose window is two k-mers longer than the shortest)
         int nw = 16, blocks = 1;
         stream8_geometry(k, true, n_kfv, n_longer - n_plus2, &nw, &blocks, n_plus2);
@@ -1805,6 +1867,7 @@ hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t s
     {
         int64_t nmax = 0;
         for (int j = 0; j < gp.n_kfv; j++) nmax = gp.N[j] > nmax ? gp.N[j] : nmax;
+        if (gp.n_sizes == 1 && stream8_c16_applies(gp.k, gp.nk, gp.n_kfv, nmax)) return launch_stream8(a, gp, st, false, false, true);
         int n1 = 0, n2 = 0;
         for (int j = 0; j < gp.n_kfv; j++) { n1 += gp.nk_of[j] == gp.nk_min + 1 ? 1 : 0; n2 += gp.nk_of[j] == gp.nk_min + 2 ? 1 : 0; }
         if (stream8_wide_applies(gp.k, gp.nk_min, gp.nk, gp.n_kfv, nmax, gp.s_fits_u8 != 0, gp.s_fits_i16 != 0, n1, n2)) return launch_stream8(a, gp, st, false, true);

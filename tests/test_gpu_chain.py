@@ -62,6 +62,40 @@ def test_chain_values_every_window(ctx, alp_ref, genes, stream, monkeypatch):
         g.free()
 
 
+@pytest.mark.parametrize("k,gene_len", [(6, 389), (6, 520), (5, 700), (6, 2036)])
+def test_chain_values_large_windows(ctx, genes, k, gene_len):
+    """Windows of 384 ... 2031 k-mers (k = 5, 6): the chain runs in the 16-bit counter form of the kernel -- every window's
+    value against the reference-order oracle, through homopolymer / N / repeat stretches longer than the window."""
+    from kmergma_amd import refprep
+    from kmergma_amd.fasta import Record
+    rng = np.random.default_rng(1000 * k + gene_len)
+    base = random_dna(rng, gene_len)
+    refs = [Record(f"g{i}", mutate(rng, base, 0.03)) for i in range(6)]
+    RV, W, cons, (S, N) = refprep.gen_ref_ws_cons(refs, k, return_int=True)
+    assert W == gene_len
+    a = bytearray(random_dna(rng, 60_000))
+    a[3000:3000 + 3 * W] = b"A" * (3 * W)
+    a[20_000:20_000 + 2 * W] = (b"AC" * W)[:2 * W]
+    a[30_000:30_000 + W + 50] = b"N" * (W + 50)
+    a[40_000:40_000 + W] = mutate(rng, base, 0.05)[:W]
+    seqs = [bytes(a), random_dna(rng, W + 700), base + random_dna(rng, 3)]
+    ctx.set_refs(k, [RV], [W], [30.0], [N])
+    g = ctx.genome_from_host(seqs)
+    try:
+        for c, seq in enumerate(seqs):
+            _, od = orc.single_scan([seq], RV, k, W, 30.0, 50, return_dists=True)
+            chain = np.concatenate([[orc.kmer_dist_kfv(seq[:W], RV, k)], od])
+            nwin = len(seq) - W + 1
+            v = g.chain_values(c, 1, [(1, nwin)])
+            assert np.array_equal(v, chain), f"record {c}: first mismatch at window {int(np.argmax(v != chain)) + 1}"
+            assert ctx.stats()["chain_device_pairs"] == 1
+            # sparse: the last window only (regular chunks in between)
+            v = g.chain_values(c, 1, [(nwin, nwin)])
+            assert v[0] == chain[-1]
+    finally:
+        g.free()
+
+
 def test_chain_values_sparse_windows_go_through_regular_chunks(ctx, alp_ref, genes):
     rng = np.random.default_rng(22)
     k, W, RV = 6, alp_ref["ws"], alp_ref["RV"]
