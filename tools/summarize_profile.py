@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--records", type=int, default=100)
     ap.add_argument("--windowsize", type=int, default=289)
     ap.add_argument("--workload", default="bench.py default: one synthetic 100 Gb genome (100 records x 1e9 bases) on one GPU")
-    ap.add_argument("--kernel", default="stream8_kernel<6, true, 1, 0, false, 0>",
+    ap.add_argument("--kernel", default="stream8_kernel<6, true, 1, 0, false, 0, false>",
                     help="substring of the scan kernel's name (the chain variant ends in `true>`: it must not be averaged in)")
     args = ap.parse_args()
     stats_csv = glob.glob(os.path.join(args.src, "trace", "*", "*_kernel_stats.csv"))[0]
