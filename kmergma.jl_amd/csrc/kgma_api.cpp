@@ -44,7 +44,7 @@ bool stream8_wide_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_re
 bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16);
 int stream8_variant(int n_kfv);
 int stream8_state_words(int k, int n_kfv);
-bool stream8_c16_applies(int k, int nk, int n_kfv, int64_t n_ref);
+bool stream8_c16_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16);
 hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
 bool chain_applies(int k, int nk, int64_t n_ref, bool s16);
 int chain_slots_per_cu(int k, bool s16, int nkfv, int nk);
@@ -426,8 +426,9 @@ std::vector<Group> make_groups(const kgma_ctx *ctx, int mode, bool s8 = false)
             if (s8) {
                 bool s16 = ctx->kfv[(size_t)j].Smax <= 32767;
                 for (int u : g.kfvs) s16 = s16 && ctx->kfv[(size_t)u].Smax <= 32767;
-                fits = (W == wmin && last == wmin && (int)g.kfvs.size() < s8_max_same) ||
-                       (derive_ok && s16 && W <= wmin + 1 && (int)g.kfvs.size() < 4);
+                const bool c8 = W - ctx->k + 1 <= 383;                  // (longer windows: the 16-bit counter form, one size per launch)
+                fits = (W == wmin && last == wmin && (int)g.kfvs.size() < std::min(s8_max_same, c8 ? KGMA_MAX_GROUP : 4) && (c8 || s16)) ||
+                       (derive_ok && s16 && c8 && W <= wmin + 1 && (int)g.kfvs.size() < 4);
             } else {
                 fits = (int)g.kfvs.size() < KGMA_MAX_GROUP && W - wmin <= KGMA_MAX_DW && (W == last || distinct < KGMA_MAX_SIZES);
             }
@@ -1544,12 +1545,12 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     // kernel groups up to 8 KFVs of up to 4 sizes.
     const char *kenv = getenv("KGMA_KERNEL");                    // testing only: run the other kernel where both apply
     bool s8_all = k >= 5 && k <= 7 && !(kenv && !strcmp(kenv, "bitslice"));
-    for (int j = 0; j < m_used && s8_all; j++)
-        s8_all = stream8_applies(k, (int)(ctx->kfv[(size_t)j].W - k + 1), 1, ctx->kfv[(size_t)j].N, ctx->kfv[(size_t)j].Smax <= 32767);
-    // one KFV with a window of 384 ... 2031 k-mers at k = 5, 6: the 16-bit counter form of the same kernel
-    const bool c16_scan = m_used == 1 && !(kenv && !strcmp(kenv, "bitslice")) &&
-                          stream8_c16_applies(k, (int)(ctx->kfv[0].W - k + 1), 1, ctx->kfv[0].N);
-    if (c16_scan) s8_all = true;
+    // (a KFV whose window has 384 ... 2031 k-mers at k = 5, 6 takes the 16-bit counter form of the same kernel)
+    for (int j = 0; j < m_used && s8_all; j++) {
+        const KfvInfo &f = ctx->kfv[(size_t)j];
+        const int nkj = (int)(f.W - k + 1);
+        s8_all = stream8_applies(k, nkj, 1, f.N, f.Smax <= 32767) || stream8_c16_applies(k, nkj, 1, f.N, f.Smax <= 32767);
+    }
     const std::vector<Group> groups = make_groups(ctx, mode, s8_all);
     auto group_nmax = [&](const Group &gr) { int64_t n = 0; for (int j : gr.kfvs) n = std::max(n, ctx->kfv[(size_t)j].N); return n; };
     auto group_one_size = [&](const Group &gr) { return ctx->kfv[(size_t)gr.kfvs.front()].W == ctx->kfv[(size_t)gr.kfvs.back()].W; };
@@ -1563,7 +1564,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         return stream8_wide_applies(k, group_nk_min(gr), (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_u8(gr), group_s16(gr), n1, n2);
     };
     auto group_s8 = [&](const Group &gr) {
-        if (c16_scan) return true;
+        if (group_one_size(gr) && stream8_c16_applies(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr))) return true;
         if (group_wide(gr)) return true;
         if (group_one_size(gr)) return stream8_applies(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr));
         return stream8_derive_applies(k, group_nk_min(gr), (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr));

@@ -535,9 +535,11 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 template <int K, bool S16, int NKFV, int ND = 0, bool CHAIN = false, int ND2 = 0, bool C16 = false>
 __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN_WAVES : 8) : (CHAIN ? 4 : (NKFV <= 5 ? 6 : 4))))) void stream8_kernel(ScanArgs a, GroupParams gp)
 {
-    // C16: 16-BIT counters (two per dword) for windows of 384 ... 2031 k-mers -- one KFV, k <= 6; a wave's table is 2 * 4^k bytes
-    // (16 waves per CU at k = 6), no count can leave its field, so the heavy-k-mer bookkeeping of the 8-bit form is compiled out.
-    static_assert(!C16 || (NKFV == 1 && K <= 6 && ND == 0 && ND2 == 0), "16-bit counters: one KFV, k <= 6");
+    // C16: 16-BIT counters (two per dword) for windows of 384 ... 2031 k-mers -- k <= 6, up to four KFVs of one window size; a
+    // wave's table is 2 * 4^k bytes (16 waves per CU at k = 6 with one KFV), no count can leave its field, so the heavy-k-mer
+    // bookkeeping of the 8-bit form is compiled out.
+    static_assert(!C16 || (NKFV <= 4 && K <= 6 && ND == 0 && ND2 == 0 && (NKFV == 1 || (S16 && !CHAIN))),
+                  "16-bit counters: k <= 6, one window size; several KFVs (scan only) with int16 S rows");
     // CHAIN: the same walk, but instead of testing thresholds the wave reproduces the reference's running Float64
     // value (kgma_device.h, ChainArgs): one KFV, no dips, no records -- chunk translations and raw increments.
     static_assert(!CHAIN || (NKFV <= 4 && ND == 0 && ND2 == 0), "the chain variant walks 1-4 KFVs of one window size");
@@ -1455,11 +1457,11 @@ bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16)
 
 // 16-bit counter form of the same kernel (C16): one KFV, k = 5, 6, windows of 384 ... 2031 k-mers.  KGMA_STREAM8_C16=0 (testing):
 // off -- such windows then take the older 16-bit stream kernel, and their chains the host.
-bool stream8_c16_applies(int k, int nk, int n_kfv, int64_t n_ref)
+bool stream8_c16_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16)
 {
     const char *e = getenv("KGMA_STREAM8_C16");
-    return stream8_env_on() && !(e && atoi(e) == 0) && n_kfv == 1 && (k == 5 || k == 6) && nk > KGMA_STREAM8_MAX_NK && nk <= KGMA_MAX_NK &&
-           n_ref < ((int64_t)1 << 22);
+    return stream8_env_on() && !(e && atoi(e) == 0) && n_kfv >= 1 && n_kfv <= 4 && (n_kfv == 1 || s16) && (k == 5 || k == 6) &&
+           nk > KGMA_STREAM8_MAX_NK && nk <= KGMA_MAX_NK && n_ref < ((int64_t)1 << 22);
 }
 
 int stream8_variant(int n_kfv) { return n_kfv <= 4 ? (n_kfv < 1 ? 1 : n_kfv) : 8; }   // instantiated NKFV: 1-4 are launched full, 8 takes 5-8 KFVs
@@ -1467,7 +1469,10 @@ int stream8_variant(int n_kfv) { return n_kfv <= 4 ? (n_kfv < 1 ? 1 : n_kfv) : 8
 static size_t stream8_lds(int k, bool s16, int nkfv, int nw, bool c16 = false)
 {
     const size_t NB = (size_t)1 << (2 * k);
-    if (c16) return NB * (s16 ? 2 : 4) + (size_t)nw * NB * 2;         // (one KFV: its S table + 16-bit count tables)
+    if (c16) {                                                        // 16-bit count tables; one KFV: its S table, several: int16 rows
+        const size_t slots16 = nkfv >= 3 ? 4 : (size_t)nkfv;
+        return (nkfv == 1 ? NB * (s16 ? 2 : 4) : NB * 2 * slots16) + (size_t)nw * (NB * 2 + (nkfv > 1 ? (size_t)nkfv * ST_WORDS * 4 : 0));
+    }
     const size_t slots = s16 && nkfv >= 2 ? (nkfv >= 5 ? 8 : nkfv >= 3 ? 4 : 2) : (size_t)nkfv;   // int16 tables of several KFVs: rows of 2 / 4 / 8 slots
     const size_t tabs = k >= 7 ? 0 : nkfv == 5 ? NB * 8 : NB * (s16 ? 2 : 4) * slots;   // k = 7: the S tables stay in global memory; 5: rows of 8 bytes
     return tabs + (size_t)nw * (NB + (nkfv > 1 && k < 7 ? (size_t)nkfv * ST_WORDS * 4 : 0));   // (k = 7: the per-KFV state is in global memory)
@@ -1560,8 +1565,20 @@ static const void *stream8_fn_k(int nkfv)
     }
 }
 
-static const void *stream8_fn_c16(int k, bool s16, bool chain)
+static const void *stream8_fn_c16(int k, bool s16, bool chain, int nkfv = 1)
 {
+    if (nkfv > 1) {                                                   // (scan only, int16 rows)
+        if (chain || !s16) return nullptr;
+        switch ((k == 5 ? 0 : 8) + nkfv) {
+        case 2: return reinterpret_cast<const void *>(&stream8_kernel<5, true, 2, 0, false, 0, true>);
+        case 3: return reinterpret_cast<const void *>(&stream8_kernel<5, true, 3, 0, false, 0, true>);
+        case 4: return reinterpret_cast<const void *>(&stream8_kernel<5, true, 4, 0, false, 0, true>);
+        case 8 + 2: return reinterpret_cast<const void *>(&stream8_kernel<6, true, 2, 0, false, 0, true>);
+        case 8 + 3: return reinterpret_cast<const void *>(&stream8_kernel<6, true, 3, 0, false, 0, true>);
+        case 8 + 4: return reinterpret_cast<const void *>(&stream8_kernel<6, true, 4, 0, false, 0, true>);
+        default: return nullptr;
+        }
+    }
     if (k == 5) {
         if (chain) return s16 ? reinterpret_cast<const void *>(&stream8_kernel<5, true, 1, 0, true, 0, true>) : reinterpret_cast<const void *>(&stream8_kernel<5, false, 1, 0, true, 0, true>);
         return s16 ? reinterpret_cast<const void *>(&stream8_kernel<5, true, 1, 0, false, 0, true>) : reinterpret_cast<const void *>(&stream8_kernel<5, false, 1, 0, false, 0, true>);
@@ -1644,7 +1661,7 @@ static GeomVal stream8_geometry_of(int k, bool s16, int nkfv, int nd, bool chain
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
-    const void *fn = c16 ? stream8_fn_c16(k, s16, chain) : chain ? chain_fn_of(k, s16, nkfv) : stream8_fn_of(k, s16, nkfv, nd, nd2);
+    const void *fn = c16 ? stream8_fn_c16(k, s16, chain, nkfv) : chain ? chain_fn_of(k, s16, nkfv) : stream8_fn_of(k, s16, nkfv, nd, nd2);
     if (fn == nullptr) return GeomVal{-1, 1};
     if (getenv("KGMA_GEOM_DEBUG")) {
         int rv = 0, dv = 0;
@@ -1710,7 +1727,7 @@ void stream8_geometry(int k, bool s16, int nkfv, int nd, int *nw_out, int *block
 // ---- chain variants (1-4 KFVs of one window size, k = 5, 6 or 7): streams resident per CU, launch
 bool chain_applies(int k, int nk, int64_t n_ref, bool s16)
 {
-    if (nk > KGMA_STREAM8_MAX_NK) return stream8_c16_applies(k, nk, 1, n_ref);       // (the 16-bit counter form: k = 5, 6)
+    if (nk > KGMA_STREAM8_MAX_NK) return stream8_c16_applies(k, nk, 1, n_ref, s16);  // (the 16-bit counter form: k = 5, 6)
     return (k == 5 || k == 6 || (k == 7 && s16)) && n_ref < ((int64_t)1 << 22);
 }
 
@@ -1788,15 +1805,16 @@ static int derived_kfvs(const GroupParams &gp)
 static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp_in, hipStream_t st, bool derive_launch, bool wide = false, bool c16 = false)
 {
     GroupParams gp = gp_in;
-    if (c16) {                                      // one KFV, 16-bit counters
+    if (c16) {                                      // 16-bit counters: 1-4 KFVs of one window size
         const bool s16c = gp.s_fits_i16 != 0;
-        const GeomVal v = stream8_geometry_of(gp.k, s16c, 1, 0, false, 0, true);
+        const GeomVal v = stream8_geometry_of(gp.k, s16c, gp.n_kfv, 0, false, 0, true);
         if (v.nw < 1) return hipErrorInvalidConfiguration;
         int nw = v.nw;
         if (gp.stream_slots > 0 && gp.stream_slots < v.nw * v.blocks && gp.stream_slots <= 16) nw = gp.stream_slots;
-        const size_t lds = stream8_lds(gp.k, s16c, 1, nw, true);
+        const size_t lds = stream8_lds(gp.k, s16c, gp.n_kfv, nw, true);
         const unsigned grid = (unsigned)((a.n_tiles + nw - 1) / nw);
-        const void *fn = stream8_fn_c16(gp.k, s16c, false);
+        const void *fn = stream8_fn_c16(gp.k, s16c, false, gp.n_kfv);
+        if (fn == nullptr) return hipErrorInvalidConfiguration;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         ScanArgs a_copy = a;
@@ -1844,8 +1862,8 @@ static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp_in, hi
 // streams resident per CU (what the host sizes the streams for); n_ref = largest reference count of the launch's KFVs
 int stream_slots_per_cu(int k, int nk, int nk_min, int n_longer, int n_kfv, int n_sizes, bool s16, int64_t n_ref, bool u8, int n_plus2)
 {
-    if (n_sizes == 1 && stream8_c16_applies(k, nk, n_kfv, n_ref)) {
-        const GeomVal v = stream8_geometry_of(k, s16, 1, 0, false, 0, true);
+    if (n_sizes == 1 && stream8_c16_applies(k, nk, n_kfv, n_ref, s16)) {
+        const GeomVal v = stream8_geometry_of(k, s16, n_kfv, 0, false, 0, true);
         return v.nw < 1 ? 0 : v.nw * v.blocks;
     }
     if (stream8_wide_applies(k, nk_min, nk, n_kfv, n_ref, u8, s16, n_longer - n_plus2, n_plus2)) {   // (n_plus2: KFVs whose window is two k-mers longer than the shortest)
@@ -1867,7 +1885,7 @@ hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t s
     {
         int64_t nmax = 0;
         for (int j = 0; j < gp.n_kfv; j++) nmax = gp.N[j] > nmax ? gp.N[j] : nmax;
-        if (gp.n_sizes == 1 && stream8_c16_applies(gp.k, gp.nk, gp.n_kfv, nmax)) return launch_stream8(a, gp, st, false, false, true);
+        if (gp.n_sizes == 1 && stream8_c16_applies(gp.k, gp.nk, gp.n_kfv, nmax, gp.s_fits_i16 != 0)) return launch_stream8(a, gp, st, false, false, true);
         int n1 = 0, n2 = 0;
         for (int j = 0; j < gp.n_kfv; j++) { n1 += gp.nk_of[j] == gp.nk_min + 1 ? 1 : 0; n2 += gp.nk_of[j] == gp.nk_min + 2 ? 1 : 0; }
         if (stream8_wide_applies(gp.k, gp.nk_min, gp.nk, gp.n_kfv, nmax, gp.s_fits_u8 != 0, gp.s_fits_i16 != 0, n1, n2)) return launch_stream8(a, gp, st, false, true);

@@ -936,6 +936,58 @@ def test_stream8_five_kfv_launch(ctx, k, lens, monkeypatch):
     assert res["1"][2] == 1 and res["0"][2] >= 2
 
 
+@pytest.mark.parametrize("k,lens", [(6, [288, 520, 520, 521, 700]), (6, [389, 389, 389, 389, 389]), (5, [600, 600, 601]), (6, [2036, 2036])])
+def test_cluster_mode_long_windows_16bit_counters(ctx, k, lens, monkeypatch):
+    """Cluster engine with windows of 384 ... 2031 k-mers at k = 5, 6: launches of the 16-bit counter form of the stream kernel (up to
+    four KFVs of one window size each), next to 8-bit launches for the short windows.  Every distance of every KFV against the
+    integer oracle; hits and dips equal to the bit-sliced kernel's (KGMA_STREAM8_C16=0); chain-mode hits equal to the Float64 oracle."""
+    from kmergma_amd.fasta import Record
+    from tests.helpers import mutate
+    rng = np.random.default_rng(31 * k + sum(lens))
+    KFVs, ws, S, N = [], [], [], []
+    genes = []
+    for i, L in enumerate(lens):
+        base = random_dna(rng, L)
+        genes.append(base)
+        refs = [Record(f"g{i}_{u}", mutate(rng, base, 0.03)) for u in range(3 + i)]
+        RV, w, cons, (s, n) = refprep.gen_ref_ws_cons(refs, k, return_int=True)
+        assert w == L
+        KFVs.append(RV); ws.append(w); S.append(s); N.append(n)
+    maxws = max(ws)
+    g1 = bytearray(_low_complexity_genome(rng, 120_000, maxws))
+    for i, gene in enumerate(genes):
+        pos = 4000 + 11_000 * i
+        g1[pos:pos + len(gene)] = mutate(rng, gene, 0.05)[:len(gene)]
+    g2 = b"A" * (maxws + 500) + random_dna(rng, 3000) + b"AC" * maxws + random_dna(rng, 20_000) + b"N" * 1000
+    contigs = [bytes(g1), g2, random_dna(rng, maxws + k - 2), random_dna(rng, maxws + k), genes[-1] + random_dna(rng, 700)]
+    thr = [float(np.median([orc.kmer_dist_kfv(random_dna(rng, w), RV, k) for _ in range(6)])) * 0.8 for RV, w in zip(KFVs, ws)]
+    T = [orc.int_threshold(t, k, n) for t, n in zip(thr, N)]
+    ohi, oD = orc.omn_scan_int(contigs, S, N, k, ws, T, 100, 55, return_D=True)
+    assert len(ohi) > 0
+    res = {}
+    for c16 in ("1", "0"):
+        monkeypatch.setenv("KGMA_STREAM8_C16", c16)
+        ctx.set_refs(k, KFVs, ws, thr, N)
+        gen = ctx.genome_from_host(contigs)
+        ctx.scan(gen, _lib.MODE_OMN, 100, 55, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
+        assert ctx.kernel_name().startswith("stream8_kernel") == (c16 == "1"), ctx.kernel_name()
+        hits, dips = ctx.hits(), ctx.dips()
+        dists = [ctx.dists(j + 1) for j in range(len(ws))]
+        assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohi]
+        assert [h["D"] for h in hits] == [h["D"] for h in ohi]
+        for j in range(len(ws)):
+            assert np.array_equal(dists[j], oD[j] / (2.0 * k * N[j] ** 2)), (c16, j)
+        if c16 == "1":
+            ctx.scan(gen, _lib.MODE_OMN, 100, 55, _lib.F_CHAIN_REPLAY, None)
+            chain_hits = ctx.hits()
+            fo, _ = orc.omn_scan(contigs, KFVs, k, ws, thr, 100, 55)
+            assert [hit_key(h) for h in chain_hits] == [hit_key(h) for h in fo]
+            assert ctx.stats()["n_tie_flagged"] == 0
+        gen.free()
+        res[c16] = (hits, dips)
+    assert res["1"] == res["0"]
+
+
 def test_stream8_five_kfvs_with_a_large_s_keep_two_launches(ctx):
     """The five-KFV launch keeps its S rows as bytes: a KFV set with an S entry of 256 or more (300 reference sequences
     here) must stay on the launches of at most four -- and give the integer oracle's distances."""
