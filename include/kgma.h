@@ -72,8 +72,7 @@ enum {
                                        scan kernel forms every window's increment in the reference's
                                        operation order; the host adds one integer per 4096-window chunk and
                                        the raw increments where the value may change binade or is wanted:
-                                       kgma_device.h) for k = 5 ... 7 with windows of <= 383 k-mers, k = 5, 6 with
-                                       windows of up to 2031 k-mers, and KFVs whose
+                                       kgma_device.h) for k = 5 ... 7 (windows of up to 2031 k-mers) and KFVs whose
                                        entries are S * (1/N) or S / N bit for bit; otherwise on host threads
                                        (about 1.8 ns per window).  kgma_stats.chain_* report both.  No dip is
                                        left KGMA_HIT_TIE / KGMA_HIT_AT_THRESHOLD.  CONVENTION: the first
@@ -291,7 +290,7 @@ int kgma_host_chain_values(const uint8_t *seq, int64_t len, const double *ref, i
  * what KGMA_F_CHAIN_REPLAY runs for its (record, KFV) pairs.  Window 1's value is the first window's
  * ScaleFactor * 0.5 * sqeuclidean (summed left to right on the host); every later value is bit for bit what a sequential
  * IEEE-754 evaluation of src/GenomeMiner.jl:70-72 gives.  KGMA_E_UNSUPPORTED when the chain kernel does not serve the KFV
- * (k = 5 or 6 with at most 2031 k-mers per window, k = 7 with at most 383; KFV bit-identical to S * (1/N) or S / N).  Two-call pattern via cap / *n_out. */
+ * (k = 5, 6 or 7; KFV bit-identical to S * (1/N) or S / N).  Two-call pattern via cap / *n_out. */
 int kgma_chain_values(kgma_ctx *ctx, const kgma_genome *genome, int64_t contig, int32_t kfv, const int64_t *win_lo,
                       const int64_t *win_hi, int64_t n_intervals, double *out, int64_t cap, int64_t *n_out);
 
@@ -426,7 +425,7 @@ void *kgma_stream(kgma_ctx *ctx);
 
 /* Name of the device kernel the last scan launched ("stream8_kernel<6>" / "stream_kernel<6>" / "scan_kernel<8>"): the
  * count-table stream kernel "stream8_kernel" serves k = 5, 6, 7 (8-bit counters for windows of <= 383 k-mers, up to eight KFVs
- * of neighbouring window sizes per launch; 16-bit counters for one KFV with a longer window at k = 5, 6), the bit-sliced
+ * of neighbouring window sizes per launch; 16-bit counters for longer windows: up to four KFVs of one size at k = 5, 6, one at k = 7), the bit-sliced
  * kernel "scan_kernel" the rest (the round-1 16-bit kernel "stream_kernel" runs under testing switches only). */
 const char *kgma_scan_kernel_name(const kgma_ctx *ctx);
 

@@ -62,9 +62,9 @@ def test_chain_values_every_window(ctx, alp_ref, genes, stream, monkeypatch):
         g.free()
 
 
-@pytest.mark.parametrize("k,gene_len", [(6, 389), (6, 520), (5, 700), (6, 2036)])
+@pytest.mark.parametrize("k,gene_len", [(6, 389), (6, 520), (5, 700), (6, 2036), (7, 390), (7, 900)])
 def test_chain_values_large_windows(ctx, genes, k, gene_len):
-    """Windows of 384 ... 2031 k-mers (k = 5, 6): the chain runs in the 16-bit counter form of the kernel -- every window's
+    """Windows of 384 ... 2031 k-mers (k = 5, 6, 7): the chain runs in the 16-bit counter form of the kernel -- every window's
     value against the reference-order oracle, through homopolymer / N / repeat stretches longer than the window."""
     from kmergma_amd import refprep
     from kmergma_amd.fasta import Record

@@ -398,7 +398,7 @@ def test_other_k_values(ctx, data_dir, genes):
         _assert_single_parity(ctx, contigs, ref, thr)
 
 
-@pytest.mark.parametrize("gene_len,k", [(520, 6), (700, 5), (1900, 6), (2036, 6), (495 + 5, 6), (496 + 5, 6)])
+@pytest.mark.parametrize("gene_len,k", [(520, 6), (700, 5), (1900, 6), (2036, 6), (495 + 5, 6), (496 + 5, 6), (520, 7), (1200, 7)])
 def test_large_windows(ctx, gene_len, k):
     """Windows beyond the 9-plane counter range (495 k-mers) use the 11-plane kernel (<= 2031)."""
     from kmergma_amd.fasta import Record
