@@ -425,7 +425,7 @@ void *kgma_stream(kgma_ctx *ctx);
 
 /* Name of the device kernel the last scan launched ("stream8_kernel<6>" / "stream_kernel<6>" / "scan_kernel<8>"): the
  * count-table stream kernel "stream8_kernel" serves k = 5, 6, 7 (8-bit counters for windows of <= 383 k-mers, up to eight KFVs
- * of neighbouring window sizes per launch; 16-bit counters for longer windows: up to four KFVs of one size at k = 5, 6, one at k = 7), the bit-sliced
+ * of neighbouring window sizes per launch; 16-bit counters for longer windows, up to four KFVs of one size per launch), the bit-sliced
  * kernel "scan_kernel" the rest (the round-1 16-bit kernel "stream_kernel" runs under testing switches only). */
 const char *kgma_scan_kernel_name(const kgma_ctx *ctx);
 

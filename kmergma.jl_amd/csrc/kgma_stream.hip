@@ -538,8 +538,8 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
     // C16: 16-BIT counters (two per dword) for windows of 384 ... 2031 k-mers -- k <= 6, up to four KFVs of one window size; a
     // wave's table is 2 * 4^k bytes (16 waves per CU at k = 6 with one KFV), no count can leave its field, so the heavy-k-mer
     // bookkeeping of the 8-bit form is compiled out.
-    static_assert(!C16 || (NKFV <= 4 && ND == 0 && ND2 == 0 && (NKFV == 1 || (S16 && !CHAIN && K <= 6))),
-                  "16-bit counters: one window size; several KFVs (scan only, k <= 6) with int16 S rows");
+    static_assert(!C16 || (NKFV <= 4 && ND == 0 && ND2 == 0 && (NKFV == 1 || (S16 && !CHAIN))),
+                  "16-bit counters: one window size; several KFVs (scan only) with int16 S rows");
     // CHAIN: the same walk, but instead of testing thresholds the wave reproduces the reference's running Float64
     // value (kgma_device.h, ChainArgs): one KFV, no dips, no records -- chunk translations and raw increments.
     static_assert(!CHAIN || (NKFV <= 4 && ND == 0 && ND2 == 0), "the chain variant walks 1-4 KFVs of one window size");
@@ -1460,7 +1460,7 @@ bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16)
 bool stream8_c16_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16)
 {
     const char *e = getenv("KGMA_STREAM8_C16");
-    if (k == 7 && !(n_kfv == 1 && s16)) return false;                 // (k = 7: one KFV, 32 KiB of counters per wave: five waves per CU)
+    if (k == 7 && !s16) return false;                                 // (k = 7: 32 KiB of counters per wave, five waves per CU; int16 S rows in global memory)
     return stream8_env_on() && !(e && atoi(e) == 0) && n_kfv >= 1 && n_kfv <= 4 && (n_kfv == 1 || s16) && (k == 5 || k == 6 || k == 7) &&
            nk > KGMA_STREAM8_MAX_NK && nk <= KGMA_MAX_NK && n_ref < ((int64_t)1 << 22);
 }
@@ -1571,6 +1571,14 @@ static const void *stream8_fn_c16(int k, bool s16, bool chain, int nkfv = 1)
 {
     if (nkfv > 1) {                                                   // (scan only, int16 rows)
         if (chain || !s16) return nullptr;
+        if (k == 7) {
+            switch (nkfv) {
+            case 2: return reinterpret_cast<const void *>(&stream8_kernel<7, true, 2, 0, false, 0, true>);
+            case 3: return reinterpret_cast<const void *>(&stream8_kernel<7, true, 3, 0, false, 0, true>);
+            case 4: return reinterpret_cast<const void *>(&stream8_kernel<7, true, 4, 0, false, 0, true>);
+            default: return nullptr;
+            }
+        }
         switch ((k == 5 ? 0 : 8) + nkfv) {
         case 2: return reinterpret_cast<const void *>(&stream8_kernel<5, true, 2, 0, false, 0, true>);
         case 3: return reinterpret_cast<const void *>(&stream8_kernel<5, true, 3, 0, false, 0, true>);

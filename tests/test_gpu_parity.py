@@ -936,7 +936,8 @@ def test_stream8_five_kfv_launch(ctx, k, lens, monkeypatch):
     assert res["1"][2] == 1 and res["0"][2] >= 2
 
 
-@pytest.mark.parametrize("k,lens", [(6, [288, 520, 520, 521, 700]), (6, [389, 389, 389, 389, 389]), (5, [600, 600, 601]), (6, [2036, 2036])])
+@pytest.mark.parametrize("k,lens", [(6, [288, 520, 520, 521, 700]), (6, [389, 389, 389, 389, 389]), (5, [600, 600, 601]), (6, [2036, 2036]),
+                                    (7, [288, 520, 520, 520, 521]), (7, [400, 400, 400, 400, 400, 400])])
 def test_cluster_mode_long_windows_16bit_counters(ctx, k, lens, monkeypatch):
     """Cluster engine with windows of 384 ... 2031 k-mers at k = 5, 6: launches of the 16-bit counter form of the stream kernel (up to
     four KFVs of one window size each), next to 8-bit launches for the short windows.  Every distance of every KFV against the
