@@ -72,7 +72,7 @@ enum {
                                        scan kernel forms every window's increment in the reference's
                                        operation order; the host adds one integer per 4096-window chunk and
                                        the raw increments where the value may change binade or is wanted:
-                                       kgma_device.h) for k = 5 ... 7 (windows of up to 2031 k-mers) and KFVs whose
+                                       kgma_device.h) for k = 5 ... 7 (windows of up to 65535 k-mers) and KFVs whose
                                        entries are S * (1/N) or S / N bit for bit; otherwise on host threads
                                        (about 1.8 ns per window).  kgma_stats.chain_* report both.  No dip is
                                        left KGMA_HIT_TIE / KGMA_HIT_AT_THRESHOLD.  CONVENTION: the first
@@ -173,13 +173,20 @@ void kgma_destroy(kgma_ctx *ctx);
 
 /* Upload the reference KFV(s).  ref: m x 4^k row-major Float64 (refVec / refVecs, natural k-mer
  * index order: first base most significant, src/Kmers.jl:37-43).  windowsizes[m], thr[m].
- * DELIBERATE LIMIT: refVec::Vector{Float64} (src/GenomeMiner.jl:6) may be any vector; here a KFV must be S/N with integer S
- * (every KFV gen_ref_ws_cons / cluster_ref_API produce is); anything else is KGMA_E_UNSUPPORTED.
- * n_refs[m]: number of reference sequences averaged into each KFV (KFV = S/N, S integer); the
- * device computes in exact integers with S = round(ref*N).  n_refs == NULL: N is inferred
- * (smallest N <= 2^20 making ref*N integral to 1e-9); KGMA_E_UNSUPPORTED if none exists.
- * Requires 2 <= k <= 10, k < min(windowsizes) (src/API.jl:70,177) and at
- * most 2031 k-mers per window (windowsize - k + 1); KGMA_E_UNSUPPORTED otherwise.
+ * refVec::Vector{Float64} (src/GenomeMiner.jl:6, src/OmnGenomeMiner.jl:9) may be any vector, and so may `ref`:
+ *   - a KFV that is S/N with integer S (every KFV gen_ref_ws_cons / cluster_ref_API produce is one: an average of N integer
+ *     histograms) is scanned in EXACT integers, S = round(ref*N).  n_refs[m] gives N per KFV; n_refs == NULL: N is inferred
+ *     (smallest N <= 2^20 with every ref*N within a relative 1e-12 of an integer);
+ *   - any other finite vector (weighted averages, smoothed or hand-edited profiles; also a KFV that is not S/n_refs for the
+ *     n_refs given) is scanned in Float64 by the generic kernel: every window's distance within ~1e-12 relative of the
+ *     reference's running value; the decisions rounding noise could take either way in the reference -- a window within a
+ *     relative 2^-30 of thr, two minima within 2^-30 of each other -- are flagged exactly like the integer form's exact ties
+ *     (KGMA_HIT_AT_THRESHOLD / KGMA_HIT_TIE), and KGMA_F_CHAIN_REPLAY decides them from the reference's own running value
+ *     (replayed from the caller's table, bit for bit).  kgma_hit.D / kgma_dip.D_* are then round(d * 2kN^2) with N a power of
+ *     two (kgma_kfv_scale), kgma_hit.dist the Float64 distance.
+ * Requires 2 <= k <= 10, k < min(windowsizes) (src/API.jl:70,177) and at most 65535 k-mers per window (windowsize - k + 1:
+ * the window counts are 16-bit; the reference itself has no bound, src/ReferenceGeneration.jl:35-40); KGMA_E_UNSUPPORTED
+ * otherwise, and for S/N KFVs whose largest possible D = sum S^2 + N^2 n^2 does not fit 61 bits.
  * Threshold semantics: with D the exact integer form of the distance (d = D / (2 k N^2)) a window
  * is below thr iff D < T, T = ceil(thr * 2kN^2 * (1 - 2^-30)).  The 2^-30 guard band stands for the
  * rounding noise of the reference's rolling Float64 chain (GenomeMiner.jl:77): windows whose exact
@@ -425,8 +432,11 @@ void *kgma_stream(kgma_ctx *ctx);
 
 /* Name of the device kernel the last scan launched ("stream8_kernel<6>" / "stream_kernel<6>" / "scan_kernel<8>"): the
  * count-table stream kernel "stream8_kernel" serves k = 5, 6, 7 (8-bit counters for windows of <= 383 k-mers, up to eight KFVs
- * of neighbouring window sizes per launch; 16-bit counters for longer windows, up to four KFVs of one size per launch), the bit-sliced
- * kernel "scan_kernel" the rest (the round-1 16-bit kernel "stream_kernel" runs under testing switches only). */
+ * of neighbouring window sizes per launch; 16-bit counters and 64-bit prefix carries for longer windows -- up to 65535 k-mers --
+ * and for prefixes beyond int32, up to four KFVs of one size per launch), the bit-sliced kernel "scan_kernel" the other k up to
+ * 2031 k-mers per window, the generic kernel "gen_kernel<k>" / "gen_kernel<f64,k>" (kgma_generic.hip, one KFV per launch) what is
+ * left: longer windows at k < 5 and k > 7, and every scan with a general Float64 KFV (the round-1 16-bit kernel
+ * "stream_kernel" runs under testing switches only). */
 const char *kgma_scan_kernel_name(const kgma_ctx *ctx);
 
 #ifdef __cplusplus

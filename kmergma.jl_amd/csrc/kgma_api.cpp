@@ -38,16 +38,19 @@ hipError_t launch_synth(uint8_t *ascii, const ContigDesc *cd, int n_contigs, int
 hipError_t launch_scan(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 int stream_waves(int k, int nk, int n_kfv, int n_sizes);
-int stream_slots_per_cu(int k, int nk, int nk_min, int n_longer, int n_kfv, int n_sizes, bool s16, int64_t n_ref, bool u8, int n_plus2);
+int stream_slots_per_cu(int k, int nk, int nk_min, int n_longer, int n_kfv, int n_sizes, bool s16, int64_t n_ref, bool u8, int n_plus2, bool need_wide);
 bool stream8_derive_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool s16);
 bool stream8_wide_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_ref, bool u8, bool s16, int n_plus1, int n_plus2);
 bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16);
 int stream8_variant(int n_kfv);
 int stream8_state_words(int k, int n_kfv);
-bool stream8_c16_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16);
+bool stream8_c16_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16, bool need_wide);
+int generic_slots_per_cu(int k, bool fp);
+bool generic_counts_in_lds(int k);
+hipError_t launch_generic(const ScanArgs &a, const GenParams &g, hipStream_t st);
 hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
-bool chain_applies(int k, int nk, int64_t n_ref, bool s16);
-int chain_slots_per_cu(int k, bool s16, int nkfv, int nk);
+bool chain_applies(int k, int nk, int64_t n_ref, bool s16, bool need_wide);
+int chain_slots_per_cu(int k, bool s16, int nkfv, int nk, bool need_wide);
 hipError_t launch_chain(const ScanArgs &a, const GroupParams &gp, hipStream_t st);
 int pos_tables_per_pass(int k);
 int64_t align_trace_bytes(int m, int n);
@@ -87,6 +90,11 @@ struct KfvInfo {
     int64_t Smax = 0;
     std::vector<int64_t> S;   // natural k-mer order
     std::vector<double> ref;  // the KFV as given (Float64), for the tie resolver
+    bool fits32 = true;       // the prefix E = (D - D0) / 2N and N * count differences fit the int32 kernels (stream8 8-bit form, bit-sliced, ...)
+    bool big_ok = false;      // a 64-window step's LOCAL prefix fits int32: the 16-bit counter form of stream8_kernel (64-bit carries) applies
+    bool fp = false;          // a general Float64 KFV (not S/N): Float64 form of the generic kernel.  N is then a power of two that only
+                              // fixes the host's integer lattice D = round(d * 2kN^2); S is empty
+    double sumR2 = 0;         // fp: sum_x ref[x]^2
     int ref_form = -1;        // how the Float64 entries follow from S, bit for bit, so that the device can form them from S (the chain
                               // kernel does): 0 = RN(S * RN(1/N)) (`answer .* (1/N)`, src/ReferenceGeneration.jl:35,40), 1 = RN(S / N)
                               // (`KFVs[i] ./= lens[i]`, :118) reproduced by the kernel's own division step, -1 = neither
@@ -225,6 +233,8 @@ struct kgma_ctx {
     int32_t *d_Stab = nullptr;        // m x 4^k, device index order (first base least significant)
     std::map<std::vector<int>, int16_t *> sinter;   // k = 7 stream kernel: interleaved int16 S tables per launch group (device)
     int32_t *d_StabC = nullptr;       // the same tables in the stream kernel's index order ((hi bits << k) | lo bits)
+    double *d_Rtab = nullptr;         // m x 4^k Float64, device index order: the KFVs as given (only when one of them is not S/N)
+    uint32_t *d_gctab = nullptr; int64_t gctab_cap = 0;   // generic kernel at k >= 8: count tables of its wave slots (dwords)
     int64_t *d_Wtab = nullptr;        // window size per KFV (export_kernel's tie gather)
     int16_t *d_diff = nullptr; int64_t diff_cap = 0;   // two-kernel cluster path: per-window self-match differences of a tile chunk
     // scan scratch
@@ -426,9 +436,13 @@ std::vector<Group> make_groups(const kgma_ctx *ctx, int mode, bool s8 = false)
             if (s8) {
                 bool s16 = ctx->kfv[(size_t)j].Smax <= 32767;
                 for (int u : g.kfvs) s16 = s16 && ctx->kfv[(size_t)u].Smax <= 32767;
-                const bool c8 = W - ctx->k + 1 <= 383;                  // (longer windows: the 16-bit counter form, one size per launch)
-                fits = (W == wmin && last == wmin && (int)g.kfvs.size() < std::min(s8_max_same, c8 ? KGMA_MAX_GROUP : 4) && (c8 || s16)) ||
-                       (derive_ok && s16 && c8 && W <= wmin + 1 && (int)g.kfvs.size() < 4);
+                // (longer windows, and KFVs whose prefix leaves int32: the 16-bit counter form with 64-bit carries, one size per launch;
+                //  a launch holds KFVs of one form)
+                const bool c8 = W - ctx->k + 1 <= 383 && ctx->kfv[(size_t)j].fits32;
+                const bool c8_front = wmin - ctx->k + 1 <= 383 && ctx->kfv[(size_t)g.kfvs.front()].fits32;
+                fits = c8 == c8_front &&
+                       ((W == wmin && last == wmin && (int)g.kfvs.size() < std::min(s8_max_same, c8 ? KGMA_MAX_GROUP : 4) && (c8 || s16)) ||
+                        (derive_ok && s16 && c8 && W <= wmin + 1 && (int)g.kfvs.size() < 4));
             } else {
                 fits = (int)g.kfvs.size() < KGMA_MAX_GROUP && W - wmin <= KGMA_MAX_DW && (W == last || distinct < KGMA_MAX_SIZES);
             }
@@ -449,6 +463,10 @@ std::vector<Group> make_groups(const kgma_ctx *ctx, int mode, bool s8 = false)
             const Group &g1 = gs[i + 1];
             const size_t total = g0.kfvs.size() + g1.kfvs.size();
             if (total != (ctx->k >= 7 ? 8u : 5u)) continue;
+            bool all32 = true;
+            for (const Group *gp : {static_cast<const Group *>(&g0), &g1})
+                for (int u : gp->kfvs) all32 = all32 && ctx->kfv[(size_t)u].fits32;
+            if (!all32) continue;
             int64_t nmax = 0, smax = 0;
             const int64_t w0 = ctx->kfv[(size_t)g0.kfvs.front()].W;
             int n1 = 0, n2 = 0;
@@ -561,6 +579,8 @@ void kgma_destroy(kgma_ctx *ctx)
     for (double *p : ctx->d_dist) if (p) (void)hipFree(p);
     if (ctx->d_Stab) (void)hipFree(ctx->d_Stab);
     if (ctx->d_StabC) (void)hipFree(ctx->d_StabC);
+    if (ctx->d_Rtab) (void)hipFree(ctx->d_Rtab);
+    if (ctx->d_gctab) (void)hipFree(ctx->d_gctab);
     for (auto &kv2 : ctx->sinter) (void)hipFree(kv2.second);
     if (ctx->d_Wtab) (void)hipFree(ctx->d_Wtab);
     if (ctx->d_diff) (void)hipFree(ctx->d_diff);
@@ -830,42 +850,68 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
             return fail(ctx, KGMA_E_ARG, "the average reference sequence length %lld exceeds/is equal to the chosen kmer length %d. please reduce k.",
                         (long long)f.W, k);
         const int64_t nk = f.W - k + 1;
-        if (nk > KGMA_MAX_NK)
-            return fail(ctx, KGMA_E_UNSUPPORTED, "window size %lld: at most %d k-mers per window are supported", (long long)f.W, KGMA_MAX_NK);
+        if (nk > KGMA_MAX_NK_WIDE)
+            return fail(ctx, KGMA_E_UNSUPPORTED, "window size %lld: at most %d k-mers per window are supported (16-bit window counts)", (long long)f.W,
+                        KGMA_MAX_NK_WIDE);
         const double *r = ref + (size_t)j * (size_t)NB;
+        // Is the KFV S/N with integer S (what gen_ref_ws_cons / cluster_ref_API produce: an average of integer histograms)?  Then the
+        // device computes in exact integers.  Anything else -- refVec::Vector{Float64} may be any vector (src/GenomeMiner.jl:6,
+        // src/OmnGenomeMiner.jl:9) -- takes the Float64 form of the generic kernel.  "Is S/N": every entry times N within 1e-12
+        // (relative) of a non-negative integer, i.e. S/N up to the rounding of its own division.
+        auto is_s_over_n = [&](const int64_t cand, const double tol) {
+            for (int64_t x = 0; x < NB; x++) {
+                const double v = r[x] * (double)cand, rv = std::nearbyint(v);
+                if (!(std::fabs(v - rv) <= tol * std::max(1.0, std::fabs(v))) || rv < 0 || rv > 2.0e9) return false;
+            }
+            return true;
+        };
         int64_t N = 0;
+        bool fp = false;
+        for (int64_t x = 0; x < NB; x++)
+            if (!std::isfinite(r[x])) return fail(ctx, KGMA_E_ARG, "KFV %d entry %lld is not finite", j + 1, (long long)x);
         if (n_refs) {
             N = n_refs[j];
             if (N < 1) return fail(ctx, KGMA_E_ARG, "n_refs[%d] = %lld", j, (long long)N);
+            if (!is_s_over_n(N, 1e-12)) fp = true;
         } else {
-            for (int64_t cand = 1; cand <= (1 << 20) && N == 0; cand++) {
-                bool ok = true;
-                for (int64_t x = 0; x < NB && ok; x++) {
-                    const double v = r[x] * (double)cand;
-                    ok = std::fabs(v - std::nearbyint(v)) <= 1e-9 * std::max(1.0, std::fabs(v));
-                }
-                if (ok) N = cand;
-            }
-            if (N == 0) return fail(ctx, KGMA_E_UNSUPPORTED, "KFV %d is not of the form S/N with integer S and N <= 2^20", j + 1);
+            for (int64_t cand = 1; cand <= (1 << 20) && N == 0; cand++)
+                if (is_s_over_n(cand, 1e-12)) N = cand;
+            if (N == 0) fp = true;
+        }
+        f.ref.assign(r, r + NB);
+        __int128 s2 = 0;
+        if (fp) {
+            // Float64 form.  The host keeps every distance on an integer lattice D = round(d * 2kN^2) with N a power of two chosen so
+            // that the largest possible D stays below 2^61 (resolution 1 / (2kN^2): 8e-14 at k = 6 for windows of a few hundred k-mers)
+            double r2 = 0, amax = 0;
+            for (int64_t x = 0; x < NB; x++) { r2 += r[x] * r[x]; amax = std::max(amax, std::fabs(r[x])); }
+            const double fmax = r2 + (double)nk * (double)nk + 2.0 * (double)nk * amax + 1.0;     // >= sum (ref - c)^2 for any window
+            int q = 20;
+            while (q > 0 && fmax * std::ldexp(1.0, 2 * q) >= std::ldexp(1.0, 61)) q--;
+            if (fmax >= std::ldexp(1.0, 61)) return fail(ctx, KGMA_E_UNSUPPORTED, "KFV %d: entries of magnitude %.3g are outside the device path's range", j + 1, amax);
+            f.fp = true; f.N = (int64_t)1 << q; f.sumR2 = r2;
+            f.S.clear(); f.Smax = INT64_MAX; f.sumS2 = 0;
+            f.fits32 = false; f.big_ok = false; f.ref_form = -1;
+            f.thr = thr[j];
+            threshold_band(thr[j], k, f.N, &f.T, &f.T_hi);
+            continue;
         }
         f.N = N;
-        f.ref.assign(r, r + NB);
         f.S.resize((size_t)NB);
-        __int128 s2 = 0;
         for (int64_t x = 0; x < NB; x++) {
-            const double v = r[x] * (double)N;
-            const double rv = std::nearbyint(v);
-            if (!(std::fabs(v - rv) <= 1e-6 * std::max(1.0, std::fabs(v))) || rv < 0 || rv > 2.0e9)
-                return fail(ctx, KGMA_E_UNSUPPORTED, "KFV %d entry %lld (%.17g) times N=%lld is not a non-negative integer", j + 1,
-                            (long long)x, r[x], (long long)N);
+            const double rv = std::nearbyint(r[x] * (double)N);
             f.S[(size_t)x] = (int64_t)rv;
             f.Smax = std::max(f.Smax, (int64_t)rv);
             s2 += (__int128)f.S[(size_t)x] * f.S[(size_t)x];
         }
-        // the device keeps E = (D - D0)/(2N) and N*diff in int32
+        // What the kernels keep in 32 bits: the int32 kernels E = (D - D0)/(2N) and N * (count difference); the 16-bit counter form of
+        // stream8_kernel the LOCAL prefix of a 64-window step, |e| <= Smax + N n per window (its carries are 64-bit); the generic
+        // kernel nothing (int64 throughout: D itself must fit)
         const __int128 dmax = s2 + (__int128)N * N * nk * nk;
-        if (dmax / (2 * N) >= ((__int128)1 << 29) || (__int128)N * nk >= ((__int128)1 << 30))
-            return fail(ctx, KGMA_E_UNSUPPORTED, "KFV %d: N = %lld with %lld k-mers per window exceeds the int32 range of the device path", j + 1,
+        f.fits32 = !(dmax / (2 * N) >= ((__int128)1 << 29) || (__int128)N * nk >= ((__int128)1 << 30));
+        f.big_ok = (__int128)64 * ((__int128)f.Smax + (__int128)N * nk) <= ((__int128)1 << 30) && N < ((int64_t)1 << 22);
+        if (dmax >= ((__int128)1 << 61))
+            return fail(ctx, KGMA_E_UNSUPPORTED, "KFV %d: N = %lld with %lld k-mers per window exceeds the int64 range of the device path", j + 1,
                         (long long)N, (long long)nk);
         f.sumS2 = (int64_t)s2;
         {
@@ -882,10 +928,24 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
         threshold_band(thr[j], k, N, &f.T, &f.T_hi);
     }
     // upload the plane-index permuted tables
-    std::vector<int32_t> tab((size_t)m * (size_t)NB);
-    for (int j = 0; j < m; j++)
+    std::vector<int32_t> tab((size_t)m * (size_t)NB, 0);
+    bool any_fp = false;
+    for (int j = 0; j < m; j++) {
+        any_fp = any_fp || kv[(size_t)j].fp;
+        if (kv[(size_t)j].fp) continue;
         for (int64_t v = 0; v < NB; v++)
             tab[(size_t)j * (size_t)NB + device_index_of((uint32_t)v, k)] = (int32_t)kv[(size_t)j].S[(size_t)v];
+    }
+    if (ctx->d_Rtab) { (void)hipFree(ctx->d_Rtab); ctx->d_Rtab = nullptr; }
+    if (any_fp) {
+        // the KFVs as given (Float64), in the kernels' index order: what the Float64 form reads
+        std::vector<double> rt((size_t)m * (size_t)NB);
+        for (int j = 0; j < m; j++)
+            for (int64_t v = 0; v < NB; v++)
+                rt[(size_t)j * (size_t)NB + device_index_of((uint32_t)v, k)] = kv[(size_t)j].ref[(size_t)v];
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_Rtab), rt.size() * sizeof(double)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_Rtab, rt.data(), rt.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     if (ctx->d_Stab) { (void)hipFree(ctx->d_Stab); ctx->d_Stab = nullptr; }
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_Stab), tab.size() * sizeof(int32_t)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_Stab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -893,9 +953,11 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
     for (auto &kv2 : ctx->sinter) (void)hipFree(kv2.second);
     ctx->sinter.clear();
     if (k <= KGMA_STREAM_MAX_K) {
-        for (int j = 0; j < m; j++)
+        for (int j = 0; j < m; j++) {
+            if (kv[(size_t)j].fp) continue;
             for (int64_t v = 0; v < NB; v++)
                 tab[(size_t)j * (size_t)NB + stream_index_of((uint32_t)v, k)] = (int32_t)kv[(size_t)j].S[(size_t)v];
+        }
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_StabC), tab.size() * sizeof(int32_t)));
         HIP_TRY(ctx, hipMemcpy(ctx->d_StabC, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
@@ -1404,6 +1466,18 @@ void kgma_genome_free(kgma_ctx *ctx, kgma_genome *g)
 // ------------------------------------------------------------------------------------------
 namespace {
 
+// Two integer distances D of KFV `f` that rounding noise may order either way.  S/N KFVs: exact arithmetic, only equal values tie.
+// Float64 KFVs (f.fp): the device's values and the reference's running value each carry a relative error far below 2^-31, so
+// values within 2^-30 of each other are treated as tied (flagged; the chain replay decides them).
+inline int64_t tie_tol(const KfvInfo &f, int64_t D) { return f.fp ? (int64_t)((double)(D < 0 ? -D : D) * 9.313225746154785e-10) + 2 : 0; }
+inline bool near_tie(const KfvInfo &f, int64_t a, int64_t b)
+{
+    const int64_t d = a > b ? a - b : b - a;
+    return d <= tie_tol(f, std::max(a, b));
+}
+// a Float64 distance on the host's integer lattice D = round(d * 2kN^2)
+inline int64_t lattice_of(const KfvInfo &f, int k, double d) { return (int64_t)std::llround(d * 2.0 * (double)k * (double)f.N * (double)f.N); }
+
 struct Frag {             // one device record in global coordinates
     int32_t contig, kfv;  // kfv 0-based
     int32_t kind;
@@ -1427,12 +1501,27 @@ int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
         const int kfv = (r.kind_kfv >> 8) - 1;
         if (kfv < 0 || kfv >= ctx->m) return fail(ctx, KGMA_E_HIP, "corrupt device record (kfv %d)", kfv + 1);
         const int64_t D0 = ctx->D0[(size_t)kfv * (size_t)n_tiles + (size_t)r.tile];
-        const int64_t twoN = 2 * ctx->kfv[(size_t)kfv].N;
+        const KfvInfo &kf = ctx->kfv[(size_t)kfv];
+        const int64_t twoN = 2 * kf.N;
         Frag f;
-        f.contig = td.contig; f.kfv = kfv; f.kind = r.kind_kfv & 0xFF;
+        f.contig = td.contig; f.kfv = kfv; f.kind = r.kind_kfv & REC_KIND_MASK;
         f.start = td.win0 + r.start; f.end = td.win0 + r.end;
-        f.minD = D0 + twoN * (int64_t)r.minE;
-        f.exitD = D0 + twoN * (int64_t)r.exitE;
+        if (r.kind_kfv & REC_WIDE) {
+            // 64-bit values: an int64 prefix E, or (Float64 KFV) the distance itself
+            const int64_t mv = (int64_t)(((uint64_t)(uint32_t)r.minE_hi << 32) | (uint32_t)r.minE);
+            const int64_t xv = (int64_t)(((uint64_t)(uint32_t)r.exitE_hi << 32) | (uint32_t)r.exitE);
+            if (kf.fp) {
+                double md, xd;
+                memcpy(&md, &mv, sizeof md); memcpy(&xd, &xv, sizeof xd);
+                f.minD = lattice_of(kf, ctx->k, md); f.exitD = lattice_of(kf, ctx->k, xd);
+            } else {
+                f.minD = D0 + twoN * mv; f.exitD = D0 + twoN * xv;
+            }
+        } else {
+            if (kf.fp) return fail(ctx, KGMA_E_HIP, "corrupt device record (int32 values for a Float64 KFV)");
+            f.minD = D0 + twoN * (int64_t)r.minE;
+            f.exitD = D0 + twoN * (int64_t)r.exitE;
+        }
         f.argf = td.win0 + r.argf; f.argl = td.win0 + r.argl;
         f.nmin = r.nmin; f.has_exit = (r.has_exit & 1) != 0;
         f.aux = (r.has_exit >> 1) > 0 ? (int64_t)((r.has_exit >> 1) - 1) * 16 : -1;
@@ -1480,7 +1569,12 @@ int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
             if (!cur.has_exit && nx < n && fr[nx].kind == REC_RUN && fr[nx].contig == cur.contig && fr[nx].kfv == cur.kfv &&
                 fr[nx].start == cur.end + 1) {
                 const Frag &b = fr[nx];
-                if (b.minD < cur.minD) { cur.minD = b.minD; cur.argf = b.argf; cur.argl = b.argl; cur.nmin = b.nmin; cur.aux = b.aux; }
+                const KfvInfo &kf = ctx->kfv[(size_t)cur.kfv];
+                if (kf.fp && near_tie(kf, b.minD, cur.minD)) {                                          // (Float64 KFV: a near tie across fragments)
+                    if (b.minD < cur.minD) { cur.minD = b.minD; cur.argf = b.argf; }
+                    cur.argl = b.argl; cur.nmin += b.nmin; cur.aux = -1;
+                }
+                else if (b.minD < cur.minD) { cur.minD = b.minD; cur.argf = b.argf; cur.argl = b.argl; cur.nmin = b.nmin; cur.aux = b.aux; }
                 else if (b.minD == cur.minD) { cur.argl = b.argl; cur.nmin += b.nmin; cur.aux = -1; }   // tied stretch spans fragments
                 cur.end = b.end; cur.has_exit = b.has_exit; cur.exitD = b.exitD;
                 jx = nx + 1;
@@ -1509,7 +1603,8 @@ int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
         // plateau only when N is not a power of two (ref = S/N is then inexact and the reference's
         // mathematically-zero increments are +-1 ulp noise; with dyadic ref they are exactly 0)
         const int64_t Nk = ctx->kfv[(size_t)cur.kfv].N;
-        if (cur.nmin > 1 && (cur.nmin != cur.argl - cur.argf + 1 || (Nk & (Nk - 1)) != 0)) { d.flags |= KGMA_HIT_TIE; n_tie++; }
+        // (Float64 KFV: the device counts the windows within 2^-30 of the minimum, one per plateau of bitwise equal values)
+        if (cur.nmin > 1 && (ctx->kfv[(size_t)cur.kfv].fp || cur.nmin != cur.argl - cur.argf + 1 || (Nk & (Nk - 1)) != 0)) { d.flags |= KGMA_HIT_TIE; n_tie++; }
         if ((d.exit_pos && d.D_exit <= ctx->kfv[(size_t)cur.kfv].T_hi) || att_at(cur.contig, cur.kfv, cur.start - 1))
             d.flags |= KGMA_HIT_AT_THRESHOLD;
         ctx->dips.push_back(d);
@@ -1545,13 +1640,30 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     // kernel groups up to 8 KFVs of up to 4 sizes.
     const char *kenv = getenv("KGMA_KERNEL");                    // testing only: run the other kernel where both apply
     bool s8_all = k >= 5 && k <= 7 && !(kenv && !strcmp(kenv, "bitslice"));
-    // (a KFV whose window has 384 ... 2031 k-mers at k = 5, 6 takes the 16-bit counter form of the same kernel)
+    // (a KFV whose window has 384 ... 65535 k-mers at k = 5, 6, 7, or whose prefix leaves int32, takes the 16-bit counter form of the
+    //  same kernel, which carries the prefix in 64 bits)
+    auto c16_ok = [&](const KfvInfo &f) {
+        return !f.fp && f.big_ok && stream8_c16_applies(k, (int)(f.W - k + 1), 1, f.N, f.Smax <= 32767, !f.fits32);
+    };
     for (int j = 0; j < m_used && s8_all; j++) {
         const KfvInfo &f = ctx->kfv[(size_t)j];
         const int nkj = (int)(f.W - k + 1);
-        s8_all = stream8_applies(k, nkj, 1, f.N, f.Smax <= 32767) || stream8_c16_applies(k, nkj, 1, f.N, f.Smax <= 32767);
+        s8_all = (!f.fp && f.fits32 && stream8_applies(k, nkj, 1, f.N, f.Smax <= 32767)) || c16_ok(f);
     }
-    const std::vector<Group> groups = make_groups(ctx, mode, s8_all);
+    // The generic kernel (kgma_generic.hip; one KFV per launch) takes the whole scan when a KFV is served by nothing else: a general
+    // Float64 KFV, a window of more than 2031 k-mers or a prefix beyond int32 where the 16-bit stream8 form does not apply
+    // (k < 5, k > 7, S beyond int16 at k = 7, N >= 2^22).  KGMA_KERNEL=generic (testing): always.
+    bool generic_all = kenv && !strcmp(kenv, "generic");
+    for (int j = 0; j < m_used; j++) {
+        const KfvInfo &f = ctx->kfv[(size_t)j];
+        if (f.fp || ((f.W - k + 1 > KGMA_MAX_NK || !f.fits32) && !(s8_all && c16_ok(f)))) generic_all = true;
+    }
+    bool generic_fp = false;
+    for (int j = 0; j < m_used; j++) generic_fp = generic_fp || ctx->kfv[(size_t)j].fp;
+    std::vector<Group> groups;
+    if (generic_all) { for (int j = 0; j < m_used; j++) groups.push_back(Group{ctx->kfv[(size_t)j].W, {j}}); }
+    else groups = make_groups(ctx, mode, s8_all);
+    auto group_need_wide = [&](const Group &gr) { bool w = false; for (int j : gr.kfvs) w = w || !ctx->kfv[(size_t)j].fits32; return w; };
     auto group_nmax = [&](const Group &gr) { int64_t n = 0; for (int j : gr.kfvs) n = std::max(n, ctx->kfv[(size_t)j].N); return n; };
     auto group_one_size = [&](const Group &gr) { return ctx->kfv[(size_t)gr.kfvs.front()].W == ctx->kfv[(size_t)gr.kfvs.back()].W; };
     auto group_s16 = [&](const Group &gr) { bool ok = true; for (int j : gr.kfvs) ok = ok && ctx->kfv[(size_t)j].Smax <= 32767; return ok; };
@@ -1564,7 +1676,9 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         return stream8_wide_applies(k, group_nk_min(gr), (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_u8(gr), group_s16(gr), n1, n2);
     };
     auto group_s8 = [&](const Group &gr) {
-        if (group_one_size(gr) && stream8_c16_applies(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr))) return true;
+        if (generic_all) return true;                                   // (reads the interleaved genome copy, like stream8_kernel)
+        if (group_one_size(gr) && stream8_c16_applies(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr), group_need_wide(gr))) return true;
+        if (group_need_wide(gr)) return false;
         if (group_wide(gr)) return true;
         if (group_one_size(gr)) return stream8_applies(k, (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr));
         return stream8_derive_applies(k, group_nk_min(gr), (int)(gr.W - k + 1), (int)gr.kfvs.size(), group_nmax(gr), group_s16(gr));
@@ -1576,10 +1690,15 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
         if (!strcmp(kv, "bitslice")) use_stream = false;
         if (!strcmp(kv, "stream")) use_stream = k <= KGMA_STREAM_MAX_K;
     }
+    if (generic_all) use_stream = true;                // (a stream kernel: same stream table, same records)
     int stream_nw = 1 << 20;         // streams resident per CU (smallest over the launch groups)
     std::vector<int> launch_slots;
     std::vector<double> launch_weight;
-    if (use_stream)
+    if (generic_all) {
+        stream_nw = generic_slots_per_cu(k, generic_fp);
+        if (stream_nw < 1) return fail(ctx, KGMA_E_HIP, "the generic kernel cannot be launched (k = %d)", k);
+    }
+    if (use_stream && !generic_all)
         for (const Group &gr : groups) {
             int n_sizes = 0;
             int64_t prev = -1;
@@ -1591,7 +1710,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             int n_plus2 = 0;                   // ... two k-mers longer (five-KFV launches)
             for (int j : gr.kfvs) n_plus2 += ctx->kfv[(size_t)j].W == ctx->kfv[(size_t)gr.kfvs.front()].W + 2 ? 1 : 0;
             const int nw = stream_slots_per_cu(k, (int)(gr.W - k + 1), group_nk_min(gr), n_longer, (int)gr.kfvs.size(), n_sizes, s16, group_nmax(gr),
-                                               group_u8(gr), n_plus2);
+                                               group_u8(gr), n_plus2, group_need_wide(gr));
             if (nw < 1) use_stream = false;
             stream_nw = std::min(stream_nw, nw);
             launch_slots.push_back(nw);
@@ -1602,7 +1721,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     // ceil(S / s) nearly full rounds (s = 22 and 32: S = 64 is 3 rounds of 22 and 2 of 32), weighing the launches by
     // their cost; with one residency (or nothing to gain) S = s and there is one round.
     bool natural_slots = false;
-    if (use_stream && !getenv("KGMA_STREAM_MINSLOTS")) {
+    if (use_stream && !generic_all && !getenv("KGMA_STREAM_MINSLOTS")) {
         int s_max = 0;
         for (int sl : launch_slots) s_max = std::max(s_max, sl);
         if (s_max > stream_nw) {
@@ -1627,12 +1746,12 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     const int64_t nc = g->n_contigs;
     const bool want_dists = (flags & KGMA_F_RETURN_DISTS) != 0;
     // (what the stream table was sized for: reserved CUs < 2^10, CUs < 2^14, streams per CU < 2^16 -- 64 bits, no packing games)
-    const uint64_t geom_version = use_stream ? 2u + ((uint64_t)(uint32_t)ctx->reserved_cus << 4) + ((uint64_t)(uint32_t)ctx->n_cus << 16) + ((uint64_t)(uint32_t)stream_nw << 32) : 1u;
+    const uint64_t geom_version = use_stream ? (generic_all ? 3u : 2u) + ((uint64_t)(uint32_t)ctx->reserved_cus << 4) + ((uint64_t)(uint32_t)ctx->n_cus << 16) + ((uint64_t)(uint32_t)stream_nw << 32) : 1u;
     {
         bool s8 = use_stream;
         if (use_stream)
             for (const Group &gr : groups) s8 = s8 && group_s8(gr);
-        snprintf(ctx->kernel_name, sizeof ctx->kernel_name, s8 ? "stream8_kernel<%d>" : use_stream ? "stream_kernel<%d>" : "scan_kernel<%d>", k);   // (+ pos_kernel for multi-KFV groups)
+        snprintf(ctx->kernel_name, sizeof ctx->kernel_name, generic_all ? (generic_fp ? "gen_kernel<f64,%d>" : "gen_kernel<%d>") : s8 ? "stream8_kernel<%d>" : use_stream ? "stream_kernel<%d>" : "scan_kernel<%d>", k);   // (+ pos_kernel for multi-KFV groups)
     }
 
     ctx->dips.clear();
@@ -1694,14 +1813,17 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             // 50.8 Mb: 0.118 ms with one round of 6.2 k windows, 0.124 with two, 0.135 with three), as long as a
             // stream stays long against its warm-up (n k-mers) and the S-table staging of its workgroup.
             {
-                int64_t want = 3, min_windows = 8192;
+                int64_t want = 3, min_windows = std::max<int64_t>(8192, 8 * (maxws - k + 1));   // (a stream's warm-up is its window's n k-mers)
+                if (generic_all && !generic_counts_in_lds(k)) min_windows = std::max<int64_t>(min_windows, (int64_t)1 << (2 * k - 2));   // (and zeroing its global count table)
                 if (const char *re = getenv("KGMA_STREAM_ROUNDS")) want = std::max(1, atoi(re));               // experiments
                 if (const char *re = getenv("KGMA_STREAM_ROUND_WINDOWS")) min_windows = std::max(64, atoi(re));
                 rounds = std::max(rounds, std::min<int64_t>(want, total_nwin / (slots * min_windows)));
             }
             P = (total_nwin + slots * rounds - 1) / (slots * rounds);
             P = ((P + 63) / 64) * 64;
-            P = std::min<int64_t>(std::max<int64_t>(P, KGMA_STREAM_MIN_WINDOWS), KGMA_STREAM_MAX_WINDOWS);
+            // (a stream's warm-up is its window's n k-mers: at least 4 n windows per stream; streams start on 64-window boundaries)
+            P = std::min<int64_t>(std::max<int64_t>(P, std::max<int64_t>(KGMA_STREAM_MIN_WINDOWS, std::min<int64_t>(((4 * (maxws - k + 1) + 63) / 64) * 64, 1 << 16))),
+                                  KGMA_STREAM_MAX_WINDOWS);
             // every record ends with a shorter stream: lengthen the streams until they fit the wave slots
             // again (one stream too many would cost a whole extra round on one CU)
             auto count_streams = [&](int64_t len) {
@@ -1860,6 +1982,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             gp.nk_min = (int32_t)(ctx->kfv[(size_t)gr.kfvs.front()].W - k + 1);
             gp.nblocks = scan_nblocks(gp.nk);
             gp.stream_slots = use_stream && !natural_slots ? stream_nw : 0;
+            gp.need_wide = group_need_wide(gr) ? 1 : 0;
             if (const char *ds = getenv("KGMA_DEBUG_SKIP")) gp.debug_skip = atoi(ds);   // timing experiments only
             for (size_t u = 0; u < gr.kfvs.size(); u++) {
                 const int j = gr.kfvs[u];
@@ -1881,6 +2004,32 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             a.planes = g->d_planes;
             a.inter = g->d_inter;
             a.tiles = ctx->d_tiles;
+            if (generic_all) {
+                const int j = gr.kfvs[0];
+                const KfvInfo &f = ctx->kfv[(size_t)j];
+                const int64_t NBk = (int64_t)1 << (2 * k);
+                GenParams gg;
+                memset(&gg, 0, sizeof gg);
+                gg.k = k; gg.nk = gp.nk; gg.N = (int32_t)f.N; gg.kfv_id = j + 1; gg.fp = f.fp ? 1 : 0;
+                gg.n_slots = (int32_t)((int64_t)std::max(1, ctx->n_cus - ctx->reserved_cus) * stream_nw);
+                gg.T = f.T; gg.T_hi = f.T_hi; gg.sumS2 = f.sumS2;
+                gg.thr_lo = f.thr * (1.0 - 9.313225746154785e-10); gg.thr_hi = f.thr * (1.0 + 9.313225746154785e-10);   // 2^-30
+                gg.sumR2 = f.sumR2; gg.SF = 1.0 / (double)k; gg.inv_scale = gp.inv_scale[0];
+                gg.tie_rel = 9.313225746154785e-10;
+                gg.S = ctx->d_Stab + (size_t)j * (size_t)NBk;
+                gg.R = ctx->d_Rtab ? ctx->d_Rtab + (size_t)j * (size_t)NBk : nullptr;
+                if (f.fp && !gg.R) return fail(ctx, KGMA_E_STATE, "internal: no Float64 table for KFV %d", j + 1);
+                if (!generic_counts_in_lds(k)) {
+                    rc = dev_reserve(ctx, ctx->d_gctab, ctx->gctab_cap, (int64_t)gg.n_slots * (NBk / 2));
+                    if (rc) return rc;
+                    gg.ctab = ctx->d_gctab;
+                }
+                a.D0out = d_D0; a.recs = d_recs; a.rec_count = reinterpret_cast<unsigned int *>(d_cnt); a.rec_cap = ctx->rec_cap;
+                a.n_tiles = (int32_t)n_tiles; a.n_att = reinterpret_cast<unsigned long long *>(d_cnt + 8);
+                HIP_TRY(ctx, launch_generic(a, gg, ctx->stream));
+                ctx->stats.n_launches++;
+                continue;
+            }
             // all tables; the kernel indexes by KFV id.  The 16-bit stream kernel indexes k-mers as (hi bits << k) | lo bits,
             // the bit-sliced kernel and the 8-bit stream kernel by the 2-bit interleaved code (first base least significant)
             a.Stab = (use_stream && !group_s8(gr)) ? ctx->d_StabC : ctx->d_Stab;
@@ -1988,6 +2137,16 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
                                reinterpret_cast<DevRecord *>(ctx->d_res + 16 + ctx->res_d0_slots * 8 + KGMA_AUX_BYTES) + n_inline,
                                ((size_t)n_recs - n_inline) * sizeof(DevRecord), hipMemcpyDeviceToHost));
     ctx->D0.assign(h_D0, h_D0 + (size_t)n_tiles * (size_t)ctx->m);
+    for (int j = 0; j < m_used; j++) {
+        // (Float64 KFV: the kernel wrote each stream's first distance as a double; the host works on the lattice)
+        const KfvInfo &kf = ctx->kfv[(size_t)j];
+        if (!kf.fp) continue;
+        for (int64_t t = 0; t < n_tiles; t++) {
+            double dv;
+            memcpy(&dv, &ctx->D0[(size_t)j * (size_t)n_tiles + (size_t)t], sizeof dv);
+            ctx->D0[(size_t)j * (size_t)n_tiles + (size_t)t] = lattice_of(kf, k, dv);
+        }
+    }
     ctx->firstD.assign((size_t)ctx->m * (size_t)nc, -1);
     for (int j = 0; j < ctx->m; j++)
         for (int64_t c = 0; c < nc; c++) {
@@ -2056,7 +2215,7 @@ struct TieResolver {
         pre_ptr.assign(nd, nullptr);
         for (size_t i = 0; i < nd; i++) {
             const kgma_dip &d = ctx->dips[i];
-            if (!(d.flags & KGMA_HIT_TIE)) continue;
+            if (!(d.flags & KGMA_HIT_TIE) || ctx->kfv[(size_t)(d.kfv - 1)].fp) continue;
             const int64_t W = ctx->kfv[(size_t)(d.kfv - 1)].W;
             const int64_t span = ctx->dip_argl[i] - d.argmin;
             if (d.argmin < 1 || span < 0 || span > MAX_SPAN) continue;
@@ -2120,6 +2279,7 @@ struct TieResolver {
         Result r{false, true, false, cand_lo};
         if (!g && !ctx->fetch) return r;                    // no residues at hand (dips came from another GPU, no residue source set)
         const KfvInfo &f = ctx->kfv[(size_t)kfv];
+        if (f.fp) return r;                                 // (a Float64 KFV has no exact lattice to replay on: its near ties stay flagged for the chain)
         const int k = ctx->k;
         const int64_t NB = (int64_t)1 << (2 * k);
         const uint64_t mask = (uint64_t)NB - 1;
@@ -2257,6 +2417,9 @@ static int replay_hits(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_
                 uint32_t dflags = d.flags;
                 if (ch) {
                     // nothing to decide: argmin is the first window attaining the chain's minimum
+                } else if (f.fp) {
+                    // Float64 KFV: a minimum within rounding noise of the running minimum is flagged (exact order kept)
+                    if (near_tie(f, d.D_min, currmin)) dflags |= KGMA_HIT_TIE;
                 } else if (resolve && improved && (d.flags & KGMA_HIT_TIE)) {
                     // (A) several separated windows attain the dip's minimum
                     const TieResolver::Result r = tr.replay(0, c, d.argmin, d.D_min, d.argmin, ctx->dip_argl[di], d.D_min, false, tr.prefetched(di));
@@ -2349,6 +2512,8 @@ static int replay_hits(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_
                     uint32_t dflags = d.flags;
                     if (ch) {
                         // decided by the Float64 chain replay
+                    } else if (f.fp) {
+                        if (near_tie(f, d.D_min, curr_mins[(size_t)j])) dflags |= KGMA_HIT_TIE;
                     } else if (resolve && improved && (d.flags & KGMA_HIT_TIE)) {
                         const TieResolver::Result r = tr.replay(j, c, d.argmin, d.D_min, d.argmin, ctx->dip_argl[dix], d.D_min, false, tr.prefetched(dix));
                         if (r.ok && !r.sensitive) {
@@ -2457,8 +2622,8 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
         const ChainPair &p = pairs[i];
         const KfvInfo &f = ctx->kfv[(size_t)p.j];
         const int nk = (int)(f.W - k + 1);
-        if (!chain_applies(k, nk, f.N, f.Smax <= 32767) || f.ref_form < 0 || p.last < 2) continue;
-        if (chain_slots_per_cu(k, f.Smax <= 32767, 1, nk) < 1) continue;
+        if (f.fp || !(f.fits32 || f.big_ok) || !chain_applies(k, nk, f.N, f.Smax <= 32767, !f.fits32) || f.ref_form < 0 || p.last < 2) continue;
+        if (chain_slots_per_cu(k, f.Smax <= 32767, 1, nk, !f.fits32) < 1) continue;
         el.push_back(i);
     }
     if (el.empty()) return KGMA_OK;
@@ -2545,7 +2710,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
             const bool s16 = f0.Smax <= 32767;
             size_t e = i + 1;
             while (e < kf.size() && (int)(e - i) < (s16 ? maxg : 1) && ctx->kfv[(size_t)kf[e]].W == f0.W && (ctx->kfv[(size_t)kf[e]].Smax <= 32767) == s16 &&
-                   chain_slots_per_cu(k, s16, (int)(e - i) + 1, (int)(f0.W - k + 1)) > 0)
+                   f0.fits32 && ctx->kfv[(size_t)kf[e]].fits32 && chain_slots_per_cu(k, s16, (int)(e - i) + 1, (int)(f0.W - k + 1), false) > 0)
                 e++;
             Launch L;
             L.kfvs.assign(kf.begin() + (long)i, kf.begin() + (long)e);
@@ -2576,10 +2741,11 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
         // 2^18 (the drift a stream may add stays far below the guard band)
         int64_t T;
         {
-            const int64_t slots = (int64_t)std::max(1, ctx->n_cus) * chain_slots_per_cu(k, L.s16, nslots, nk);
+            const int64_t slots = (int64_t)std::max(1, ctx->n_cus) * chain_slots_per_cu(k, L.s16, nslots, nk, !ctx->kfv[(size_t)L.kfvs[0]].fits32);
             T = (windows + slots * 3 - 1) / (slots * 3);
             if (const char *e = getenv("KGMA_CHAIN_STREAM")) T = atoll(e);                     // experiments / tests
-            T = std::min<int64_t>(std::max<int64_t>(((T + 63) / 64) * 64, 1024), (int64_t)1 << 18);
+            // (a stream's warm-up is its window's n k-mers: streams of at least 4 n transitions)
+            T = std::min<int64_t>(std::max<int64_t>(((T + 63) / 64) * 64, std::max<int64_t>(1024, (((int64_t)4 * nk + 63) / 64) * 64)), (int64_t)1 << 18);
         }
         L.T = T;
         L.t0 = tiles.size();
@@ -2727,6 +2893,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
             gp.nk = gp.nk_min = (int32_t)(ctx->kfv[(size_t)L.kfvs[0]].W - k + 1);
             gp.n_sizes = 1; gp.sizes[0] = gp.nk;
             gp.s_fits_i16 = L.s16 ? 1 : 0;
+            gp.need_wide = ctx->kfv[(size_t)L.kfvs[0]].fits32 ? 0 : 1;
             for (int u = 0; u < nslots; u++) {
                 const KfvInfo &f = ctx->kfv[(size_t)L.kfvs[(size_t)u]];
                 gp.nk_of[u] = gp.nk;
@@ -3008,7 +3175,7 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64
                 bool stop = true;
                 for (size_t u = p.d0; u < p.d1 && !need; u++) {
                     const kgma_dip &d = ctx->dips[u];
-                    if (d.D_min == currmin) need = true;
+                    if (near_tie(ctx->kfv[0], d.D_min, currmin)) need = true;
                     if (d.D_min < currmin) { currmin = d.D_min; CMI = d.argmin + k - 2; stop = false; }
                     if (d.exit_pos == 0 || stop) continue;
                     stop = true;
@@ -3024,10 +3191,11 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64
                 // range is a sub-range of its candidate range max(CMI-buff,1) : CMI+ws-1+buff, so A can only be suppressed
                 // if its candidate range meets that of another dip of the record (any KFV).  Superset taken: equal minima
                 // A before B where A's widest possible candidate range meets another dip's.
-                for (size_t u = p.d0; u < p.d1 && !need; u++) need = ctx->dips[u].D_min == mins[0];
+                const KfvInfo &fj = ctx->kfv[(size_t)j];
+                for (size_t u = p.d0; u < p.d1 && !need; u++) need = near_tie(fj, ctx->dips[u].D_min, mins[0]);
                 for (size_t u = p.d0; u < p.d1 && !need; u++) {
                     if (!dip_meets_other[u]) continue;
-                    for (size_t v = u + 1; v < p.d1 && !need; v++) need = ctx->dips[v].D_min == ctx->dips[u].D_min;
+                    for (size_t v = u + 1; v < p.d1 && !need; v++) need = near_tie(fj, ctx->dips[v].D_min, ctx->dips[u].D_min);
                 }
             }
             if (need) pairs.push_back(std::move(p));
@@ -3665,7 +3833,8 @@ int kgma_chain_export(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int32
         if (src) return src;
     }
     const int k = ctx->k;
-    if (!chain_applies(k, (int)(f.W - k + 1), f.N, f.Smax <= 32767) || f.ref_form < 0 || chain_slots_per_cu(k, f.Smax <= 32767, 1, (int)(f.W - k + 1)) < 1)
+    if (f.fp || !(f.fits32 || f.big_ok) || !chain_applies(k, (int)(f.W - k + 1), f.N, f.Smax <= 32767, !f.fits32) || f.ref_form < 0 ||
+        chain_slots_per_cu(k, f.Smax <= 32767, 1, (int)(f.W - k + 1), !f.fits32) < 1)
         return fail(ctx, KGMA_E_UNSUPPORTED, "the chain kernel does not serve this KFV");
     std::vector<char> done(1, 0);
     ChainDevInfo info;

@@ -15,7 +15,8 @@ constexpr int KGMA_MAX_GROUP = 8;                              // KFVs of one wi
 constexpr int KGMA_NPLANES_SMALL = 9;                          // bit-sliced counter width for <= 495 k-mers per window
 constexpr int KGMA_NPLANES_LARGE = 11;                         // ... for <= 2031
 constexpr int KGMA_MAX_NK_SMALL = 16 * 31 - 1;
-constexpr int KGMA_MAX_NK = 16 * 127 - 1;                      // max k-mers per window (counter range)
+constexpr int KGMA_MAX_NK = 16 * 127 - 1;                      // max k-mers per window of the bit-sliced kernel (counter range)
+constexpr int KGMA_MAX_NK_WIDE = 65535;                        // ... of the 16-bit count-table kernels (stream8 C16 form, generic kernel)
 
 // One tile of the scan grid (built on the host, read by every workgroup).
 struct TileDesc {
@@ -47,6 +48,8 @@ struct GroupParams {
     int32_t stream_slots;                // stream kernels: streams resident per CU the tile table was sized for (all launches of a scan share it)
     int32_t s_fits_u8;                   // every S entry of the launch's KFVs is below 256 (the five-KFV stream8_kernel keeps rows of bytes)
     int32_t s_fits_i16;                  // every S entry of the launch's KFVs fits int16 (stream8_kernel keeps the table as int16)
+    int32_t need_wide;                   // a KFV of the launch needs the 64-bit prefix carry (its E = (D - D0) / 2N leaves int32): the 16-bit
+                                         // counter form of stream8_kernel serves it whatever its window length
     int32_t kfv_id[KGMA_MAX_GROUP];      // 1-based KFV index reported in records
     int32_t N[KGMA_MAX_GROUP];           // reference count of each KFV
     int64_t T[KGMA_MAX_GROUP];           // integer threshold: window below thr  <=>  D < T
@@ -60,8 +63,11 @@ struct GroupParams {
                                          // 1: RN(S / N) -- `KFVs[i] ./= lens[i]`, src/ReferenceGeneration.jl:118
 };
 
-// Device record kinds.
-enum : int32_t { REC_RUN = 0, REC_EXIT = 1, REC_ATT = 2 };
+// Device record kinds (low bits of DevRecord::kind_kfv) and the WIDE flag: the record's two values (minimum, exit) are 64-bit
+// quantities kept in (minE_hi : minE) and (exitE_hi : exitE) -- an int64 prefix E from the kernels that carry the prefix in
+// 64 bits (windows of more than 2031 k-mers, large N), or the bits of a Float64 distance from the Float64 KFV path.  Records
+// without the flag hold int32 E values and leave the two high words unwritten.
+enum : int32_t { REC_RUN = 0, REC_EXIT = 1, REC_ATT = 2, REC_KIND_MASK = 0x3F, REC_WIDE = 0x40 };
 
 // One record emitted by the scan kernel (positions are local to the tile; E is the integer
 // prefix (D - D0[tile]) / (2N)).
@@ -76,7 +82,10 @@ struct DevRecord {
     int32_t exitE;        // RUN: E at end+1 when has_exit
     int32_t has_exit;     // RUN: bit 0 = end+1 was evaluated by the same lane/wave (exitE valid);
                           // bits 1.. = 1 + 16-byte slot of the residues under the tied minimum in the aux region (0: none)
+    int32_t minE_hi;      // REC_WIDE records only: high words of the two values
+    int32_t exitE_hi;
 };
+static_assert(sizeof(DevRecord) == 48, "device records are 48 bytes");
 
 // ---- Float64 chain on the device (stream8_kernel<..., CHAIN>; KGMA_F_CHAIN_REPLAY) --------------------------
 // The reference's running distance is ONE sequential Float64 value per record and KFV: v' = RN(v + inc)
@@ -141,6 +150,25 @@ struct ScanArgs {
     int16_t *diff[KGMA_MAX_SIZES];
     int32_t *wave_state;            // stream8_kernel at k = 7 with several KFVs: per-stream cold state (stream8_state_words() words each)
     ChainArgs chain;                // chain launches only (no other kernel reads it)
+};
+
+// Parameters of one launch of the generic kernel (kgma_generic.hip): ONE KFV, any 2 <= k <= 10, up to 65535 k-mers per
+// window; integer form (S/N KFV, int64 prefix) or Float64 form (any KFV).
+struct GenParams {
+    int32_t k, nk;                       // k-mer length, k-mers per window
+    int32_t N;                           // integer form: reference count
+    int32_t kfv_id;                      // 1-based KFV index reported in records
+    int32_t n_slots;                     // wave slots of the launch (grid x waves per workgroup): the streams are dealt over them
+    int32_t fp;                          // Float64 form
+    int64_t T, T_hi, sumS2;              // integer form: thresholds (as GroupParams), sum_x S[x]^2
+    double thr_lo, thr_hi;               // Float64 form: below thr <=> d < thr_lo; thr_lo <= d <= thr_hi: at threshold
+    double sumR2;                        // Float64 form: sum_x ref[x]^2
+    double SF;                           // ScaleFactor = 1 / k
+    double inv_scale;                    // integer form: 2 k N^2
+    double tie_rel;                      // Float64 form: minima within this relative distance of each other are reported as tied
+    const int32_t *S;                    // integer form: the KFV's S table, 2-bit interleaved index order (first base least significant)
+    const double *R;                     // Float64 form: the KFV as given, same index order
+    uint32_t *ctab;                      // k >= 8: 4^k / 2 dwords of counters per wave slot (global memory)
 };
 
 // Count-table stream kernel (kgma_stream.hip): one wave per stream of consecutive window starts.

@@ -1,0 +1,415 @@
+// kgma_generic.hip -- the count-table stream walk without the specialisations of kgma_stream.hip: any 2 <= k <= 10, windows of
+// up to 65535 k-mers, 64-bit integer prefix -- or a Float64 running value for KFVs that are not S/N (refVec::Vector{Float64},
+// src/GenomeMiner.jl:6, src/OmnGenomeMiner.jl:9, may be any vector).  It serves what the tuned kernels do not: windows of more
+// than 2031 k-mers at k < 5 or k > 7, prefixes beyond int32 where the 16-bit stream8 form does not apply, and every general
+// Float64 KFV.  One KFV per launch (the cluster engine's KFVs are launched one after the other over the same stream table).
+//
+// Same quantity, same records as stream8_kernel (kgma_stream.hip: the per-record body of src/GenomeMiner.jl:32-107 and
+// src/OmnGenomeMiner.jl:55-160): ONE WAVE owns a stream (a run of consecutive window starts of one record) and a table of 4^k
+// 16-bit counters -- in LDS while 2 * 4^k bytes fit a wave's share (k <= 7), else in global memory (k = 8 ... 10: 128 KiB ... 2 MiB
+// per wave, L2 traffic) --, advances 64 windows per step (lane = window), and corrects the counts of the k-mers that several lanes
+// of a step touch with ballots of the lower lanes' transitions.  The waves are persistent (a grid-stride loop over the streams:
+// the global count tables belong to the wave slots, not to the streams) and every wave reaches the loop's end.
+//   integer form:  e = S[l] - S[r] - N (c[l] - 1 - c[r]),  E = (D - D0) / 2N as an int64 prefix, compared with (T - D0) / 2N;
+//   Float64 form:  inc = SF * (1 + c[r] + ref[l] - ref[r] - c[l]) in the reference's operation order (GenomeMiner.jl:70-72:
+//                  the same bits as the reference's increment), d = d0 + prefix, d0 anchored per stream on the first window's
+//                  directly computed distance; windows within a relative 2^-30 of thr are "at threshold", minima within
+//                  tie_rel of each other are reported as tied (nmin > 1) -- what rounding noise could decide differently in the
+//                  reference is flagged, exactly as in the integer form.
+// Records are REC_WIDE: (minE_hi : minE) and (exitE_hi : exitE) hold the int64 E or the Float64 distance's bits.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cstdlib>
+#include <type_traits>
+
+#include "kgma_device.h"
+
+#pragma clang fp contract(off)
+
+namespace kgma {
+
+namespace {
+
+__device__ __forceinline__ int g_uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ int64_t g_uni64(int64_t v)
+{
+    return (int64_t)(((uint64_t)(uint32_t)g_uni((int)(uint32_t)((uint64_t)v >> 32)) << 32) | (uint32_t)g_uni((int)(uint32_t)v));
+}
+__device__ __forceinline__ double g_unid(double v) { return __longlong_as_double(g_uni64(__double_as_longlong(v))); }
+
+__device__ __forceinline__ int64_t g_shfl_up64(int64_t v, int d)
+{
+    const int lo = __shfl_up((int)(uint32_t)v, d), hi = __shfl_up((int)(uint32_t)((uint64_t)v >> 32), d);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+__device__ __forceinline__ int64_t g_shfl_xor64(int64_t v, int d)
+{
+    const int lo = __shfl_xor((int)(uint32_t)v, d), hi = __shfl_xor((int)(uint32_t)((uint64_t)v >> 32), d);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+__device__ __forceinline__ int64_t g_readlane64(int64_t v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+template <class V> struct Ops;
+template <> struct Ops<int64_t> {
+    static __device__ __forceinline__ int64_t scan(int64_t v, int lane)
+    {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int64_t o = g_shfl_up64(v, d); v += lane >= d ? o : 0; }
+        return v;
+    }
+    static __device__ __forceinline__ int64_t sum(int64_t v)
+    {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += g_shfl_xor64(v, d);
+        return v;
+    }
+    static __device__ __forceinline__ int64_t wmin(int64_t v)
+    {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const int64_t o = g_shfl_xor64(v, d); v = o < v ? o : v; }
+        return v;
+    }
+    static __device__ __forceinline__ int64_t lane_of(int64_t v, int l) { return g_readlane64(v, l); }
+    static __device__ __forceinline__ int64_t bits(int64_t v) { return v; }
+    static __device__ __forceinline__ int64_t big() { return INT64_MAX; }
+};
+template <> struct Ops<double> {
+    static __device__ __forceinline__ double scan(double v, int lane)
+    {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const double o = __longlong_as_double(g_shfl_up64(__double_as_longlong(v), d)); v += lane >= d ? o : 0.0; }
+        return v;
+    }
+    static __device__ __forceinline__ double sum(double v)
+    {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __longlong_as_double(g_shfl_xor64(__double_as_longlong(v), d));
+        return v;
+    }
+    static __device__ __forceinline__ double wmin(double v)
+    {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const double o = __longlong_as_double(g_shfl_xor64(__double_as_longlong(v), d)); v = o < v ? o : v; }
+        return v;
+    }
+    static __device__ __forceinline__ double lane_of(double v, int l) { return __longlong_as_double(g_readlane64(__double_as_longlong(v), l)); }
+    static __device__ __forceinline__ int64_t bits(double v) { return __double_as_longlong(v); }
+    static __device__ __forceinline__ double big() { return 1.0e308; }
+};
+
+}  // namespace
+
+template <bool FP, bool CGLOBAL>
+__global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
+{
+    typedef std::conditional_t<FP, double, int64_t> V;
+    typedef Ops<V> O;
+    extern __shared__ uint32_t gsmem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = g_uni((int)(threadIdx.x >> 6));
+    const int nw = (int)(blockDim.x >> 6);
+    const int slot = (int)blockIdx.x * nw + wave;
+    const int k = g.k, nk = g.nk;
+    const int NB = 1 << (2 * k);
+    const uint32_t KM = (uint32_t)NB - 1u;
+    const int CW = NB / 2;                                            // dwords of a count table (two 16-bit counters each)
+    uint32_t *C = CGLOBAL ? g.ctab + (size_t)slot * (size_t)CW : gsmem + (size_t)wave * (size_t)CW;
+    const int kid = g.kfv_id;
+    const int64_t Nn = g.N, twoN = 2 * (int64_t)g.N;
+    double *dist = a.dist[0];
+
+    for (int tile = slot; tile < a.n_tiles; tile += g.n_slots) {
+        for (int i = lane; i < CW; i += 64) C[i] = 0;
+        if constexpr (CGLOBAL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const TileDesc td = a.tiles[tile];
+        const int n_valid = td.n_valid, first_test = td.first_test;
+        const uint32_t *gi = a.inter + 2 * td.word_base;              // 2-bit codes, 16 residues per dword, first residue = bits 0-1
+        const int n_pos = n_valid + nk - 1;
+        const int n_blocks = (n_pos + 63) >> 6;
+        // first window: sum_{p<n} S[K_p] (ref[K_p]) and the pair count
+        V wsum = 0;
+        int64_t pairs = 0;
+        int64_t D0 = 0;                                               // integer form: exact D of the stream's first window
+        double d0 = 0.0;                                              // Float64 form: its distance
+        int64_t TE = 0, TEhi = 0;                                     // integer form: E < TE below thr; TE <= E < TEhi at threshold
+        V carry = 0;
+        // dip under construction (wave-uniform)
+        int in_run = 0, run_start = 0, argf = 0, argl = 0, nmin = 0;
+        V minV = 0;
+
+        for (int b = 0; b < n_blocks; b++) {
+            const int p = (b << 6) + lane;
+            uint32_t kp, ks;
+            {
+                const int ie = p >> 4;
+                const uint32_t w0 = gi[ie], w1 = gi[ie + 1];
+                kp = __builtin_amdgcn_alignbit(w1, w0, 2u * (uint32_t)(p & 15)) & KM;
+            }
+            const bool haveL = p >= nk;
+            {
+                const int pl = haveL ? p - nk : 0;
+                const int il = pl >> 4;
+                const uint32_t w0 = gi[il], w1 = gi[il + 1];
+                ks = __builtin_amdgcn_alignbit(w1, w0, 2u * (uint32_t)(pl & 15)) & KM;
+                ks = haveL ? ks : kp;
+            }
+            const bool differ = kp != ks;                             // GenomeMiner.jl:66: nothing happens if left == right
+            const bool actE = differ || !haveL, actL = differ && haveL;
+            const uint32_t shp = 16u * (kp & 1u), shs = 16u * (ks & 1u);
+            uint32_t wcp, wcs, wop = 0, wos = 0;
+            if constexpr (CGLOBAL) {
+                // counts at the start of the step, read past the vector L1 (the atomics below work in L2), and complete before them
+                wcp = __hip_atomic_load(&C[kp >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wcs = __hip_atomic_load(&C[ks >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wcp), "+v"(wcs) : : "memory");
+                if (actE) wop = __hip_atomic_fetch_add(&C[kp >> 1], 1u << shp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (actL) wos = __hip_atomic_fetch_add(&C[ks >> 1], (uint32_t)(-(int32_t)(1u << shs)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wop), "+v"(wos) : : "memory");
+            } else {
+                wcp = C[kp >> 1];                                     // (LDS operations of a wave complete in order)
+                wcs = C[ks >> 1];
+                if (actE) wop = atomicAdd(&C[kp >> 1], 1u << shp);
+                if (actL) wos = atomicSub(&C[ks >> 1], 1u << shs);
+            }
+            // exact counts of the entering / leaving k-mer in THIS lane's window: the value read, corrected by the transitions of
+            // the lower lanes wherever another lane of the step touched the k-mer (its returned old value then differs from the
+            // value read; windows shorter than a step can enter and leave a k-mer inside one step, whose transient counts could
+            // hide that -- there every acting lane takes the correction rounds)
+            int32_t cP, cS;
+            {
+                const uint32_t cp = (wcp >> shp) & 0xFFFFu, cs = (wcs >> shs) & 0xFFFFu;
+                const uint32_t oldp = (wop >> shp) & 0xFFFFu, olds = (wos >> shs) & 0xFFFFu;
+                const bool all = nk < 64;
+                uint64_t pendE = __ballot(actE && (all || oldp != cp)), pendL = __ballot(actL && (all || olds != cs));
+                int32_t corrP = 0, corrS = 0;
+                if (pendE | pendL) {
+                    const uint64_t AE = __ballot(actE), AL = __ballot(actL);
+                    while ((pendE | pendL) != 0) {
+                        uint32_t x0;
+                        if (pendE) x0 = (uint32_t)__builtin_amdgcn_readlane((int)kp, __builtin_ctzll(pendE));
+                        else x0 = (uint32_t)__builtin_amdgcn_readlane((int)ks, __builtin_ctzll(pendL));
+                        const uint64_t eqP = __ballot(kp == x0), eqS = __ballot(ks == x0);
+                        const uint64_t ME = eqP & AE, ML = eqS & AL;
+                        const int32_t ne = (int32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(ME >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ME, 0u));
+                        const int32_t nl = (int32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(ML >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ML, 0u));
+                        corrP = kp == x0 ? ne - nl : corrP;
+                        corrS = ks == x0 ? ne - nl : corrS;
+                        pendE &= ~eqP;
+                        pendL &= ~eqS;
+                    }
+                }
+                cP = (int32_t)cp + corrP;
+                cS = (int32_t)cs + corrS;
+            }
+            // ---- this lane's transition ------------------------------------------------------------------------------
+            V e = 0;
+            V tab_p = 0;                                              // S[kp] / ref[kp] (warm-up sum)
+            if constexpr (FP) {
+                const double rr = g.R[kp], rl = g.R[ks];
+                tab_p = rr;
+                if (actL) {
+                    double t = (double)(1 + cP);                      // 1 + curr_kmer_freq[right]: an Int addition in the reference
+                    t = t + rl;                                       // + refVec[left]
+                    t = t - rr;                                       // - refVec[right]
+                    t = t - (double)cS;                               // - curr_kmer_freq[left]
+                    e = g.SF * t;
+                }
+            } else {
+                const int64_t Sr = g.S[kp], Sl = g.S[ks];
+                tab_p = Sr;
+                if (actL) e = Sl - Sr - Nn * (int64_t)(cS - 1 - cP);
+            }
+            if ((b << 6) < nk) {                                      // warm-up steps: the stream's first window
+                const bool wu = p < nk;
+                wsum += O::sum(wu ? tab_p : (V)0);
+                pairs += Ops<int64_t>::sum(wu ? (int64_t)cP : 0);
+                if (nk - 1 < (b << 6) + 64) {
+                    if constexpr (FP) {
+                        // sum (ref - c)^2 = sum ref^2 - 2 sum_p ref[K_p] + (n + 2 pairs)   (Kmers.jl:33-44 + the sqeuclidean call sites)
+                        d0 = g_unid(g.SF * 0.5 * ((g.sumR2 - 2.0 * wsum) + (double)((int64_t)nk + 2 * pairs)));
+                        if (lane == 0) a.D0out[(size_t)(kid - 1) * a.n_tiles + tile] = __double_as_longlong(d0);
+                    } else {
+                        D0 = g_uni64(g.sumS2 - twoN * wsum + Nn * Nn * ((int64_t)nk + 2 * pairs));
+                        if (lane == 0) a.D0out[(size_t)(kid - 1) * a.n_tiles + tile] = D0;
+                        // E < TE  <=>  D0 + 2N E < T;  TE <= E < TEhi  <=>  T <= D <= T_hi
+                        const int64_t num = g.T - D0;
+                        TE = num > 0 ? (num + twoN - 1) / twoN : -((-num) / twoN);
+                        const int64_t numh = g.T_hi - D0;
+                        const int64_t TH = numh >= 0 ? numh / twoN : -((-numh + twoN - 1) / twoN);
+                        TEhi = g.T_hi >= g.T && TH + 1 > TE ? TH + 1 : TE;
+                        TE = g_uni64(TE); TEhi = g_uni64(TEhi);
+                    }
+                }
+            }
+            const V pre = O::scan(e, lane);
+            V val = carry + pre;                                      // integer form: E; Float64 form: the sum of increments since the first window
+            if constexpr (FP) {
+                // A window whose increment is exactly 0 has its lower neighbour's value in the reference (GenomeMiner.jl:66-77: no
+                // update, or an update by 0.0).  The tree-shaped prefix sum above does not guarantee that (the two lanes' sums are
+                // rounded along different paths), so every such lane takes the value of the head of its run of zero increments:
+                // plateaus are bitwise plateaus, and the strict running minimum picks their first window like the reference.
+                const uint64_t H = ~__ballot(e == 0.0) | 1ull;        // (lane 0 heads a run: with e = 0 its value is the carry itself)
+                const int head = 63 - __builtin_clzll(H & (~(uint64_t)0 >> (63 - lane)));
+                const int64_t vb = __double_as_longlong(val);
+                const int lo = __shfl((int)(uint32_t)vb, head), hi = __shfl((int)(uint32_t)((uint64_t)vb >> 32), head);
+                val = __longlong_as_double((int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
+            }
+            carry = O::lane_of(val, 63);
+            if constexpr (FP) val = d0 + val;
+            const int q = p - nk + 1;                                 // window start (local) this transition leads to
+            const bool tested = q >= first_test && q < n_valid;
+            bool under, att;
+            if constexpr (FP) { under = tested && val < g.thr_lo; att = tested && !under && val <= g.thr_hi; }
+            else { under = tested && val < TE; att = tested && !under && val < TEhi; }
+            if (dist != nullptr && tested) {
+                if constexpr (FP) dist[td.dist_base + q] = val;
+                else dist[td.dist_base + q] = (double)(D0 + twoN * val) / g.inv_scale;
+            }
+            const uint64_t U = __ballot(under), A = __ballot(att);
+            if ((U | A) == 0 && !in_run) continue;
+
+            // ---- a dip touches this step -------------------------------------------------------------------------------
+            const int q0 = (b << 6) - nk + 1;
+            if (att) {
+                DevRecord rec;
+                rec.tile = tile; rec.kind_kfv = REC_ATT | REC_WIDE | (kid << 8);
+                rec.start = q; rec.end = q; rec.argf = rec.argl = q; rec.nmin = 0; rec.has_exit = 0;
+                const int64_t vb = O::bits(val);
+                rec.minE = rec.exitE = (int32_t)(uint32_t)vb; rec.minE_hi = rec.exitE_hi = (int32_t)(uint32_t)((uint64_t)vb >> 32);
+                const unsigned int idx = atomicAdd(a.rec_count, 1u);
+                if (idx < a.rec_cap) a.recs[idx] = rec;
+                atomicAdd(a.n_att, 1ull);
+            }
+            const uint64_t CONT = FP ? __ballot(e == (V)0) : 0;        // lanes whose value is bitwise their lower neighbour's
+            int cursor = 0;
+            while (cursor < 64) {
+                const uint64_t rem = ~(uint64_t)0 << cursor;
+                if (in_run) {
+                    const uint64_t nz = ~U & rem;
+                    const int end_lane = nz ? __builtin_ctzll(nz) : 64;
+                    if (end_lane > cursor) {
+                        const bool inseg = lane >= cursor && lane < end_lane;
+                        const V segmin = O::wmin(inseg ? val : O::big());
+                        const uint64_t eq = __ballot(inseg && val == segmin);
+                        const int fl = __builtin_ctzll(eq);
+                        if constexpr (FP) {
+                            // windows within tie_rel of the segment's minimum: the reference's rounding noise may order them
+                            // differently.  A window whose increment is exactly 0 continues its lower neighbour's value bit for bit
+                            // (GenomeMiner.jl:66-77: no update, or an update by 0): one plateau counts once.
+                            const double tol = g.tie_rel * fabs(segmin);
+                            const uint64_t near = __ballot(inseg && val <= segmin + tol);
+                            uint64_t starts = near & ~(CONT & (near << 1));
+                            const int ll2 = 63 - __builtin_clzll(near);
+                            if (nmin != 0 && cursor == 0 && (near & CONT & 1u) && argl == q0 - 1) starts &= ~(uint64_t)1;   // the plateau came in from the previous step
+                            const int pc = __builtin_popcountll(starts);
+                            const double mtol = g.tie_rel * fabs(minV);
+                            if (nmin == 0 || segmin < minV - mtol) { minV = segmin; argf = q0 + fl; argl = q0 + ll2; nmin = pc > 0 ? pc : 1; }
+                            else if (segmin <= minV + mtol) {
+                                if (segmin < minV) { minV = segmin; argf = q0 + fl; }
+                                argl = q0 + ll2; nmin += pc;
+                            }
+                        } else {
+                            const int ll2 = 63 - __builtin_clzll(eq), pc = __builtin_popcountll(eq);
+                            if (nmin == 0 || segmin < minV) { minV = segmin; argf = q0 + fl; argl = q0 + ll2; nmin = pc; }
+                            else if (segmin == minV) { argl = q0 + ll2; nmin += pc; }
+                        }
+                    }
+                    if (end_lane < 64) {
+                        const int qe = q0 + end_lane;
+                        const V exitV = O::lane_of(val, end_lane);
+                        if (lane == 0) {
+                            DevRecord rec;
+                            rec.tile = tile; rec.kind_kfv = REC_RUN | REC_WIDE | (kid << 8);
+                            rec.start = run_start; rec.end = qe - 1; rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
+                            rec.has_exit = qe < n_valid ? 1 : 0;
+                            const int64_t mb = O::bits(minV), xb = O::bits(exitV);
+                            rec.minE = (int32_t)(uint32_t)mb; rec.minE_hi = (int32_t)(uint32_t)((uint64_t)mb >> 32);
+                            rec.exitE = (int32_t)(uint32_t)xb; rec.exitE_hi = (int32_t)(uint32_t)((uint64_t)xb >> 32);
+                            const unsigned int idx = atomicAdd(a.rec_count, 1u);
+                            if (idx < a.rec_cap) a.recs[idx] = rec;
+                        }
+                        in_run = 0;
+                        cursor = end_lane;
+                    } else {
+                        cursor = 64;
+                    }
+                } else {
+                    const uint64_t nu = U & rem;
+                    if (!nu) break;
+                    cursor = __builtin_ctzll(nu);
+                    in_run = 1; run_start = q0 + cursor; nmin = 0; minV = 0; argf = argl = run_start;
+                }
+            }
+        }
+        // a run still open at the end of the stream (the host joins it with the next stream's)
+        if (in_run && lane == 0) {
+            DevRecord rec;
+            rec.tile = tile; rec.kind_kfv = REC_RUN | REC_WIDE | (kid << 8);
+            rec.start = run_start; rec.end = n_valid - 1; rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
+            rec.has_exit = 0;
+            const int64_t mb = O::bits(minV);
+            rec.minE = (int32_t)(uint32_t)mb; rec.minE_hi = (int32_t)(uint32_t)((uint64_t)mb >> 32);
+            rec.exitE = 0; rec.exitE_hi = 0;
+            const unsigned int idx = atomicAdd(a.rec_count, 1u);
+            if (idx < a.rec_cap) a.recs[idx] = rec;
+        }
+    }
+}
+
+// ---- geometry + launch ----------------------------------------------------------------------------------------------
+bool generic_counts_in_lds(int k) { return k <= 7; }                  // 2 * 4^k bytes per wave: 32 KiB at k = 7
+
+static int generic_waves(int k)                                       // waves (= streams) per workgroup
+{
+    if (!generic_counts_in_lds(k)) return 4;
+    const size_t per = (size_t)2 << (2 * k);
+    const size_t w = (((size_t)160 << 10) - 1024) / per;
+    return (int)(w > 16 ? 16 : w);
+}
+
+static const void *generic_fn(bool fp, bool cglobal)
+{
+    if (fp) return cglobal ? reinterpret_cast<const void *>(&gen_kernel<true, true>) : reinterpret_cast<const void *>(&gen_kernel<true, false>);
+    return cglobal ? reinterpret_cast<const void *>(&gen_kernel<false, true>) : reinterpret_cast<const void *>(&gen_kernel<false, false>);
+}
+
+// streams resident per CU (what the host sizes the stream table and the global count tables for)
+int generic_slots_per_cu(int k, bool fp)
+{
+    const bool cg = !generic_counts_in_lds(k);
+    const int nw = generic_waves(k);
+    const size_t lds = cg ? 0 : (size_t)nw * ((size_t)2 << (2 * k));
+    const void *fn = generic_fn(fp, cg);
+    int blocks = 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64 * nw, lds) != hipSuccess || blocks < 1) {
+        (void)hipGetLastError();
+        blocks = 1;
+    }
+    if (cg) blocks = 1;                                               // (global count tables: 2 * 4^k bytes per slot)
+    if (blocks * nw > 32) blocks = 32 / nw;
+    return nw * (blocks < 1 ? 1 : blocks);
+}
+
+hipError_t launch_generic(const ScanArgs &a, const GenParams &g, hipStream_t st)
+{
+    if (a.n_tiles <= 0) return hipSuccess;
+    const bool cg = !generic_counts_in_lds(g.k);
+    const int nw = generic_waves(g.k);
+    if (nw < 1 || g.n_slots < nw || g.n_slots % nw != 0) return hipErrorInvalidConfiguration;
+    if (cg && g.ctab == nullptr) return hipErrorInvalidValue;
+    const size_t lds = cg ? 0 : (size_t)nw * ((size_t)2 << (2 * g.k));
+    const void *fn = generic_fn(g.fp != 0, cg);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    ScanArgs a_copy = a;
+    GenParams g_copy = g;
+    void *args[2] = {&a_copy, &g_copy};
+    return hipLaunchKernel(fn, dim3((unsigned)(g.n_slots / nw)), dim3(64u * (unsigned)nw), args, lds, st);
+}
+
+}  // namespace kgma

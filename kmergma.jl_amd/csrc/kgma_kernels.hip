@@ -1155,7 +1155,7 @@ __device__ __forceinline__ void tie_gather_body(DevRecord *__restrict__ recs, co
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
     for (unsigned int i = wave; i < n; i += n_waves) {
         const DevRecord r = recs[i];
-        if ((r.kind_kfv & 0xFF) != REC_RUN || r.nmin <= 1) continue;
+        if ((r.kind_kfv & REC_KIND_MASK) != REC_RUN || r.nmin <= 1) continue;
         const TileDesc td = tiles[r.tile];
         const ContigDesc c = cd[td.contig];
         const int64_t W = Wtab[(r.kind_kfv >> 8) - 1];

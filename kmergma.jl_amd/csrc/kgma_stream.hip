@@ -540,6 +540,27 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
     // bookkeeping of the 8-bit form is compiled out.
     static_assert(!C16 || (NKFV <= 4 && ND == 0 && ND2 == 0 && (NKFV == 1 || (S16 && !CHAIN))),
                   "16-bit counters: one window size; several KFVs (scan only) with int16 S rows");
+    // BIG (the 16-bit counter form): windows of up to 65535 k-mers.  The prefix E = (D - D0) / 2N of such windows leaves int32
+    // (N n^2 / 2), so the stream's carry, its thresholds and the dip state are 64-bit SCALARS; the lanes keep the step's LOCAL
+    // prefix (|local| <= 64 (Smax + N n) < 2^31, checked on the host) and compare it with threshold - carry, clamped to int32.
+    // Records carry 64-bit values (REC_WIDE).
+    constexpr bool BIG = C16;
+    typedef std::conditional_t<BIG, int64_t, int32_t> hot_t;
+    auto uni64 = [](const int64_t v) __attribute__((always_inline)) -> int64_t {
+        return (int64_t)(((uint64_t)(uint32_t)uni((int)(uint32_t)((uint64_t)v >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)v));
+    };
+    auto clamp32 = [](const int64_t v) __attribute__((always_inline)) -> int32_t {
+        return v > 0x7FFFFFFFll ? 0x7FFFFFFF : (v < -0x7FFFFFFFll - 1 ? -0x7FFFFFFF - 1 : (int32_t)v);
+    };
+    // (BIG: 64-bit state in two words -- the threshold's high word in ST_CARRY, the running minimum's in ST_INRUN, the warm-up
+    //  pair count's in ST_PAD0; none of the three is used otherwise)
+    auto st_ld64 = [](const int32_t *st, const int lo, const int hi) __attribute__((always_inline)) -> int64_t {
+        return (int64_t)(((uint64_t)(uint32_t)uni(st[hi]) << 32) | (uint32_t)uni(st[lo]));
+    };
+    auto st_st64 = [](int32_t *st, const int lo, const int hi, const int64_t v) __attribute__((always_inline)) {
+        st[lo] = (int32_t)(uint32_t)v; st[hi] = (int32_t)(uint32_t)((uint64_t)v >> 32);
+    };
+    (void)uni64; (void)clamp32; (void)st_ld64; (void)st_st64;
     // CHAIN: the same walk, but instead of testing thresholds the wave reproduces the reference's running Float64
     // value (kgma_device.h, ChainArgs): one KFV, no dips, no records -- chunk translations and raw increments.
     static_assert(!CHAIN || (NKFV <= 4 && ND == 0 && ND2 == 0), "the chain variant walks 1-4 KFVs of one window size");
@@ -617,7 +638,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
 #pragma unroll
     for (int i = 0; i < ST_WORDS; i++) st_reg[i] = 0;
     // hot per-KFV state (wave-uniform): prefix carry, threshold; one bit per KFV for "inside a dip", "has a guard band", "distances"
-    int32_t h_carry[NKFV], h_TE[NKFV];
+    hot_t h_carry[NKFV], h_TE[NKFV];
 #pragma unroll
     for (int j = 0; j < NKFV; j++) { h_carry[j] = 0; h_TE[j] = 0; }
     uint32_t inrun_mask = 0, att_mask = 0, dist_mask = 0;
@@ -700,20 +721,21 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
     int c_chunk_b0 = 0;                                               // ... of the chunk
     int64_t c_gid[NKFV];
     uint64_t c_hot[NKFV];                                             // steps of this chunk that hold a wanted window
-    int32_t c_Elo[NKFV], c_Ehi[NKFV];                                 // E range (stream-relative) that stays inside the binade, guard band
+    hot_t c_Elo[NKFV], c_Ehi[NKFV];                                   // E range (stream-relative) that stays inside the binade, guard band
                                                                       // off; empty (lo > hi): no binade is known to hold
+    constexpr hot_t E_EMPTY_LO = BIG ? (hot_t)((int64_t)1 << 62) : (hot_t)0x7FFFFFFF, E_EMPTY_HI = BIG ? (hot_t)(-((int64_t)1 << 62)) : (hot_t)(-0x7FFFFFFF - 1);
     uint32_t c_XLhi[NKFV];                                            // high dword of 2^e
 #pragma unroll
     for (int j = 0; j < NKFV; j++) {
         c_acc[j] = 0; c_corr[j] = 0; c_dA[j] = 0; c_P[j] = 0; c_state[j] = CS_SPLIT; c_ent[j] = 0; c_run_b0[j] = 0; c_gid[j] = 0; c_hot[j] = 0;
-        c_Elo[j] = 0x7FFFFFFF; c_Ehi[j] = -0x7FFFFFFF - 1; c_XLhi[j] = 0;
+        c_Elo[j] = E_EMPTY_LO; c_Ehi[j] = E_EMPTY_HI; c_XLhi[j] = 0;
     }
     // the slots whose chain this record needs (several KFVs of one window size share the count table of a launch; a record
     // may be flagged for some of them only: the stream carries the slots' mask in TileDesc::first_test)
     const uint32_t c_active = CHAIN && NKFV > 1 ? (uint32_t)uni((int)td.first_test) : 1u;
     // binade of the exact distance D / (2kN^2), with the E range in which the reference's value provably shares it
     auto chain_binade = [&](const int j, const int64_t D) __attribute__((always_inline)) {
-        c_Elo[j] = 0x7FFFFFFF; c_Ehi[j] = -0x7FFFFFFF - 1;
+        c_Elo[j] = E_EMPTY_LO; c_Ehi[j] = E_EMPTY_HI;
         if (D <= 0) return;
         const double scale = gpp->inv_scale[j];                       // 2kN^2 (an integer)
         const double Dd = (double)D;
@@ -725,10 +747,12 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
         const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
         const double twoN = 2.0 * (double)gpp->N[j];
         double el = ceil((lo - (double)D0) / twoN), eh = floor((hi - (double)D0) / twoN);
-        el = el < -1073741824.0 ? -1073741824.0 : el;
-        eh = eh > 1073741824.0 ? 1073741824.0 : eh;
+        constexpr double ELIM = BIG ? 2305843009213693952.0 /* 2^61 */ : 1073741824.0;
+        el = el < -ELIM ? -ELIM : el;
+        eh = eh > ELIM ? ELIM : eh;
         if (!(el <= eh)) return;
-        c_Elo[j] = uni((int32_t)el); c_Ehi[j] = uni((int32_t)eh);
+        if constexpr (BIG) { c_Elo[j] = uni64((int64_t)el); c_Ehi[j] = uni64((int64_t)eh); }
+        else { c_Elo[j] = uni((int32_t)el); c_Ehi[j] = uni((int32_t)eh); }
         c_XLhi[j] = (uint32_t)uni((int32_t)((uint32_t)(e + 1023) << 20));
     };
     // n units of the pool (16 bytes each); past its end nothing is written and the launch is repeated with a larger one
@@ -796,7 +820,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
         }
         c_ent[j] += 1;
         run_reset(j, b + 1);
-        c_Elo[j] = 0x7FFFFFFF; c_Ehi[j] = -0x7FFFFFFF - 1;            // the binade is looked up again at the next step
+        c_Elo[j] = E_EMPTY_LO; c_Ehi[j] = E_EMPTY_HI;                 // the binade is looked up again at the next step
     };
     auto chain_begin = [&](const int b) __attribute__((always_inline)) {
         c_chunk_b0 = b;
@@ -836,12 +860,20 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
         int64_t na = Thj >= Tj ? TH64 - TE64 + 1 : 0;
         if (na < 0) na = 0;
         if (na > 0x3FFFFFFF) na = 0x3FFFFFFF;
-        if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; na = 0; }
-        if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; na = 0; }
-        // (the step compares against TE + natt: "below or at the threshold" is ONE test on its fast path; the cold path
-        //  takes the two apart with TE from the KFV's state)
-        h_TE[j] = uni((int32_t)(TE64 + na));
-        st[ST_TE] = (int32_t)TE64;
+        if constexpr (BIG) {
+            constexpr int64_t LIM = (int64_t)1 << 61;
+            if (TE64 > LIM) { TE64 = LIM; na = 0; }
+            if (TE64 < -LIM) { TE64 = -LIM; na = 0; }
+            h_TE[j] = uni64(TE64 + na);
+            st_st64(st, ST_TE, ST_CARRY, TE64);
+        } else {
+            if (TE64 > 0x3FFFFFFF) { TE64 = 0x3FFFFFFF; na = 0; }
+            if (TE64 < -0x3FFFFFFF) { TE64 = -0x3FFFFFFF; na = 0; }
+            // (the step compares against TE + natt: "below or at the threshold" is ONE test on its fast path; the cold path
+            //  takes the two apart with TE from the KFV's state)
+            h_TE[j] = uni((int32_t)(TE64 + na));
+            st[ST_TE] = (int32_t)TE64;
+        }
         st[ST_NATT] = (int32_t)na;
         att_mask = (att_mask & ~(1u << j)) | (uni((int32_t)na) != 0 ? 1u << j : 0u);
     };
@@ -1065,12 +1097,13 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
                     const int64_t ssum = wave_sum_i64(wu ? (int64_t)Sr[j] : 0);
                     const int64_t psum = wave_sum_i64(wu ? (int64_t)cP : 0);
                     int64_t sumS = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_SUMHI]) << 32) | (uint32_t)uni(st[ST_SUMLO])) + ssum;
-                    const int32_t pairs = uni(st[ST_PAIRS]) + (int32_t)psum;
+                    int64_t pairs;                                    // (n^2 / 2 at most: beyond int32 for windows of more than 65535 / sqrt 2 k-mers)
+                    if constexpr (BIG) { pairs = st_ld64(st, ST_PAIRS, ST_PAD0) + psum; st_st64(st, ST_PAIRS, ST_PAD0, pairs); }
+                    else { const int32_t p32 = uni(st[ST_PAIRS]) + (int32_t)psum; st[ST_PAIRS] = p32; pairs = p32; }
                     st[ST_SUMLO] = (int32_t)(uint32_t)sumS;
                     st[ST_SUMHI] = (int32_t)(uint32_t)((uint64_t)sumS >> 32);
-                    st[ST_PAIRS] = pairs;
                     if (nk - 1 < (b << 6) + 64) {                     // last warm-up position is in this step
-                        const int64_t D0 = gpp->sumS2[j] - twoN * sumS + (int64_t)Nj * Nj * ((int64_t)nk + 2 * (int64_t)pairs);
+                        const int64_t D0 = gpp->sumS2[j] - twoN * sumS + (int64_t)Nj * Nj * ((int64_t)nk + 2 * pairs);
                         if (lane == 0) a.D0out[(size_t)(gpp->kfv_id[j] - 1) * a.n_tiles + tile] = D0;
                         set_first_window(j, st, D0);
                     }
@@ -1101,9 +1134,10 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
 #pragma unroll
             for (int j = 0; j < NKFV; j++) {
                 if (NKFV > 1 && !((c_active >> j) & 1u)) continue;
-                const int32_t carry_prev = h_carry[j];
-                const int32_t Ecur = sc[j] + carry_prev;              // (D - D0) / 2N after this lane's transition
-                h_carry[j] = __builtin_amdgcn_readlane(Ecur, 63);
+                const hot_t carry_prev = h_carry[j];
+                int32_t Ecur;                                         // (D - D0) / 2N after this lane's transition (BIG: minus carry_prev)
+                if constexpr (BIG) { Ecur = sc[j]; h_carry[j] = carry_prev + (int64_t)__builtin_amdgcn_readlane(Ecur, 63); }
+                else { Ecur = sc[j] + carry_prev; h_carry[j] = __builtin_amdgcn_readlane(Ecur, 63); }
                 double inc = 0.0;
                 if (ACT != 0) {
                     // (plain operators: this file is compiled with fp contract off, see the pragma at its top -- the __dmul_rn /
@@ -1139,7 +1173,10 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
                         const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
                         chain_binade(j, D0 + 2 * (int64_t)gpp->N[j] * (int64_t)carry_prev);
                     }
-                    const uint64_t inl = __builtin_amdgcn_sicmp(Ecur, c_Elo[j], 39 /* sge */) & __builtin_amdgcn_sicmp(Ecur, c_Ehi[j], 41 /* sle */);
+                    int32_t elo, ehi;
+                    if constexpr (BIG) { elo = clamp32(c_Elo[j] - carry_prev); ehi = clamp32(c_Ehi[j] - carry_prev); }
+                    else { elo = c_Elo[j]; ehi = c_Ehi[j]; }
+                    const uint64_t inl = __builtin_amdgcn_sicmp(Ecur, elo, 39 /* sge */) & __builtin_amdgcn_sicmp(Ecur, ehi, 41 /* sle */);
                     raw = (inl | ~ACT) != ~(uint64_t)0;
                 }
                 if (raw) {
@@ -1204,11 +1241,19 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
             d2_prev_ks = (uint32_t)__builtin_amdgcn_readlane((int)ks, 63);
         }
         int32_t E[NKFV];
+        hot_t base[NKFV];                                             // BIG: the carry the step started on (E[j] is then the LOCAL prefix)
         uint64_t anyU = 0;                                            // (the KFVs' masks are formed again on the cold path: not kept in scalar registers)
 #pragma unroll
         for (int j = 0; j < NKFV; j++) {
-            E[j] = 0;
+            E[j] = 0; base[j] = 0;
             if (!FULL && j >= n_kfv) continue;
+            if constexpr (BIG) {
+                base[j] = h_carry[j];
+                E[j] = sc[j];
+                h_carry[j] = base[j] + (int64_t)__builtin_amdgcn_readlane(E[j], 63);
+                anyU |= __builtin_amdgcn_sicmp(E[j], clamp32(h_TE[j] - base[j]), 40 /* slt */) & TESTED;
+                continue;
+            }
             E[j] = sc[j] + h_carry[j];
             h_carry[j] = __builtin_amdgcn_readlane(E[j], 63);
             if (ND2 > 0 && ((dm2 >> j) & 1u)) {
@@ -1268,7 +1313,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
                 const int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
                 const int64_t twoN = 2 * (int64_t)gp.N[j];
                 const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
-                a.dist[j][td.dist_base + q_cold() - dj] = (double)(D0 + twoN * (int64_t)E[j]) / gpp->inv_scale[j];
+                a.dist[j][td.dist_base + q_cold() - dj] = (double)(D0 + twoN * ((int64_t)base[j] + (int64_t)E[j])) / gpp->inv_scale[j];
             }
         }
         if (anyU == 0 && inrun_mask == 0) return;                     // fast path: nothing below or at any threshold
@@ -1278,11 +1323,16 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
             if (!FULL && j >= n_kfv) continue;
             int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
             const int32_t Ej = E[j];
+            const hot_t bj = base[j];                                  // (0 unless BIG)
             const int dj = DERIVE ? (int)((dm1 >> j) & 1u) + 2 * (int)((dm2 >> j) & 1u) : 0;
-            uint64_t U = __builtin_amdgcn_sicmp(Ej, h_TE[j], 40 /* slt */) & (dj == 2 ? TESTED_D2 : dj ? TESTED_D : TESTED);   // tested windows below TE + natt
+            int32_t tcmp, tcmp_te;                                     // TE + natt and TE as this step's lanes see them
+            if constexpr (BIG) { tcmp = clamp32(h_TE[j] - bj); tcmp_te = clamp32(st_ld64(st, ST_TE, ST_CARRY) - bj); }
+            else { tcmp = h_TE[j]; tcmp_te = 0; }
+            uint64_t U = __builtin_amdgcn_sicmp(Ej, tcmp, 40 /* slt */) & (dj == 2 ? TESTED_D2 : dj ? TESTED_D : TESTED);   // tested windows below TE + natt
             uint64_t A = 0;
             if (((att_mask >> j) & 1u) && U != 0) {                    // (only when the threshold sits on the distance lattice)
-                const uint64_t below = __builtin_amdgcn_sicmp(Ej, uni(st[ST_TE]), 40 /* slt */);
+                if constexpr (!BIG) tcmp_te = uni(st[ST_TE]);
+                const uint64_t below = __builtin_amdgcn_sicmp(Ej, tcmp_te, 40 /* slt */);
                 A = U & ~below;                                        // TE <= E < TE + natt: at the threshold
                 U &= below;
             }
@@ -1296,15 +1346,20 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
             const int q0 = (b << 6) - nk + 1 - dj;                    // window of lane 0
             if (att) {
                 DevRecord rec;
-                rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8);
+                rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8) | (BIG ? REC_WIDE : 0);
                 const int qa = q_cold() - dj;
                 rec.start = qa; rec.end = qa; rec.minE = E;
                 rec.argf = rec.argl = qa; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
+                if constexpr (BIG) {
+                    const int64_t Ew = (int64_t)bj + (int64_t)E;
+                    rec.minE = rec.exitE = (int32_t)(uint32_t)Ew; rec.minE_hi = rec.exitE_hi = (int32_t)(uint32_t)((uint64_t)Ew >> 32);
+                }
                 emit_global(a, rec);
                 atomicAdd(a.n_att, 1ull);
             }
-            int run_start = uni(st[ST_START]), minE = uni(st[ST_MINE]), argf = uni(st[ST_ARGF]), argl = uni(st[ST_ARGL]),
-                nmin = uni(st[ST_NMIN]);
+            int run_start = uni(st[ST_START]), argf = uni(st[ST_ARGF]), argl = uni(st[ST_ARGL]), nmin = uni(st[ST_NMIN]);
+            hot_t minE;
+            if constexpr (BIG) minE = st_ld64(st, ST_MINE, ST_INRUN); else minE = uni(st[ST_MINE]);
             int cursor = 0;
             while (cursor < 64) {
                 const uint64_t rem = ~(uint64_t)0 << cursor;
@@ -1313,21 +1368,23 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
                     const int end_lane = nz ? __builtin_ctzll(nz) : 64;
                     if (end_lane > cursor) {
                         const bool inseg = lane >= cursor && lane < end_lane;
-                        const int32_t segmin = wave_min_i32(inseg ? E : 0x7FFFFFFF);
-                        const uint64_t eq = __ballot(inseg && E == segmin);
+                        const int32_t segmin0 = wave_min_i32(inseg ? E : 0x7FFFFFFF);
+                        const uint64_t eq = __ballot(inseg && E == segmin0);
+                        const hot_t segmin = bj + (hot_t)segmin0;
                         const int fl = __builtin_ctzll(eq), ll2 = 63 - __builtin_clzll(eq), pc = __builtin_popcountll(eq);
                         if (nmin == 0 || segmin < minE) { minE = segmin; argf = q0 + fl; argl = q0 + ll2; nmin = pc; }
                         else if (segmin == minE) { argl = q0 + ll2; nmin += pc; }
                     }
                     if (end_lane < 64) {
                         const int qe = q0 + end_lane;
-                        const int32_t exitE = __builtin_amdgcn_readlane(E, end_lane);
+                        const hot_t exitE = bj + (hot_t)__builtin_amdgcn_readlane(E, end_lane);
                         if (lane == 0) {
                             DevRecord rec;
-                            rec.tile = tile; rec.kind_kfv = REC_RUN | (kid << 8);
-                            rec.start = run_start; rec.end = qe - 1; rec.minE = minE;
+                            rec.tile = tile; rec.kind_kfv = REC_RUN | (kid << 8) | (BIG ? REC_WIDE : 0);
+                            rec.start = run_start; rec.end = qe - 1; rec.minE = (int32_t)(uint32_t)minE;
                             rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
-                            rec.exitE = exitE; rec.has_exit = qe < n_valid ? 1 : 0;
+                            rec.exitE = (int32_t)(uint32_t)exitE; rec.has_exit = qe < n_valid ? 1 : 0;
+                            if constexpr (BIG) { rec.minE_hi = (int32_t)(uint32_t)((uint64_t)minE >> 32); rec.exitE_hi = (int32_t)(uint32_t)((uint64_t)exitE >> 32); }
                             emit_global(a, rec);
                         }
                         in_run = 0;
@@ -1343,7 +1400,8 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
                 }
             }
             inrun_mask = (inrun_mask & ~(1u << j)) | ((uint32_t)in_run << j);
-            st[ST_START] = run_start; st[ST_MINE] = minE; st[ST_ARGF] = argf; st[ST_ARGL] = argl; st[ST_NMIN] = nmin;
+            st[ST_START] = run_start; st[ST_ARGF] = argf; st[ST_ARGL] = argl; st[ST_NMIN] = nmin;
+            if constexpr (BIG) st_st64(st, ST_MINE, ST_INRUN, minE); else st[ST_MINE] = minE;
         }
     };
 
@@ -1376,10 +1434,11 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
         const int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
         if (((inrun_mask >> j) & 1u) && lane == 0) {
             DevRecord rec;
-            rec.tile = tile; rec.kind_kfv = REC_RUN | (gpp->kfv_id[j] << 8);
+            rec.tile = tile; rec.kind_kfv = REC_RUN | (gpp->kfv_id[j] << 8) | (BIG ? REC_WIDE : 0);
             rec.start = st[ST_START]; rec.end = n_valid - 1; rec.minE = st[ST_MINE];
             rec.argf = st[ST_ARGF]; rec.argl = st[ST_ARGL]; rec.nmin = st[ST_NMIN];
             rec.exitE = 0; rec.has_exit = 0;
+            if constexpr (BIG) { rec.minE_hi = st[ST_INRUN]; rec.exitE_hi = 0; }
             emit_global(a, rec);
         }
     }
@@ -1455,14 +1514,16 @@ bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16)
            n_ref < ((int64_t)1 << 22);
 }
 
-// 16-bit counter form of the same kernel (C16): one KFV, k = 5, 6, windows of 384 ... 2031 k-mers.  KGMA_STREAM8_C16=0 (testing):
-// off -- such windows then take the older 16-bit stream kernel, and their chains the host.
-bool stream8_c16_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16)
+// 16-bit counter form of the same kernel (C16): k = 5, 6, 7, windows of 384 ... 65535 k-mers, and -- need_wide -- shorter windows
+// whose prefix does not fit int32 (large N): the form carries the prefix in 64-bit scalars.  (The host has checked that a step's
+// local prefix fits int32: kgma_set_refs.)  KGMA_STREAM8_C16=0 (testing): off -- windows of up to 2031 k-mers then take the older
+// 16-bit stream kernel, and their chains the host.
+bool stream8_c16_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16, bool need_wide)
 {
     const char *e = getenv("KGMA_STREAM8_C16");
     if (k == 7 && !s16) return false;                                 // (k = 7: 32 KiB of counters per wave, five waves per CU; int16 S rows in global memory)
     return stream8_env_on() && !(e && atoi(e) == 0) && n_kfv >= 1 && n_kfv <= 4 && (n_kfv == 1 || s16) && (k == 5 || k == 6 || k == 7) &&
-           nk > KGMA_STREAM8_MAX_NK && nk <= KGMA_MAX_NK && n_ref < ((int64_t)1 << 22);
+           (nk > KGMA_STREAM8_MAX_NK || need_wide) && nk <= KGMA_MAX_NK_WIDE && n_ref < ((int64_t)1 << 22);
 }
 
 int stream8_variant(int n_kfv) { return n_kfv <= 4 ? (n_kfv < 1 ? 1 : n_kfv) : 8; }   // instantiated NKFV: 1-4 are launched full, 8 takes 5-8 KFVs
@@ -1739,16 +1800,16 @@ void stream8_geometry(int k, bool s16, int nkfv, int nd, int *nw_out, int *block
 }
 
 // ---- chain variants (1-4 KFVs of one window size, k = 5, 6 or 7): streams resident per CU, launch
-bool chain_applies(int k, int nk, int64_t n_ref, bool s16)
+bool chain_applies(int k, int nk, int64_t n_ref, bool s16, bool need_wide)
 {
-    if (nk > KGMA_STREAM8_MAX_NK) return stream8_c16_applies(k, nk, 1, n_ref, s16);  // (the 16-bit counter form: k = 5, 6)
+    if (nk > KGMA_STREAM8_MAX_NK || need_wide) return stream8_c16_applies(k, nk, 1, n_ref, s16, need_wide);  // (the 16-bit counter form)
     return (k == 5 || k == 6 || (k == 7 && s16)) && n_ref < ((int64_t)1 << 22);
 }
 
-int chain_slots_per_cu(int k, bool s16, int nkfv, int nk)
+int chain_slots_per_cu(int k, bool s16, int nkfv, int nk, bool need_wide)
 {
     if (nkfv < 1 || nkfv > 4 || (nkfv > 1 && !s16)) return 0;
-    const bool c16 = nk > KGMA_STREAM8_MAX_NK;
+    const bool c16 = nk > KGMA_STREAM8_MAX_NK || need_wide;
     if (c16 && nkfv != 1) return 0;
     const GeomVal v = stream8_geometry_of(k, s16, nkfv, 0, true, 0, c16);
     return v.nw < 1 ? 0 : v.nw * v.blocks;
@@ -1759,11 +1820,11 @@ hipError_t launch_chain(const ScanArgs &a, const GroupParams &gp, hipStream_t st
     const bool s16 = gp.s_fits_i16 != 0;
     const int nkfv = gp.n_kfv;
     if (nkfv < 1 || nkfv > 4 || (nkfv > 1 && !s16)) return hipErrorInvalidConfiguration;
-    const bool c16 = gp.nk > KGMA_STREAM8_MAX_NK;
+    const bool c16 = gp.nk > KGMA_STREAM8_MAX_NK || gp.need_wide != 0;
     if (c16 && nkfv != 1) return hipErrorInvalidConfiguration;
     const GeomVal v = stream8_geometry_of(gp.k, s16, nkfv, 0, true, 0, c16);
     for (int j = 0; j < nkfv; j++)
-        if (!chain_applies(gp.k, gp.nk, gp.N[j], s16)) return hipErrorInvalidConfiguration;
+        if (!chain_applies(gp.k, gp.nk, gp.N[j], s16, gp.need_wide != 0)) return hipErrorInvalidConfiguration;
     if (v.nw < 1) return hipErrorInvalidConfiguration;
     const int nw = v.nw;
     const size_t lds = stream8_lds(gp.k, s16, nkfv, nw, c16);
@@ -1874,9 +1935,9 @@ static hipError_t launch_stream8(const ScanArgs &a, const GroupParams &gp_in, hi
 }
 
 // streams resident per CU (what the host sizes the streams for); n_ref = largest reference count of the launch's KFVs
-int stream_slots_per_cu(int k, int nk, int nk_min, int n_longer, int n_kfv, int n_sizes, bool s16, int64_t n_ref, bool u8, int n_plus2)
+int stream_slots_per_cu(int k, int nk, int nk_min, int n_longer, int n_kfv, int n_sizes, bool s16, int64_t n_ref, bool u8, int n_plus2, bool need_wide)
 {
-    if (n_sizes == 1 && stream8_c16_applies(k, nk, n_kfv, n_ref, s16)) {
+    if (n_sizes == 1 && stream8_c16_applies(k, nk, n_kfv, n_ref, s16, need_wide)) {
         const GeomVal v = stream8_geometry_of(k, s16, n_kfv, 0, false, 0, true);
         return v.nw < 1 ? 0 : v.nw * v.blocks;
     }
@@ -1899,7 +1960,7 @@ hipError_t launch_stream(const ScanArgs &a, const GroupParams &gp, hipStream_t s
     {
         int64_t nmax = 0;
         for (int j = 0; j < gp.n_kfv; j++) nmax = gp.N[j] > nmax ? gp.N[j] : nmax;
-        if (gp.n_sizes == 1 && stream8_c16_applies(gp.k, gp.nk, gp.n_kfv, nmax, gp.s_fits_i16 != 0)) return launch_stream8(a, gp, st, false, false, true);
+        if (gp.n_sizes == 1 && stream8_c16_applies(gp.k, gp.nk, gp.n_kfv, nmax, gp.s_fits_i16 != 0, gp.need_wide != 0)) return launch_stream8(a, gp, st, false, false, true);
         int n1 = 0, n2 = 0;
         for (int j = 0; j < gp.n_kfv; j++) { n1 += gp.nk_of[j] == gp.nk_min + 1 ? 1 : 0; n2 += gp.nk_of[j] == gp.nk_min + 2 ? 1 : 0; }
         if (stream8_wide_applies(gp.k, gp.nk_min, gp.nk, gp.n_kfv, nmax, gp.s_fits_u8 != 0, gp.s_fits_i16 != 0, n1, n2)) return launch_stream8(a, gp, st, false, true);
