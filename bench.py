@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--plants", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--dump-hits", default="", help="rank 0 writes the last step's hit list here (JSON; tests compare N ranks with one)")
     args = ap.parse_args()
 
     import numpy as np
@@ -271,6 +272,11 @@ def main():
                                          "per SIMD: 0.21-0.24 is what gfx950 issues of 3-operand forms, 0.38-0.41 of 2-operand ones, "
                                          "profiles/r01_valu_issue_rates.txt); the pack kernel is the HBM-bound one"},
         }
+        if args.dump_hits:
+            cols = ("contig", "kfv", "cmi", "lo", "hi", "genome_pos", "D")
+            with open(args.dump_hits, "w") as fh:
+                json.dump({"columns": cols, "hits": [] if hits is None else [[int(h[c]) for c in cols] for h in hits]}, fh)
+        out["per_rank"] = {"rank0_records": [int(rec0), int(rec1)], "rank0_bases": int(my_bases), "world": int(world)}
         if world == 1 and not args.no_secondary:
             # the same step without the chain (exact integers + the local tie resolver), for the record
             for _ in range(2):

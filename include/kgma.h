@@ -151,8 +151,12 @@ typedef struct {
     double chain_device_ms;    /* device time of the chain kernels (hipEvents; part of chain_ms)                      */
     int64_t chain_raw_steps;   /* 64-window steps whose increments the host added one by one (wanted windows, binade
                                   changes); every other step reached the host as part of one integer add per chunk    */
-    double chain_max_drift;    /* largest |chain value - exact distance| / exact distance seen at a stream start (the
-                                  device chain is only used while this stays below 2^-31; the guard bands are 2^-29/30) */
+    double chain_max_drift;    /* largest |chain value - exact distance| seen, relative to the exact distance at the stream
+                                  starts of the device chain (it is only used while this stays below 2^-31 there) and to
+                                  max(exact distance, thr) at the first windows and dip minima of the chained pairs         */
+    int32_t chain_band_log2;   /* the guard band around thr the last kgma_scan ended with: 2^-30 unless the chain's drift
+                                  exceeded half of it and the scan was repeated with a wider one (kgma_scan's drift policy) */
+    int32_t chain_rescans;     /* ... and how often it was repeated (0, 1 or 2)                                              */
 } kgma_stats;
 
 /* Host-side stand-in for `pairalign` + `cigar_to_UnitRange` (src/Alignment.jl:33-52,

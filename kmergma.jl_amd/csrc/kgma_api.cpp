@@ -229,6 +229,11 @@ struct kgma_ctx {
     uint64_t tk_uid = 0, tk_version = 0; int tk_mode = -1, tk_k = 0; int64_t tk_maxws = 0;
     // references
     int k = 0, m = 0;
+    // The guard band around thr is 2^-band_log2 (relative): windows that close count as "at threshold", the chain replay samples
+    // them, and a chain that has drifted more than half of it from the exact distances (2^-(band_log2 + 1) of max(distance, thr))
+    // makes kgma_scan repeat the scan with a band wide enough for the drift it measured.  30 unless KGMA_BAND_LOG2 says otherwise
+    // at kgma_create (tests: a narrow band forces the repeat on small inputs).
+    int band_log2 = 30, band_log2_default = 30;
     std::vector<KfvInfo> kfv;
     int32_t *d_Stab = nullptr;        // m x 4^k, device index order (first base least significant)
     std::map<std::vector<int>, int16_t *> sinter;   // k = 7 stream kernel: interleaved int16 S tables per launch group (device)
@@ -376,7 +381,7 @@ hipError_t sync_spin(hipStream_t st)
 //   T_hi = floor(thr * 2kN^2 * (1 + 2^-30))   T <= D <= T_hi  <=>  "at threshold" (flagged)
 // For thresholds away from the distance lattice the band is empty (T_hi = T - 1) and T is exactly
 // ceil(thr * 2kN^2).
-void threshold_band(double thr, int k, int64_t N, int64_t *T_lo, int64_t *T_hi)
+void threshold_band(double thr, int k, int64_t N, int64_t *T_lo, int64_t *T_hi, int band_log2 = 30)
 {
     *T_lo = 0; *T_hi = -1;
     if (!(thr > 0.0)) return;
@@ -387,7 +392,7 @@ void threshold_band(double thr, int k, int64_t N, int64_t *T_lo, int64_t *T_hi)
     e -= 53;
     const __int128 scale = (__int128)2 * k * N * N;
     const __int128 prod = (__int128)mant * scale;
-    const __int128 lo = prod - (prod >> 30), hi = prod + (prod >> 30);
+    const __int128 lo = prod - (prod >> band_log2), hi = prod + (prod >> band_log2);
     auto clamp = [](__int128 v) { return v > (__int128)INT64_MAX ? INT64_MAX : (int64_t)v; };
     if (e >= 0) {
         if (e > 60) { *T_lo = INT64_MAX; return; }
@@ -546,6 +551,10 @@ int kgma_create(int device_ordinal, kgma_ctx **out)
     kgma_ctx *ctx = new (std::nothrow) kgma_ctx();
     if (!ctx) return KGMA_E_NOMEM;
     ctx->device = device_ordinal;
+    if (const char *e = getenv("KGMA_BAND_LOG2")) {                   // tests: a narrower (or wider) threshold guard band
+        const int b = atoi(e);
+        if (b >= 10 && b <= 50) ctx->band_log2 = ctx->band_log2_default = b;
+    }
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0) ctx->n_cus = cus;
@@ -829,7 +838,7 @@ int kgma_set_thresholds(kgma_ctx *ctx, const double *thr)
     if (ctx->m == 0) return fail(ctx, KGMA_E_STATE, "kgma_set_refs has not been called");
     for (int j = 0; j < ctx->m; j++) {
         ctx->kfv[j].thr = thr[j];
-        threshold_band(thr[j], ctx->k, ctx->kfv[j].N, &ctx->kfv[j].T, &ctx->kfv[j].T_hi);
+        threshold_band(thr[j], ctx->k, ctx->kfv[j].N, &ctx->kfv[j].T, &ctx->kfv[j].T_hi, ctx->band_log2);
     }
     return KGMA_OK;
 }
@@ -893,7 +902,7 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
             f.S.clear(); f.Smax = INT64_MAX; f.sumS2 = 0;
             f.fits32 = false; f.big_ok = false; f.ref_form = -1;
             f.thr = thr[j];
-            threshold_band(thr[j], k, f.N, &f.T, &f.T_hi);
+            threshold_band(thr[j], k, f.N, &f.T, &f.T_hi, ctx->band_log2);
             continue;
         }
         f.N = N;
@@ -925,7 +934,7 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
             f.ref_form = mul ? 0 : (div ? 1 : -1);
         }
         f.thr = thr[j];
-        threshold_band(thr[j], k, N, &f.T, &f.T_hi);
+        threshold_band(thr[j], k, N, &f.T, &f.T_hi, ctx->band_log2);
     }
     // upload the plane-index permuted tables
     std::vector<int32_t> tab((size_t)m * (size_t)NB, 0);
@@ -1469,7 +1478,7 @@ namespace {
 // Two integer distances D of KFV `f` that rounding noise may order either way.  S/N KFVs: exact arithmetic, only equal values tie.
 // Float64 KFVs (f.fp): the device's values and the reference's running value each carry a relative error far below 2^-31, so
 // values within 2^-30 of each other are treated as tied (flagged; the chain replay decides them).
-inline int64_t tie_tol(const KfvInfo &f, int64_t D) { return f.fp ? (int64_t)((double)(D < 0 ? -D : D) * 9.313225746154785e-10) + 2 : 0; }
+inline int64_t tie_tol(const KfvInfo &f, int64_t D) { return f.fp ? (int64_t)((double)(D < 0 ? -D : D) * 9.313225746154785e-10 /* 2^-30 */) + 2 : 0; }
 inline bool near_tie(const KfvInfo &f, int64_t a, int64_t b)
 {
     const int64_t d = a > b ? a - b : b - a;
@@ -1618,6 +1627,55 @@ int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
 }
 
 }  // namespace
+
+// stream8_kernel at k = 7 gathers its S values from global memory, one row of `nv` int16 slots per k-mer for all KFVs of the
+// launch -- COMPACTED (kgma_device.h, ScanArgs::Sinter / Sbits): [per 32 k-mers {bitmap of the rows with a non-zero entry, 1 + number
+// of such rows before them}][row 0 = zeros][the non-zero rows in k-mer order].  Built once per launch group, kept by the context.
+static int sinter_tables(kgma_ctx *ctx, const std::vector<int> &kfvs, int nv, const int16_t **rows, const uint32_t **bits)
+{
+    const int k = ctx->k;
+    const int64_t NBk = (int64_t)1 << (2 * k), n_words = NBk / 32;
+    const bool compact = nv >= 8;                                            // (the kernel variants of 5-8 KFVs; narrower rows stay dense)
+    std::vector<int> key = kfvs;
+    key.push_back(-nv);
+    auto it = ctx->sinter.find(key);
+    if (it == ctx->sinter.end()) {
+        std::vector<int16_t> dense((size_t)NBk * (size_t)nv, 0);
+        for (size_t u = 0; u < kfvs.size(); u++)
+            for (int64_t v = 0; v < NBk; v++)
+                dense[(size_t)device_index_of((uint32_t)v, k) * (size_t)nv + u] = (int16_t)ctx->kfv[(size_t)kfvs[u]].S[(size_t)v];
+        std::vector<uint32_t> bw((size_t)n_words * 2, 0u);
+        std::vector<int16_t> packed((size_t)nv, 0);                          // row 0: all zero
+        uint32_t n_rows = 1;
+        if (!compact) packed = dense;                                        // (dense: the rows as they are, indexed by k-mer)
+        for (int64_t w = 0; compact && w < n_words; w++) {
+            uint32_t m = 0;
+            bw[(size_t)w * 2 + 1] = n_rows;
+            for (int b = 0; b < 32; b++) {
+                const int16_t *row = &dense[(size_t)(w * 32 + b) * (size_t)nv];
+                bool nz = false;
+                for (int u = 0; u < nv; u++) nz = nz || row[u] != 0;
+                if (!nz) continue;
+                m |= 1u << b;
+                packed.insert(packed.end(), row, row + nv);
+                n_rows++;
+            }
+            bw[(size_t)w * 2] = m;
+        }
+        const size_t bits_bytes = bw.size() * 4, rows_bytes = packed.size() * 2;
+        uint8_t *d = nullptr;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d), bits_bytes + rows_bytes + 64));
+        if (hipMemcpy(d, bw.data(), bits_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d + bits_bytes, packed.data(), rows_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d);
+            return fail(ctx, KGMA_E_HIP, "cannot upload the interleaved S tables");
+        }
+        it = ctx->sinter.emplace(key, reinterpret_cast<int16_t *>(d)).first;
+    }
+    *bits = compact ? reinterpret_cast<const uint32_t *>(it->second) : nullptr;
+    *rows = it->second + (size_t)n_words * 4;                                // (n_words x 8 bytes of bitmap entries in front)
+    return KGMA_OK;
+}
 
 extern "C" {
 
@@ -2013,7 +2071,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
                 gg.k = k; gg.nk = gp.nk; gg.N = (int32_t)f.N; gg.kfv_id = j + 1; gg.fp = f.fp ? 1 : 0;
                 gg.n_slots = (int32_t)((int64_t)std::max(1, ctx->n_cus - ctx->reserved_cus) * stream_nw);
                 gg.T = f.T; gg.T_hi = f.T_hi; gg.sumS2 = f.sumS2;
-                gg.thr_lo = f.thr * (1.0 - 9.313225746154785e-10); gg.thr_hi = f.thr * (1.0 + 9.313225746154785e-10);   // 2^-30
+                gg.thr_lo = f.thr * (1.0 - std::ldexp(1.0, -ctx->band_log2)); gg.thr_hi = f.thr * (1.0 + std::ldexp(1.0, -ctx->band_log2));
                 gg.sumR2 = f.sumR2; gg.SF = 1.0 / (double)k; gg.inv_scale = gp.inv_scale[0];
                 gg.tie_rel = 9.313225746154785e-10;
                 gg.S = ctx->d_Stab + (size_t)j * (size_t)NBk;
@@ -2035,24 +2093,10 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             a.Stab = (use_stream && !group_s8(gr)) ? ctx->d_StabC : ctx->d_Stab;
             a.Sinter = nullptr;
             if (use_stream && group_s8(gr) && k >= 7) {
-                // the launch's S tables interleaved per k-mer, int16, in the interleaved-code index order; built once per group
                 const int nv0 = stream8_variant((int)gr.kfvs.size());
                 const int nv = nv0 == 3 ? 4 : nv0;                     // row width in int16 slots (the kernel variant's)
-                std::vector<int> key = gr.kfvs;
-                key.push_back(-nv);
-                auto it = ctx->sinter.find(key);
-                if (it == ctx->sinter.end()) {
-                    const int64_t NBk = (int64_t)1 << (2 * k);
-                    std::vector<int16_t> tab((size_t)NBk * (size_t)nv, 0);
-                    for (size_t u = 0; u < gr.kfvs.size(); u++)
-                        for (int64_t v = 0; v < NBk; v++)
-                            tab[(size_t)device_index_of((uint32_t)v, k) * (size_t)nv + u] = (int16_t)ctx->kfv[(size_t)gr.kfvs[u]].S[(size_t)v];
-                    int16_t *d = nullptr;
-                    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d), tab.size() * sizeof(int16_t)));
-                    HIP_TRY(ctx, hipMemcpy(d, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice));
-                    it = ctx->sinter.emplace(key, d).first;
-                }
-                a.Sinter = it->second;
+                rc = sinter_tables(ctx, gr.kfvs, nv, &a.Sinter, &a.Sbits);
+                if (rc) return rc;
             }
             if (use_stream && stream8_state_words(k, (int)gr.kfvs.size()) > 0) {
                 rc = dev_reserve(ctx, ctx->d_wstate, ctx->wstate_cap, n_tiles * stream8_state_words(k, (int)gr.kfvs.size()));
@@ -2674,7 +2718,6 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
                                  ChainDevInfo &info, bool export_only, int pin_sel, std::function<int()> *deferred)
 {
     const int k = ctx->k;
-    const int64_t NB = (int64_t)1 << (2 * k);
     const double ts0 = now_ms();
     // ---- launch groups: the KFVs of one window size share the count table of a pass, so up to `maxg` of them that are
     //      wanted on this batch CAN go into one launch (slots; a record's streams carry the mask of the slots it is flagged
@@ -2909,22 +2952,10 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
             a.n_tiles = (int32_t)(L.t1 - L.t0);
             a.Stab = ctx->d_Stab;
             if (k >= 7) {
-                // k = 7: the kernel gathers S from global memory, one row of int16 slots per k-mer (the scan's interleaved layout)
+                // k = 7: the kernel gathers S from global memory, one row of int16 slots per k-mer (the scan's compacted layout)
                 const int nv = nslots == 3 ? 4 : nslots;               // row width in int16 slots (the kernel variant's)
-                std::vector<int> key = L.kfvs;
-                key.push_back(-nv);
-                auto it = ctx->sinter.find(key);
-                if (it == ctx->sinter.end()) {
-                    std::vector<int16_t> tab((size_t)NB * (size_t)nv, 0);
-                    for (int u = 0; u < nslots; u++)
-                        for (int64_t v = 0; v < NB; v++)
-                            tab[(size_t)device_index_of((uint32_t)v, k) * (size_t)nv + (size_t)u] = (int16_t)ctx->kfv[(size_t)L.kfvs[(size_t)u]].S[(size_t)v];
-                    int16_t *d = nullptr;
-                    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d), tab.size() * sizeof(int16_t)));
-                    HIP_TRY(ctx, hipMemcpy(d, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice));
-                    it = ctx->sinter.emplace(key, d).first;
-                }
-                a.Sinter = it->second;
+                rc = sinter_tables(ctx, L.kfvs, nv, &a.Sinter, &a.Sbits);
+                if (rc) return rc;
             }
             if (stream8_state_words(k, nslots) > 0) {
                 rc = dev_reserve(ctx, ctx->d_wstate, ctx->wstate_cap, (int64_t)(L.t1 - L.t0) * stream8_state_words(k, nslots));
@@ -2943,6 +2974,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
             a.chain.chunk_stride = L.n_chunks;
             a.chain.SF = 1.0 / (double)k;                           // src/API.jl:86,204
             a.chain.guard = 1.862645149230957e-09;                  // 2^-29
+            a.chain.guard_abs = 9.313225746154785e-10;              // 2^-30 of the stream's first distance
             a.chain.status = ctx->d_cctl + 1;
             HIP_TRY(ctx, launch_chain(a, gp, ctx->stream));
         }
@@ -3095,7 +3127,10 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
 // stale running minimum" (GenomeMiner.jl:93-103), which is only known once the hit state machine runs.
 // Every other pair has no exact tie anywhere, so exact arithmetic and the chain decide alike.
 // ------------------------------------------------------------------------------------------
-static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff)
+// (*drift_out, when given: instead of failing on a chain that has drifted beyond the guard band's half width, the largest drift seen
+//  is returned there with status CHAIN_DRIFT_RETRY, and kgma_scan repeats the scan with a band that covers it)
+constexpr int CHAIN_DRIFT_RETRY = -77;
+static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, double *drift_out = nullptr)
 {
     const double t0 = now_ms();
     const int k = ctx->k, m = ctx->m;
@@ -3343,6 +3378,7 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64
     if (getenv("KGMA_CHAIN_DEBUG")) fprintf(stderr, "chain replay: residues copied in %.1f ms, chains %.1f ms, %d threads\n", copy_ms, jobs_ms, n_threads);
     // ---- rebuild the dips of the chain pairs from the chain values ---------------------------
     struct DipX { kgma_dip d; int64_t argl, aux; double fmin, fexit; };
+    double worst_drift = 0;                                            // beyond the limit, over all pairs
     std::vector<DipX> all;
     all.reserve(ctx->dips.size() + 16);
     {
@@ -3371,18 +3407,28 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64
                 }
                 return nullptr;
             };
+            // What the band has to cover is the value's ABSOLUTE error where the distance is near thr: the error is measured
+            // against max(exact distance, thr) -- at a dip's minimum the distance can be tiny (near-identical reference
+            // sequences: D_min of a few units) and an error inherited from windows of ordinary distances says nothing about
+            // the threshold there.  (The device chain's binade decisions have their own guard: kgma_device.h, ChainArgs.)
+            const double limit = std::ldexp(1.0, -(ctx->band_log2 + 1));
+            double pair_drift = 0;
             auto drifted = [&](int64_t w, int64_t D) {
                 const double *v = value_at(w);
-                if (!v || D <= 0) return false;
-                const double exact = (double)D / scale, dr = std::fabs(*v - exact) / exact;
-                ctx->stats.chain_max_drift = std::max(ctx->stats.chain_max_drift, dr);
-                return dr > 4.656612873077393e-10;                      // 2^-31
+                if (!v || D < 0) return;
+                const double exact = (double)D / scale, dr = std::fabs(*v - exact) / std::max(exact, f.thr > 0 ? f.thr : exact);
+                if (!(dr >= 0)) return;
+                pair_drift = std::max(pair_drift, dr);
             };
-            bool bad = drifted(1, ctx->firstD[(size_t)p.j * (size_t)nc + (size_t)p.c]);
-            for (size_t u = p.d0; u < p.d1 && !bad; u++) bad = drifted(ctx->dips[u].argmin, ctx->dips[u].D_min);
-            if (bad)
-                return fail(ctx, KGMA_E_STATE, "chain replay: the running Float64 value of record %d KFV %d has drifted more than 2^-31 from the exact distance; "
-                            "the threshold guard band (2^-30) no longer covers it", p.c, p.j + 1);
+            drifted(1, ctx->firstD[(size_t)p.j * (size_t)nc + (size_t)p.c]);
+            for (size_t u = p.d0; u < p.d1; u++) drifted(ctx->dips[u].argmin, ctx->dips[u].D_min);
+            ctx->stats.chain_max_drift = std::max(ctx->stats.chain_max_drift, pair_drift);
+            if (pair_drift > limit) {
+                if (!drift_out)
+                    return fail(ctx, KGMA_E_STATE, "chain replay: the running Float64 value of record %d KFV %d has drifted %.3g (relative to max(distance, thr)) from the "
+                                "exact distance; the threshold guard band (2^-%d) no longer covers it", p.c, p.j + 1, pair_drift, ctx->band_log2);
+                worst_drift = std::max(worst_drift, pair_drift);
+            }
         }
         bool in_run = false;
         DipX cur{};
@@ -3424,6 +3470,7 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64
             close_run(0, 0.0);                                         // still open at the record end: dropped by the state machine
         }
     }
+    if (worst_drift > 0) { *drift_out = worst_drift; return CHAIN_DRIFT_RETRY; }
     std::stable_sort(all.begin(), all.end(), [](const DipX &a, const DipX &b) {
         if (a.d.contig != b.d.contig) return a.d.contig < b.d.contig;
         if (a.d.kfv != b.d.kfv) return a.d.kfv < b.d.kfv;
@@ -3446,14 +3493,44 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64
 int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, int64_t genome_pos0,
               uint32_t flags, kgma_align_fn align, void *align_user)
 {
-    int rc = kgma_scan_device(ctx, g, mode, flags);
-    if (rc) return rc;
-    reset_chain_stats(ctx);
-    if ((flags & KGMA_F_CHAIN_REPLAY) && !(flags & KGMA_F_NO_TIE_RESOLVE)) {
-        rc = chain_decide(ctx, g, mode, buff);
-        if (rc) return rc;
+    // Drift policy of the chain replay: the scan samples the reference's running value at the windows whose exact distance is
+    // below or within 2^-band_log2 of thr.  If the replayed value turns out further than half of that from the exact distances
+    // (long records, values accumulated at large distances), the band no longer provably holds every window the reference may
+    // see below thr: the scan is repeated with a band that covers four times the drift measured (more windows sampled, more raw
+    // steps in the chain kernel), up to twice; only a drift beyond 2^-10 fails (KGMA_E_STATE).
+    if (!ctx) return KGMA_E_ARG;
+    auto set_band = [&](int b) {
+        ctx->band_log2 = b;
+        for (int j = 0; j < ctx->m; j++) threshold_band(ctx->kfv[(size_t)j].thr, ctx->k, ctx->kfv[(size_t)j].N, &ctx->kfv[(size_t)j].T, &ctx->kfv[(size_t)j].T_hi, b);
+    };
+    int rc = KGMA_OK, rescans = 0;
+    for (;;) {
+        rc = kgma_scan_device(ctx, g, mode, flags);
+        if (rc) break;
+        reset_chain_stats(ctx);
+        if ((flags & KGMA_F_CHAIN_REPLAY) && !(flags & KGMA_F_NO_TIE_RESOLVE)) {
+            double drift = 0;
+            rc = chain_decide(ctx, g, mode, buff, &drift);
+            if (rc == CHAIN_DRIFT_RETRY) {
+                const int b = (int)std::floor(-std::log2(drift)) - 2;        // 2^-(b + 1) >= 2 x the drift
+                if (rescans >= 2 || b < 10 || b >= ctx->band_log2) {
+                    rc = fail(ctx, KGMA_E_STATE, "chain replay: the running Float64 value has drifted %.3g (relative to max(distance, thr)) from the exact "
+                              "distances; a guard band of 2^-%d does not cover it%s", drift, ctx->band_log2, rescans >= 2 ? " (after two repeated scans)" : "");
+                    break;
+                }
+                set_band(b);
+                rescans++;
+                continue;
+            }
+            if (rc) break;
+        }
+        rc = replay_hits(ctx, g, mode, buff, genome_pos0, flags, align, align_user);
+        break;
     }
-    return replay_hits(ctx, g, mode, buff, genome_pos0, flags, align, align_user);
+    ctx->stats.chain_band_log2 = ctx->band_log2;
+    ctx->stats.chain_rescans = rescans;
+    if (ctx->band_log2 != ctx->band_log2_default) set_band(ctx->band_log2_default);
+    return rc;
 }
 
 int kgma_chain_values(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int32_t kfv, const int64_t *win_lo, const int64_t *win_hi,
@@ -3487,6 +3564,19 @@ int kgma_chain_values(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int32
     }
     p.last = prev;
     p.val.assign((size_t)total, 0.0);
+    if (prev == 1) {
+        // only window 1 is wanted: its value is the first window's kmer_count! + sqeuclidean (GenomeMiner.jl:42-47), formed on the
+        // host from the window's 2-bit codes like the first value of every device chain
+        const size_t dw = (size_t)((f.W + 15) / 16) + 2;
+        std::vector<uint32_t> codes(dw, 0u);
+        HIP_TRY(ctx, hipMemcpy(codes.data(), g->d_inter + 2 * g->cd[(size_t)contig].word_off, dw * 4, hipMemcpyDeviceToHost));
+        static const ChainInterval one{1, 1};
+        ChainJob J;
+        J.seq = nullptr; J.packed = codes.data(); J.n_res = f.W; J.ref = f.ref.data(); J.k = ctx->k; J.W = f.W; J.last_window = 1;
+        J.iv = &one; J.n_iv = 1; J.out = out; J.n_out = 0; J.ok = false;
+        run_chain_jobs(&J, 1, 1);
+        return J.ok && J.n_out == 1 ? KGMA_OK : fail(ctx, KGMA_E_HIP, "internal: first window of record %lld", (long long)contig);
+    }
     std::vector<char> done(1, 0);
     ChainDevInfo info;
     const int rc = chain_on_device(ctx, g, pairs, done, info);

@@ -194,15 +194,24 @@ void chain_walk_one(ChainWalkJob &J)
     const ChainInterval *iv = J.iv;
     size_t ii = 0;
     double *o = J.out;
-    int64_t cur_lo = iv[0].lo, cur_hi = iv[0].hi;
+    // `out` holds one value per wanted window (the callers size it so).  The wanted windows must arrive in order, each exactly
+    // once: a window that is skipped (its step was not raw: chunk records that do not belong to these intervals -- caller-supplied
+    // ones, or a remote rank's hot list that disagrees with this one) would leave the cursor behind and every later raw step
+    // writing past the buffer, so it ends the walk instead.
+    int64_t total = 0;
+    for (size_t i = 0; i < J.n_iv; i++) total += iv[i].hi - iv[i].lo + 1;
+    const double *const o_end = J.out + total;
+    bool lost = false;
+    int64_t cur_lo = iv[0].lo, cur_hi = iv[0].hi;                       // cur_lo: the next wanted window
     auto sample = [&](int64_t w, double x) {
-        if (w < cur_lo) return;
+        if (w < cur_lo || lost) return;
+        if (w > cur_lo || o == o_end) { lost = true; return; }
         *o++ = x;
         if (w == cur_hi) {
             ii++;
             if (ii < J.n_iv) { cur_lo = iv[ii].lo; cur_hi = iv[ii].hi; }
             else { cur_lo = INT64_MAX; cur_hi = INT64_MAX; }
-        }
+        } else cur_lo = w + 1;
     };
     sample(1, v);
     const int nk = J.nk;
@@ -289,6 +298,7 @@ void chain_walk_one(ChainWalkJob &J)
                         const int64_t q = p - nk + 1;
                         if (q >= 1 && q < S.n_valid) sample(S.win0 + q, v);
                     }
+                    if (lost) return;                                    // (status stays CHAIN_WALK_INTERNAL)
                 }
                 covered += 1;
             }

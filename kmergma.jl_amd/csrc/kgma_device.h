@@ -126,6 +126,10 @@ struct ChainArgs {
     int64_t chunk_stride;         // chunk records of KFV slot j of the launch: chunks[first chunk + j * chunk_stride] (hot bits alike)
     double SF;                    // ScaleFactor = 1 / k (src/API.jl:86,204)
     double guard;                 // relative guard band around the powers of two (2^-29)
+    double guard_abs;             // ... and an absolute one, as a fraction of the STREAM's first-window distance (2^-30): the host
+                                  // checks the running value against the exact one at every stream start, relative to that
+                                  // distance -- so that is what bounds the value's ABSOLUTE error inside the stream, also at
+                                  // windows whose own distance is tiny (a perfect match inside a record of ordinary distances)
     unsigned int *status;         // bit 0: the pool ran out
 };
 
@@ -135,7 +139,10 @@ struct ScanArgs {
     const uint32_t *inter;      // the same genome as 2-bit codes, 16 bases per dword (first base = bits 0-1): two dwords per plane word
     const TileDesc *tiles;
     const int32_t *Stab;        // all KFVs' tables, 4^k int32 each, in the launching kernel's index order
-    const int16_t *Sinter;      // stream8_kernel at k = 7: the launch's S tables interleaved per k-mer ([k-mer][NKFV] int16), in global memory
+    const int16_t *Sinter;      // stream8_kernel at k = 7: the launch's S tables interleaved per k-mer (rows of NV int16 slots), in global
+                                // memory, COMPACTED: only the rows with a non-zero entry, behind row 0 which is all zero
+    const uint32_t *Sbits;      // ... and, per 32 k-mers, {bitmap of the non-zero rows, 1 + number of non-zero rows before them}: the row
+                                // of k-mer x is Sbits[2 (x / 32) + 1] + popcount(bits below x) if bit x % 32 is set, else 0
     int64_t *D0out;             // [KFV id - 1][n_tiles]
     DevRecord *recs;
     unsigned int *rec_count;

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdlib>
+#include <algorithm>
 #include <type_traits>
 
 #include "kgma_device.h"
@@ -390,7 +391,9 @@ int generic_slots_per_cu(int k, bool fp)
         (void)hipGetLastError();
         blocks = 1;
     }
-    if (cg) blocks = 1;                                               // (global count tables: 2 * 4^k bytes per slot)
+    // (global count tables: 2 * 4^k bytes per slot; a step is two dependent round trips to L2, so the walk is latency-bound and
+    //  wants waves: 16 per CU at k = 8, 9 (128 / 512 KiB per slot), 8 at k = 10 (2 MiB per slot: 4 GiB of tables))
+    if (cg) blocks = std::min(blocks, k >= 10 ? 2 : 4);
     if (blocks * nw > 32) blocks = 32 / nw;
     return nw * (blocks < 1 ? 1 : blocks);
 }

@@ -740,11 +740,14 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
         const double scale = gpp->inv_scale[j];                       // 2kN^2 (an integer)
         const double Dd = (double)D;
         const int e = ilogb(Dd / scale);
-        const double g = a.chain.guard;
-        const double lo = ldexp(scale, e) * (1.0 + g), hi = ldexp(scale, e + 1) * (1.0 - g);
-        if (!(Dd > lo && Dd < hi) || e < -900 || e > 900) return;
         const int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
         const int64_t D0 = (int64_t)(((uint64_t)(uint32_t)uni(st[ST_D0HI]) << 32) | (uint32_t)uni(st[ST_D0LO]));
+        // guard bands around the binade's ends: relative to the end, and absolute -- a fraction of the stream's first distance,
+        // which is what the host's drift check at the stream start bounds the value's absolute error with
+        const double g = a.chain.guard, gabs = a.chain.guard_abs * (double)D0;
+        const double blo = ldexp(scale, e), bhi = ldexp(scale, e + 1);
+        const double lo = blo + fmax(blo * g, gabs), hi = bhi - fmax(bhi * g, gabs);
+        if (!(Dd > lo && Dd < hi) || e < -900 || e > 900) return;
         const double twoN = 2.0 * (double)gpp->N[j];
         double el = ceil((lo - (double)D0) / twoN), eh = floor((hi - (double)D0) / twoN);
         constexpr double ELIM = BIG ? 2305843009213693952.0 /* 2^61 */ : 1073741824.0;
@@ -917,14 +920,34 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
             // latency of the step; k <= 6: a row of the LDS table)
             constexpr int NW = NKFV >= 2 ? (SBYTE ? NV / 4 : NV / 2) : 1;   // dwords per table row (NKFV = 3: a 4-slot row)
             uint32_t vr[NW], vl[NW];
+            // k = 7: a KFV of N sequences of ~300 residues has a few hundred distinct 7-mers of the 16384 -- most rows of the
+            // interleaved table are all zero (BASELINE configs[4]: 88 % of them for its eight KFVs).  So the table is kept
+            // COMPACTED (kgma_device.h, ScanArgs::Sbits): a lane first reads its k-mer's {32-bit word of the non-zero bitmap, number
+            // of non-zero rows before the word, plus one} from a 4 KiB table that stays in the vector L1, and then the row
+            // rank + popcount(bits below) -- or row 0, which is all zero, when its bit is clear: those lanes all read one address.
+            // What goes to L2 is the few rows that exist instead of 128 scattered 16-byte rows per step.
+            // (Measured: BASELINE configs[4] 0.723 -> 0.699 s with the eight-KFV launch -- the step is bound by the latency of its
+            //  dependent chain at ten waves per CU, not by L2 traffic, and the bitmap read is one more link in it.  Rows of one to four
+            //  KFVs (2-8 bytes: tables of 32-128 KiB) stay dense: the one-KFV chain kernel lost 19 % to the extra link.)
+            constexpr bool SCOMPACT = SGLOBAL && NKFV >= 5;
+            [[maybe_unused]] uint32_t rp = kp, rs = ks;                // row index of the entering / leaving k-mer
+            if constexpr (SCOMPACT) {
+                const u32x2_t *bits = reinterpret_cast<const u32x2_t *>(a.Sbits);
+                const u32x2_t bp = bits[kp >> 5], bs = bits[ks >> 5];
+                const uint32_t ip = (uint32_t)__builtin_popcount(bp.x & ((1u << (kp & 31u)) - 1u)) + bp.y;
+                const uint32_t is = (uint32_t)__builtin_popcount(bs.x & ((1u << (ks & 31u)) - 1u)) + bs.y;
+                rp = ((bp.x >> (kp & 31u)) & 1u) ? ip : 0u;
+                rs = ((bs.x >> (ks & 31u)) & 1u) ? is : 0u;
+            }
             if constexpr (NKFV == 1) {
-                vr[0] = (uint32_t)(uint16_t)a.Sinter[kp]; vl[0] = (uint32_t)(uint16_t)a.Sinter[ks];
+                vr[0] = (uint32_t)(uint16_t)a.Sinter[rp]; vl[0] = (uint32_t)(uint16_t)a.Sinter[rs];
             } else {
                 typedef uint32_t rowv __attribute__((ext_vector_type(NW)));
                 auto rows_of = [&](auto base) {
-                    if constexpr (NW == 1) { vr[0] = base[kp]; vl[0] = base[ks]; }
+                    const uint32_t xp = SGLOBAL ? rp : kp, xs = SGLOBAL ? rs : ks;
+                    if constexpr (NW == 1) { vr[0] = base[xp]; vl[0] = base[xs]; }
                     else {
-                        const auto r = base[kp], l = base[ks];
+                        const auto r = base[xp], l = base[xs];
 #pragma unroll
                         for (int w = 0; w < NW; w++) { vr[w] = r[w]; vl[w] = l[w]; }
                     }
@@ -1752,13 +1775,24 @@ static GeomVal stream8_geometry_of(int k, bool s16, int nkfv, int nd, bool chain
     }
     int best_nw = 0, best_blocks = 0;
     int regs = 0;
+    size_t dev_lds = (size_t)160 << 10;
+    int dev_regs_per_simd_lane = 512;
     {
+        // (a small private segment does not change the estimate below -- the one-KFV kernels have 12 bytes of it, and they are the
+        //  case the estimate exists for: the runtime was seen to halve their residency when another HIP user shares the process;
+        //  kernels with a real scratch frame keep the runtime's answer)
         hipFuncAttributes fa0;
-        if (hipFuncGetAttributes(&fa0, fn) == hipSuccess) regs = fa0.numRegs;
+        if (hipFuncGetAttributes(&fa0, fn) == hipSuccess && fa0.localSizeBytes <= 64) regs = fa0.numRegs;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            if (prop.sharedMemPerMultiprocessor > 0) dev_lds = (size_t)prop.sharedMemPerMultiprocessor;
+            // regsPerMultiprocessor: 32-bit registers per CU = 4 SIMDs x 64 lanes x registers per lane
+            if (prop.regsPerMultiprocessor >= 4 * 64 * 128) dev_regs_per_simd_lane = prop.regsPerMultiprocessor / (4 * 64);
+        }
     }
     for (int nw = 16; nw >= 4; nw--) {
         const size_t lds = stream8_lds(k, s16, nkfv, nw, c16);
-        if (lds > ((size_t)160 << 10)) continue;
+        if (lds > dev_lds) continue;
         int blocks = 0;
         const hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const hipError_t e2 = e1 == hipSuccess ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64 * nw, lds) : e1;
@@ -1771,10 +1805,13 @@ static GeomVal stream8_geometry_of(int k, bool s16, int nkfv, int nd, bool chain
         // does follows from the kernel's registers and LDS: 512 vector registers per lane and SIMD in granules of 8, at most
         // 8 waves per SIMD, 160 KiB of LDS per CU in granules of 1280 bytes.
         if (regs > 0) {
-            const int per_simd = std::min(8, 512 / (((regs + 7) / 8) * 8));
+            const int per_simd = std::min(8, dev_regs_per_simd_lane / (((regs + 7) / 8) * 8));
             const int by_regs = (4 * per_simd) / nw;
-            const int by_lds = (int)(((size_t)160 << 10) / (((lds + 1279) / 1280) * 1280));
-            blocks = std::max(blocks, std::min(by_regs, by_lds));
+            const int by_lds = (int)(dev_lds / (((lds + 1279) / 1280) * 1280));
+            const int est = std::min(by_regs, by_lds);
+            if (est > blocks && getenv("KGMA_GEOM_DEBUG"))
+                fprintf(stderr, "  geometry: the runtime reports %d workgroups per CU, registers (%d) and LDS (%zu B) allow %d: using %d\n", blocks, regs, lds, est, est);
+            blocks = std::max(blocks, est);
         }
         if (blocks * nw > 32) blocks = 32 / nw;
         if (blocks * nw > best_blocks * best_nw) { best_blocks = blocks; best_nw = nw; }

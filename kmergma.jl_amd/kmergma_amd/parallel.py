@@ -502,8 +502,9 @@ def serve_chain_request(ctx, genome, my_slices, nwin_of, pairs) -> np.ndarray:
                 head[4:8] = [ex["win0"].size, ex["chunks"].size, ex["pool"].size, int(np.float64(ex["first"]).view(np.int64))]
                 body = [ex["win0"].astype(np.int64), ex["n_valid"].astype(np.int64), ex["chunk_base"].astype(np.int64), ex["D0"].astype(np.int64),
                         np.ascontiguousarray(ex["chunks"]).view(np.int64).reshape(-1), np.ascontiguousarray(ex["pool"]).view(np.int64).reshape(-1)]
-            except _lib.KgmaError as e:
-                head[8] = int(e.status) or 1
+            except Exception as e:                                  # (any failure travels as the piece's status: the gather must complete on every rank)
+                head[4:8] = [0, 0, 0, 0]
+                head[8] = int(getattr(e, "status", 0)) or 1
                 body = []
             pieces.append(np.concatenate([np.asarray(head, dtype=np.int64)] + body))
     return np.concatenate([np.asarray([len(pieces)], dtype=np.int64)] + pieces) if pieces else np.asarray([0], dtype=np.int64)
@@ -673,19 +674,23 @@ def scan_sharded(ctx, records, mode: int, buff: int = 50, genome_pos: int = 0, f
                     break
                 _gather_int64(serve_chain_request(ctx, genome, plan[rank], nwin_of, decode_chain_request(req)), device=device, group=group)
             return []
-        dips, last_min, first_D = merge_payloads(gathered, len(lengths), m)
-        ctx.set_residue_source(lambda c, pos, n: src.fetch(c, pos - 1, pos - 1 + n))
-        if chain:
-            att = np.concatenate([p["att"] for p in gathered]) if gathered else np.zeros((0, 3), dtype=np.int64)
-            ctx.set_att(np.unique(att, axis=0) if att.shape[0] else att)     # (a window shared by two slices is reported by both)
-
-            def source(pairs):
-                _bcast_int64(encode_chain_request(pairs), 0, device=device, group=group)
-                blocks = _gather_int64(serve_chain_request(ctx, genome, plan[0], nwin_of, pairs), device=device, group=group)
-                pieces = [d for b in blocks for d in decode_chain_pieces(b)]
-                return walk_chain_pieces(ctx, pairs, pieces, ws if not mode_single else [ctx.ws[0]])
-            ctx.set_chain_source(source)
+        # From here on the other ranks sit in their serve loop (chain mode): whatever happens on rank 0 -- also before the replay
+        # starts -- the release broadcast in the finally below must go out, or they block in the collective for ever.
         try:
+            dips, last_min, first_D = merge_payloads(gathered, len(lengths), m)
+            ctx.set_residue_source(lambda c, pos, n: src.fetch(c, pos - 1, pos - 1 + n))
+            if chain:
+                att = np.concatenate([p["att"] for p in gathered]) if gathered else np.zeros((0, 3), dtype=np.int64)
+                ctx.set_att(np.unique(att, axis=0) if att.shape[0] else att)     # (a window shared by two slices is reported by both)
+
+                def source(pairs):
+                    # (the broadcast and the gather form one exchange: nothing that can raise sits between them --
+                    #  serve_chain_request reports its failures as piece statuses)
+                    _bcast_int64(encode_chain_request(pairs), 0, device=device, group=group)
+                    blocks = _gather_int64(serve_chain_request(ctx, genome, plan[0], nwin_of, pairs), device=device, group=group)
+                    pieces = [d for b in blocks for d in decode_chain_pieces(b)]
+                    return walk_chain_pieces(ctx, pairs, pieces, ws if not mode_single else [ctx.ws[0]])
+                ctx.set_chain_source(source)
             ctx.replay_dips(mode, buff, genome_pos, flags, lengths, first_D, dips, last_min, align)
         finally:
             ctx.set_residue_source(None)

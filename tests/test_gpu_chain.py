@@ -254,3 +254,77 @@ def test_chain_replay_in_small_batches(ctx, alp_ref, genes, monkeypatch):
         assert [(hit_key(h), h["dist"]) for h in hits] == [(hit_key(h), h["dist"]) for h in ohits]
     finally:
         g.free()
+
+
+def test_chain_near_identical_references_tiny_minima(ctx):
+    """A family of 128 near-identical alleles (one substitution in one copy), an exact copy at the START of a 200 kb record (the
+    first window's distance is where the running minimum starts, GenomeMiner.jl:57) and more exact copies further on: the dips'
+    minima are a few units of D (distance ~1e-5) and tie with the running minimum, so the pair is chained.  The running value's error, inherited from
+    windows of ordinary distance, is large RELATIVE to such a minimum (1e-9 ... 1e-7) -- which says nothing about the threshold:
+    the drift check measures against max(distance, thr) and the chain replay must go through (it used to fail with KGMA_E_STATE)."""
+    from kmergma_amd import refprep
+    from kmergma_amd.fasta import Record
+    k, L = 6, 300
+    for n_refs in (64, 128, 256):
+        rng = np.random.default_rng(n_refs)
+        base = bytearray(random_dna(rng, L))
+        odd = bytearray(base); odd[150] = ord("A") if base[150] != ord("A") else ord("C")
+        refs = [Record(f"a{i}", bytes(base)) for i in range(n_refs - 1)] + [Record("odd", bytes(odd))]
+        RV, W, cons, (S, N) = refprep.gen_ref_ws_cons(refs, k, return_int=True)
+        a = bytearray(random_dna(rng, 200_000))
+        for pos in (0, 30_000, 120_000):
+            a[pos:pos + L] = base
+        a[170_000:170_000 + L] = mutate(rng, bytes(base), 0.02)
+        seq = bytes(a)
+        thr = 20.0
+        ohits, _ = orc.single_scan([seq], RV, k, W, thr, 50)
+        ctx.set_refs(k, [RV], [W], [thr], [N])
+        g = ctx.genome_from_host([seq])
+        try:
+            ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_CHAIN_REPLAY, None)
+            hits, st = ctx.hits(), ctx.stats()
+            assert st["n_chain_pairs"] == 1 and st["chain_rescans"] == 0
+            assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohits]
+            assert [h["dist"] for h in hits] == [h["dist"] for h in ohits]
+            assert min(d["D_min"] for d in ctx.dips()) <= 64 * N      # (the planted exact copies: a few units of D per reference)
+        finally:
+            g.free()
+
+
+def test_chain_drift_beyond_the_band_repeats_the_scan(alp_ref, monkeypatch):
+    """kgma_scan's drift policy, forced on a small input: with the threshold guard band narrowed to 2^-44 (KGMA_BAND_LOG2, read at
+    kgma_create) the chain's ordinary rounding drift (1e-13 ... 1e-12) exceeds half of it, the scan is repeated with a band that
+    covers the measured drift, and the hits are the oracle's."""
+    monkeypatch.setenv("KGMA_BAND_LOG2", "44")
+    c2 = _lib.Context(0)
+    try:
+        rng = np.random.default_rng(5150)
+        contigs = [random_dna(rng, 3_000_000)]
+        thr, k, W = 37.0, 6, alp_ref["ws"]
+        c2.set_refs(k, [alp_ref["RV"]], [W], [thr], [alp_ref["N"]])
+        g = c2.genome_from_host(contigs)
+        c2.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_CHAIN_REPLAY, None)
+        hits, st = c2.hits(), c2.stats()
+        g.free()
+        ohits, _ = orc.single_scan(contigs, alp_ref["RV"], k, W, thr, 50)
+        assert st["chain_rescans"] >= 1 and st["chain_band_log2"] < 44, st
+        assert st["chain_max_drift"] < 2.0 ** -(st["chain_band_log2"] + 1)
+        assert [hit_key(h) for h in hits] == [hit_key(h) for h in ohits]
+        assert [h["dist"] for h in hits] == [h["dist"] for h in ohits]
+        assert st["n_tie_flagged"] == 0
+        # the band is back at its default for the next scan
+        c2.scan(g if False else c2.genome_from_host([contigs[0][:100_000]]), _lib.MODE_SINGLE, 50, 0, 0, None)
+    finally:
+        c2.close()
+
+
+def test_chain_values_first_window_only(ctx, alp_ref):
+    rng = np.random.default_rng(3)
+    seq = random_dna(rng, 5000)
+    ctx.set_refs(6, [alp_ref["RV"]], [alp_ref["ws"]], [30.0], [alp_ref["N"]])
+    g = ctx.genome_from_host([seq])
+    try:
+        v = g.chain_values(0, 1, [(1, 1)])
+        assert v.tolist() == [orc.kmer_dist_kfv(seq[:alp_ref["ws"]], alp_ref["RV"], 6)]
+    finally:
+        g.free()

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--gb", type=float, default=100.0)
     ap.add_argument("--plants", type=int, default=2000)
     ap.add_argument("--out", default="")
+    ap.add_argument("--dump-hits", default="", help="rank 0 writes the merged hit list here (JSON; tests compare N ranks with one)")
+    ap.add_argument("--no-chain", action="store_true", help="skip the chain-mode repeat of the one-process run")
     args = ap.parse_args()
     k = 7
     tf = os.path.join(ROOT, "tests", "data", "Alp_V_ref.fasta")
@@ -90,7 +92,7 @@ def main():
     st = ctx.stats()
     hits = ctx.hits_array()
     chain = None
-    if world == 1:
+    if world == 1 and not args.no_chain:
         # the same scan in chain mode (KGMA_F_CHAIN_REPLAY: what findGenes_cluster_mode's mirror runs): twice, the second
         # with the context's buffers and pool estimate in place
         for _ in range(2):
@@ -112,6 +114,7 @@ def main():
     by_c = {}
     for h in hits:
         by_c.setdefault(int(h["contig"]) + rec0, []).append(int(h["cmi"]) + 1)
+    hit_rows = [[int(h["contig"]) + rec0, int(h["kfv"]), int(h["cmi"]), int(h["lo"]), int(h["hi"]), int(h["genome_pos"])] for h in hits]
     if world > 1:
         import torch
         from kmergma_amd import parallel
@@ -130,6 +133,7 @@ def main():
             by_c = {}
             for h in merged:
                 by_c.setdefault(int(h["contig"]), []).append(int(h["cmi"]) + 1)
+            hit_rows = [[int(h["contig"]), int(h["kfv"]), int(h["cmi"]), int(h["lo"]), int(h["hi"]), int(h["genome_pos"])] for h in merged]
     if rank != 0:
         g.free()
         ctx.close()
@@ -155,6 +159,9 @@ def main():
         "chain_mode": chain,
     }
     print(json.dumps(out, indent=1))
+    if args.dump_hits:
+        with open(args.dump_hits, "w") as fh:
+            json.dump({"columns": ["contig", "kfv", "cmi", "lo", "hi", "genome_pos"], "hits": hit_rows}, fh)
     if args.out:
         with open(args.out, "w") as fh:
             json.dump(out, fh, indent=1)
