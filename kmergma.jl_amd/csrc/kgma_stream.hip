@@ -1785,9 +1785,10 @@ static GeomVal stream8_geometry_of(int k, bool s16, int nkfv, int nd, bool chain
         if (hipFuncGetAttributes(&fa0, fn) == hipSuccess && fa0.localSizeBytes <= 64) regs = fa0.numRegs;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
-            if (prop.sharedMemPerMultiprocessor > 0) dev_lds = (size_t)prop.sharedMemPerMultiprocessor;
-            // regsPerMultiprocessor: 32-bit registers per CU = 4 SIMDs x 64 lanes x registers per lane
-            if (prop.regsPerMultiprocessor >= 4 * 64 * 128) dev_regs_per_simd_lane = prop.regsPerMultiprocessor / (4 * 64);
+            // (gfx950: 160 KiB of LDS per CU, 512 vector registers per lane and SIMD.  The runtime's property fields are taken when
+            //  they say MORE -- some report the per-workgroup limits there, 64 KiB / 65536 registers, which would halve the estimate)
+            if ((size_t)prop.sharedMemPerMultiprocessor > dev_lds) dev_lds = (size_t)prop.sharedMemPerMultiprocessor;
+            if (prop.regsPerMultiprocessor / (4 * 64) > dev_regs_per_simd_lane) dev_regs_per_simd_lane = prop.regsPerMultiprocessor / (4 * 64);
         }
     }
     for (int nw = 16; nw >= 4; nw--) {

@@ -14,8 +14,9 @@ keeps what the reference keeps on the host: FASTA parsing, reference preparation
 re-alignment of hits and FASTA-record construction.  There is no CPU scan path in this package.
 
 Differences a caller can observe (all documented in DESIGN.md):
-  * `refVec` must be an average of integer histograms (KFV = S/N).  Pass `n_refs=N` (the number of
-    reference sequences) or let the library infer it.
+  * a `refVec` that is an average of integer histograms (KFV = S/N: what gen_ref_ws_cons / cluster_ref_API produce) is
+    scanned in exact integers: pass `n_refs=N` (the number of reference sequences) or let the library infer it.  Any
+    other Float64 vector is scanned in Float64 (kgma.h, kgma_set_refs).
   * with KmerDistThr = 0 the threshold estimate uses numpy's RNG, not Julia's (explicit
     thresholds reproduce the reference bit for bit).
   * `do_align=True` needs an `aligner` callable (see `kmergma_amd.align`); the default is the
