@@ -180,7 +180,7 @@ void kgma_destroy(kgma_ctx *ctx);
  * refVec::Vector{Float64} (src/GenomeMiner.jl:6, src/OmnGenomeMiner.jl:9) may be any vector, and so may `ref`:
  *   - a KFV that is S/N with integer S (every KFV gen_ref_ws_cons / cluster_ref_API produce is one: an average of N integer
  *     histograms) is scanned in EXACT integers, S = round(ref*N).  n_refs[m] gives N per KFV; n_refs == NULL: N is inferred
- *     (smallest N <= 2^20 with every ref*N within a relative 1e-12 of an integer);
+ *     (smallest N <= 2^20 with every ref*N within a relative 1e-14 of an integer);
  *   - any other finite vector (weighted averages, smoothed or hand-edited profiles; also a KFV that is not S/n_refs for the
  *     n_refs given) is scanned in Float64 by the generic kernel: every window's distance within ~1e-12 relative of the
  *     reference's running value; the decisions rounding noise could take either way in the reference -- a window within a

@@ -865,11 +865,17 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
         const double *r = ref + (size_t)j * (size_t)NB;
         // Is the KFV S/N with integer S (what gen_ref_ws_cons / cluster_ref_API produce: an average of integer histograms)?  Then the
         // device computes in exact integers.  Anything else -- refVec::Vector{Float64} may be any vector (src/GenomeMiner.jl:6,
-        // src/OmnGenomeMiner.jl:9) -- takes the Float64 form of the generic kernel.  "Is S/N": every entry times N within 1e-12
-        // (relative) of a non-negative integer, i.e. S/N up to the rounding of its own division.
+        // src/OmnGenomeMiner.jl:9) -- takes the Float64 form of the generic kernel.  "Is S/N": every entry times N within 1e-14
+        // (relative) of a non-negative integer, i.e. S/N up to the rounding of its own division or multiplication (a looser test
+        // finds "N" for irrational vectors too: 1/sqrt(2)-weighted averages are within 5e-13 of S/665857, a convergent).
+        // (only the non-zero entries can fail: a KFV at k = 10 has a million entries, nearly all of them zero, and the inference
+        //  below tries up to 2^20 candidates)
+        std::vector<double> nz;
+        for (int64_t x = 0; x < NB; x++)
+            if (r[x] != 0.0) nz.push_back(r[x]);
         auto is_s_over_n = [&](const int64_t cand, const double tol) {
-            for (int64_t x = 0; x < NB; x++) {
-                const double v = r[x] * (double)cand, rv = std::nearbyint(v);
+            for (const double e : nz) {
+                const double v = e * (double)cand, rv = std::nearbyint(v);
                 if (!(std::fabs(v - rv) <= tol * std::max(1.0, std::fabs(v))) || rv < 0 || rv > 2.0e9) return false;
             }
             return true;
@@ -881,10 +887,10 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
         if (n_refs) {
             N = n_refs[j];
             if (N < 1) return fail(ctx, KGMA_E_ARG, "n_refs[%d] = %lld", j, (long long)N);
-            if (!is_s_over_n(N, 1e-12)) fp = true;
+            if (!is_s_over_n(N, 1e-14)) fp = true;
         } else {
             for (int64_t cand = 1; cand <= (1 << 20) && N == 0; cand++)
-                if (is_s_over_n(cand, 1e-12)) N = cand;
+                if (is_s_over_n(cand, 1e-14)) N = cand;
             if (N == 0) fp = true;
         }
         f.ref.assign(r, r + NB);

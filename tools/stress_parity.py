@@ -41,12 +41,17 @@ def key(h):
 
 
 KSET = None          # --k: restrict the k-mer lengths (e.g. 5,6,7: the ones the chain kernel serves)
+WIDE = False         # --wide: windows of 2040 ... 9000 residues as well (64-bit carries / the generic kernel)
+FLOAT = 0.0          # --float p: with probability p the KFVs are made general Float64 vectors (the generic kernel's Float64 form)
 DEVICE_PAIRS = [0, 0]     # chain pairs walked on the device / in all
 
 
 def one_case(ctx, rng, case):
     k = int(rng.integers(2, 11)) if not KSET else int(rng.choice(KSET))
     base_len = int(rng.choice([rng.integers(k + 2, 60), rng.integers(60, 400), rng.integers(400, 2030 + k)]))
+    if WIDE and rng.random() < 0.6:
+        base_len = int(rng.choice([rng.integers(2031 + k, 2100), rng.integers(2100, 9000)]))
+    as_float = FLOAT > 0 and rng.random() < FLOAT
     m = int(rng.choice([1, 1, 2, 3, 5, 8]))
     # reference sets: m clusters of mutated copies of related genes, lengths spread by up to +-6
     root = rdna(rng, base_len + 8)
@@ -60,15 +65,25 @@ def one_case(ctx, rng, case):
         n = int(rng.integers(1, 9))
         recs = [Record(f"r{j}_{i}", mutate(rng, g, 0.03)) for i in range(n)]
         RV, W, cons, (S, N) = refprep.gen_ref_ws_cons(recs, k, return_int=True)
-        if W <= k or W - k + 1 > 2031:
+        if W <= k or W - k + 1 > (65535 if WIDE else 2031):
             return None
         if case % 3 == 1:
             RV = np.asarray(S, dtype=np.float64) / float(N)      # the division form of cluster_ref_API (ReferenceGeneration.jl:118)
+        if as_float:
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                RV = RV * (1.0 + rng.uniform(-1.0, 1.0, RV.size) * 10.0 ** rng.uniform(-9, -3, RV.size))
+            elif kind == 1:
+                RV = RV * (1.0 / np.sqrt(2.0)) + np.roll(RV, 1) * (1.0 - 1.0 / np.sqrt(2.0))
+            else:
+                RV = (RV + 0.01 / np.pi) / (1.0 + 0.01 / np.pi)
         KFVs.append(RV); ws.append(W); Ss.append(S); Ns.append(N); genes.append(g)
     # genome
     contigs = []
     for c in range(int(rng.integers(1, 5))):
         L = int(rng.choice([rng.integers(1, 3 * base_len + 10), rng.integers(1000, 60000)]))
+        if base_len > 2031 and rng.random() < 0.5:
+            L = int(rng.integers(base_len, 6 * base_len))
         a = bytearray(rdna(rng, L))
         for _ in range(int(rng.integers(0, 6))):
             g = mutate(rng, genes[int(rng.integers(0, m))], float(rng.random()) * 0.2)
@@ -90,13 +105,15 @@ def one_case(ctx, rng, case):
     buff = int(rng.choice([0, 5, 50, 200]))
     gp0 = int(rng.integers(0, 1000))
     try:
-        ctx.set_refs(k, KFVs, ws, thr, Ns)
+        ctx.set_refs(k, KFVs, ws, thr, None if as_float else Ns)
     except _lib.KgmaError as e:
         if e.status == _lib.KGMA_E_UNSUPPORTED:
             return None
         raise
     gen = ctx.genome_from_host(contigs)
     try:
+        if as_float:
+            return float_case(ctx, gen, rng, contigs, KFVs, ws, thr, k, m, mode_single, buff, gp0)
         if mode_single:
             ctx.scan(gen, _lib.MODE_SINGLE, buff, 0, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
             hits, d = ctx.hits(), ctx.dists(1)
@@ -161,18 +178,57 @@ def one_case(ctx, rng, case):
         gen.free()
 
 
+def float_case(ctx, gen, rng, contigs, KFVs, ws, thr, k, m, mode_single, buff, gp0):
+    """General Float64 KFVs: distances within 1e-6 of the Float64 oracle, default-mode differences only with a flag, chain mode
+    identical (chain-decided distances bit for bit)."""
+    if not mode_single and any(len(c) < k - 1 for c in contigs):
+        return None
+    mode = _lib.MODE_SINGLE if mode_single else _lib.MODE_OMN
+    g0 = 0 if mode_single else gp0
+    ctx.scan(gen, mode, buff, g0, _lib.F_RETURN_DISTS, None)
+    assert ctx.kernel_name().startswith("gen_kernel<f64"), ctx.kernel_name()
+    hits_f, dips_f, st_f = ctx.hits(), ctx.dips(), ctx.stats()
+    dl = [ctx.dists(j + 1) for j in range(1 if mode_single else m)]
+    ctx.scan(gen, mode, buff, g0, _lib.F_CHAIN_REPLAY, None)
+    hits_c, st_c = ctx.hits(), ctx.stats()
+    if mode_single:
+        ohf, od = orc.single_scan(contigs, KFVs[0], k, ws[0], thr[0], buff, return_dists=True)
+        od = [od]
+    else:
+        ohf, od = orc.omn_scan(contigs, KFVs, k, ws, thr, buff, gp0, return_dists=True)
+    for j in range(len(dl)):
+        assert len(dl[j]) == len(od[j]), "number of distances"
+        if len(dl[j]):
+            # (relative to max(d, 1): a distance near 0 is the difference of O(n) terms)
+            assert np.max(np.abs(dl[j] - od[j]) / np.maximum(np.abs(od[j]), 1.0)) < 1e-6, f"float dists kfv {j}"
+    assert [key(h) for h in hits_c] == [key(h) for h in ohf], "float KFV: chain replay vs float oracle"
+    assert st_c["n_tie_flagged"] == 0, "float KFV: chain replay left a tie flagged"
+    for a, b in zip(hits_c, ohf):
+        if a["flags"] & _lib.HIT_CHAIN:
+            assert a["dist"] == b["dist"], "float KFV: chain replay distance"
+    nflag = 0
+    if [key(h) for h in hits_f] != [key(h) for h in ohf]:
+        assert any(d["flags"] & 3 for d in dips_f) or st_f["n_at_threshold"] > 0, "float KFV: difference with nothing flagged"
+        nflag = 1
+    return dict(k=k, m=m, ws=ws, single=mode_single, hits=len(hits_f), amb=nflag)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--k", default="", help="comma-separated k-mer lengths to draw from (default: 2 ... 10)")
+    ap.add_argument("--wide", action="store_true", help="windows of 2040 ... 9000 residues as well")
+    ap.add_argument("--float", type=float, default=0.0, dest="float_p", help="probability of a general Float64 KFV set")
     args = ap.parse_args()
-    global KSET
+    global KSET, WIDE, FLOAT
     KSET = [int(x) for x in args.k.split(",")] if args.k else None
+    WIDE, FLOAT = args.wide, args.float_p
     ctx = _lib.Context(0)
     t0 = time.time()
     n = skipped = total_hits = amb = 0
     case = 0
+    last_print = t0
     while time.time() - t0 < args.seconds:
         rng = np.random.default_rng([args.seed, case])
         try:
@@ -185,7 +241,8 @@ def main():
             skipped += 1
             continue
         n += 1; total_hits += r["hits"]; amb += r["amb"]
-        if n % 50 == 0:
+        if n % 50 == 0 or time.time() - last_print > 30:
+            last_print = time.time()
             print(f"{n} cases ok ({skipped} skipped), {total_hits} hits, {amb} cases with flagged float differences, "
                   f"{time.time() - t0:.0f}s", flush=True)
     print(f"DONE {n} cases ok, {skipped} skipped, {total_hits} hits compared, {amb} cases with flagged differences; "
