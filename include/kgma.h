@@ -157,6 +157,10 @@ typedef struct {
     int32_t chain_band_log2;   /* the guard band around thr the last kgma_scan ended with: 2^-30 unless the chain's drift
                                   exceeded half of it and the scan was repeated with a wider one (kgma_scan's drift policy) */
     int32_t chain_rescans;     /* ... and how often it was repeated (0, 1 or 2)                                              */
+    double overlap_ms;         /* kgma_repack_scan_hits on a large genome re-encodes the records group by group on a few CUs
+                                  BESIDE the scan launches of the previous groups: wall time of that pack + scan region (then
+                                  pack_ms / scan_ms are the SUMS of the groups' kernel times, n_launches their number); 0 when
+                                  pack and scan ran one after the other                                                       */
 } kgma_stats;
 
 /* Host-side stand-in for `pairalign` + `cigar_to_UnitRange` (src/Alignment.jl:33-52,

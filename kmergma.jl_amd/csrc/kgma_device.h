@@ -150,6 +150,8 @@ struct ScanArgs {
     int32_t n_tiles;
     double *dist[KGMA_MAX_GROUP];   // per-KFV distance arrays or nullptr
     unsigned long long *n_att;      // stats: tested windows inside the threshold guard band
+    // stream8_kernel launched over a PART of the stream table (the pack / scan overlap of kgma_repack_scan_hits): `tiles`, `D0out`
+    // and `n_tiles` are the part's, tile0 its first stream's index in the whole table (added to the records' tile numbers).
     // two-kernel cluster path (kgma_pos.hip): this launch covers tiles [tile0, tile0 + n_chunk_tiles);
     // diff[z] holds, per window size z of the launch, tile_windows int16 per tile of the chunk
     int32_t tile0, n_chunk_tiles;

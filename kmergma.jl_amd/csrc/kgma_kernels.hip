@@ -138,10 +138,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
                                                    uint32_t *__restrict__ planes, uint32_t *__restrict__ inter,
                                                    const ContigDesc *__restrict__ cd, int n_contigs,
                                                    int64_t total_words, const int32_t *__restrict__ block_contig,
-                                                   unsigned long long *__restrict__ first_bad)
+                                                   unsigned long long *__restrict__ first_bad, int block0)
 {
-    const int64_t g0 = (int64_t)blockIdx.x * PACK_BLOCK_WORDS;
-    const int c0 = block_contig[blockIdx.x];                          // record of word g0 (or the one before its lead padding)
+    const int blk = (int)blockIdx.x + block0;                         // (block0: a launch over a part of the genome)
+    const int64_t g0 = (int64_t)blk * PACK_BLOCK_WORDS;
+    const int c0 = block_contig[blk];                                 // record of word g0 (or the one before its lead padding)
     const ContigDesc d0 = cd[c0];
     const int64_t g_end = g0 + PACK_BLOCK_WORDS <= total_words ? g0 + PACK_BLOCK_WORDS : total_words;
     const int64_t next_off = c0 + 1 < n_contigs ? cd[c0 + 1].word_off : INT64_MAX;
@@ -1236,12 +1237,16 @@ hipError_t launch_export(uint8_t *res, uint8_t *host, int64_t d0_slots, int64_t 
 int pack_block_words() { return PACK_BLOCK_WORDS; }
 
 hipError_t launch_pack(const uint8_t *ascii, uint32_t *planes, uint32_t *inter, const ContigDesc *cd, int n_contigs,
-                       int64_t total_words, const int32_t *block_contig, unsigned long long *first_bad, hipStream_t st)
+                       int64_t total_words, const int32_t *block_contig, unsigned long long *first_bad, hipStream_t st,
+                       int64_t block0, int64_t n_blocks)
 {
     if (total_words <= 0) return hipSuccess;
     const int64_t blocks = (total_words + PACK_BLOCK_WORDS - 1) / PACK_BLOCK_WORDS;
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ascii, planes, inter, cd,
-                       n_contigs, total_words, block_contig, first_bad);
+    if (n_blocks < 0) { block0 = 0; n_blocks = blocks; }              // the whole genome
+    if (block0 < 0 || block0 + n_blocks > blocks) return hipErrorInvalidValue;
+    if (n_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, ascii, planes, inter, cd,
+                       n_contigs, total_words, block_contig, first_bad, (int)block0);
     return hipGetLastError();
 }
 

@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
             const int q0 = (b << 6) - nk + 1 - dj;                    // window of lane 0
             if (att) {
                 DevRecord rec;
-                rec.tile = tile; rec.kind_kfv = REC_ATT | (kid << 8) | (BIG ? REC_WIDE : 0);
+                rec.tile = tile + a.tile0; rec.kind_kfv = REC_ATT | (kid << 8) | (BIG ? REC_WIDE : 0);
                 const int qa = q_cold() - dj;
                 rec.start = qa; rec.end = qa; rec.minE = E;
                 rec.argf = rec.argl = qa; rec.nmin = 0; rec.exitE = E; rec.has_exit = 0;
@@ -1403,7 +1403,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
                         const hot_t exitE = bj + (hot_t)__builtin_amdgcn_readlane(E, end_lane);
                         if (lane == 0) {
                             DevRecord rec;
-                            rec.tile = tile; rec.kind_kfv = REC_RUN | (kid << 8) | (BIG ? REC_WIDE : 0);
+                            rec.tile = tile + a.tile0; rec.kind_kfv = REC_RUN | (kid << 8) | (BIG ? REC_WIDE : 0);
                             rec.start = run_start; rec.end = qe - 1; rec.minE = (int32_t)(uint32_t)minE;
                             rec.argf = argf; rec.argl = argl; rec.nmin = nmin;
                             rec.exitE = (int32_t)(uint32_t)exitE; rec.has_exit = qe < n_valid ? 1 : 0;
@@ -1457,7 +1457,7 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
         const int32_t *st = NKFV > 1 ? sState + j * ST_WORDS : st_reg;
         if (((inrun_mask >> j) & 1u) && lane == 0) {
             DevRecord rec;
-            rec.tile = tile; rec.kind_kfv = REC_RUN | (gpp->kfv_id[j] << 8) | (BIG ? REC_WIDE : 0);
+            rec.tile = tile + a.tile0; rec.kind_kfv = REC_RUN | (gpp->kfv_id[j] << 8) | (BIG ? REC_WIDE : 0);
             rec.start = st[ST_START]; rec.end = n_valid - 1; rec.minE = st[ST_MINE];
             rec.argf = st[ST_ARGF]; rec.argl = st[ST_ARGL]; rec.nmin = st[ST_NMIN];
             rec.exitE = 0; rec.has_exit = 0;

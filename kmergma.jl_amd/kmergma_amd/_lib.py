@@ -61,7 +61,8 @@ class KgmaStats(C.Structure):
                 ("device_bytes", C.c_int64), ("n_tiles", C.c_int32), ("n_launches", C.c_int32),
                 ("chain_ms", C.c_double), ("n_chain_pairs", C.c_int64), ("chain_windows", C.c_int64),
                 ("chain_device_pairs", C.c_int64), ("chain_device_ms", C.c_double), ("chain_raw_steps", C.c_int64),
-                ("chain_max_drift", C.c_double), ("chain_band_log2", C.c_int32), ("chain_rescans", C.c_int32)]
+                ("chain_max_drift", C.c_double), ("chain_band_log2", C.c_int32), ("chain_rescans", C.c_int32),
+                ("overlap_ms", C.c_double)]
 
 
 HIT_DTYPE = np.dtype([("contig", "<i4"), ("kfv", "<i4"), ("cmi", "<i8"), ("lo", "<i8"), ("hi", "<i8"),

@@ -1124,3 +1124,43 @@ def test_stream8_int32_s_tables(ctx, k):
         assert np.array_equal(gen.chain_values(0, 1, [(100_000, 100_001)]), od[99_998:100_000])
     finally:
         gen.free()
+
+
+def test_overlapped_step_equals_sequential_step(alp_ref, genes, monkeypatch):
+    """kgma_repack_scan_hits on a large genome re-encodes the records group by group on a few CUs beside the scan launches of the
+    previous groups (CU-masked streams).  Forced here on a small genome (KGMA_OVERLAP_MIN_BASES): hits, distances of the chain
+    mode and statistics must equal the sequential step's (KGMA_OVERLAP=0), also after the residues changed (poke)."""
+    rng = np.random.default_rng(99)
+    lengths = [900_000, 1_200_000, 300, 2_000_000, 700_000, 1_500_000, 288, 1_100_000, 400_000, 2_500_000, 650_000, 1_000_000]
+    contigs, _ = make_genome(rng, lengths, genes, n_plants_per_mb=30)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("KGMA_OVERLAP", mode)
+        monkeypatch.setenv("KGMA_OVERLAP_MIN_BASES", "1000000")
+        c = _lib.Context(0)
+        try:
+            c.set_refs(6, [alp_ref["RV"]], [alp_ref["ws"]], [30.0], [alp_ref["N"]])
+            g = c.genome_from_host(contigs)
+            out = []
+            for flags in (_lib.F_NO_TIE_RESOLVE, _lib.F_CHAIN_REPLAY, _lib.F_CHAIN_REPLAY):
+                h = c.step_hits(g, _lib.MODE_SINGLE, 50, 0, flags)
+                st = c.stats()
+                out.append(([tuple(int(x[f]) for f in ("contig", "cmi", "lo", "hi", "genome_pos", "D")) for x in h], [float(x["dist"]) for x in h]))
+                assert (st["overlap_ms"] > 0) == (mode == "1"), st
+                assert st["n_launches"] == (1 if mode == "0" else 8)
+            gene = genes[3]
+            g.poke(3, 1_000_001, gene)                          # a new gene in record 3, and a residue that is not A/C/G/T/N in record 9
+            h = c.step_hits(g, _lib.MODE_SINGLE, 50, 0, 0)
+            out.append(([tuple(int(x[f]) for f in ("contig", "cmi", "lo", "hi", "genome_pos", "D")) for x in h], []))
+            g.poke(9, 77, b"R")
+            with pytest.raises(_lib.BadBaseError) as e:
+                c.step_hits(g, _lib.MODE_SINGLE, 50, 0, 0)
+            assert "record 9 position 77" in str(e.value)
+            g.free()
+            res[mode] = out
+        finally:
+            c.close()
+    assert res["0"] == res["1"]
+    assert len(res["0"][0][0]) > 100
+    ohits, _ = orc.single_scan(contigs, alp_ref["RV"], 6, alp_ref["ws"], 30.0, 50)
+    assert [t[:5] for t in res["1"][1][0]] == [(h["contig"], h["cmi"], h["lo"], h["hi"], h["genome_pos"]) for h in ohits]

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.KgmaHit) == 64
     assert ctypes.sizeof(_lib.KgmaDip) == 64
-    assert ctypes.sizeof(_lib.KgmaStats) == 152
+    assert ctypes.sizeof(_lib.KgmaStats) == 160
 
 
 def test_version_and_status_strings():
