@@ -3664,15 +3664,13 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64
     return KGMA_OK;
 }
 
-int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, int64_t genome_pos0,
-              uint32_t flags, kgma_align_fn align, void *align_user)
+// Device scan + (KGMA_F_CHAIN_REPLAY) the chain replay, with the replay's drift policy: the scan samples the reference's running
+// value at the windows whose exact distance is below or within 2^-band_log2 of thr.  If the replayed value turns out further than
+// half of that from the exact distances (long records, values accumulated at large distances), the band no longer provably holds
+// every window the reference may see below thr: the scan is repeated with a band that covers four times the drift measured (more
+// windows sampled, more raw steps in the chain kernel), up to twice; only a drift beyond 2^-10 fails (KGMA_E_STATE).
+static int scan_and_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, uint32_t flags)
 {
-    // Drift policy of the chain replay: the scan samples the reference's running value at the windows whose exact distance is
-    // below or within 2^-band_log2 of thr.  If the replayed value turns out further than half of that from the exact distances
-    // (long records, values accumulated at large distances), the band no longer provably holds every window the reference may
-    // see below thr: the scan is repeated with a band that covers four times the drift measured (more windows sampled, more raw
-    // steps in the chain kernel), up to twice; only a drift beyond 2^-10 fails (KGMA_E_STATE).
-    if (!ctx) return KGMA_E_ARG;
     auto set_band = [&](int b) {
         ctx->band_log2 = b;
         for (int j = 0; j < ctx->m; j++) threshold_band(ctx->kfv[(size_t)j].thr, ctx->k, ctx->kfv[(size_t)j].N, &ctx->kfv[(size_t)j].T, &ctx->kfv[(size_t)j].T_hi, b);
@@ -3696,15 +3694,22 @@ int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, i
                 rescans++;
                 continue;
             }
-            if (rc) break;
         }
-        rc = replay_hits(ctx, g, mode, buff, genome_pos0, flags, align, align_user);
         break;
     }
     ctx->stats.chain_band_log2 = ctx->band_log2;
     ctx->stats.chain_rescans = rescans;
-    if (ctx->band_log2 != ctx->band_log2_default) set_band(ctx->band_log2_default);
+    if (ctx->band_log2 != ctx->band_log2_default) set_band(ctx->band_log2_default);   // (the dips carry their flags: the replay below does not read the band)
     return rc;
+}
+
+int kgma_scan(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t buff, int64_t genome_pos0,
+              uint32_t flags, kgma_align_fn align, void *align_user)
+{
+    if (!ctx) return KGMA_E_ARG;
+    const int rc = scan_and_decide(ctx, g, mode, buff, flags);
+    if (rc) return rc;
+    return replay_hits(ctx, g, mode, buff, genome_pos0, flags, align, align_user);
 }
 
 int kgma_chain_values(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int32_t kfv, const int64_t *win_lo, const int64_t *win_hi,
@@ -3887,12 +3892,10 @@ int kgma_scan_aligned(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t
             return fail(ctx, KGMA_E_UNSUPPORTED, "consensus %d: %lld residues", j + 1, (long long)consensus_len[j]);
     ctx->aligns.clear();
     ctx->n_align_device = ctx->n_align_host = 0;
-    int rc = kgma_scan_device(ctx, g, mode, flags);
+    int rc = scan_and_decide(ctx, g, mode, buff, flags);
     if (rc) return rc;
-    reset_chain_stats(ctx);
     if ((flags & KGMA_F_CHAIN_REPLAY) && !(flags & KGMA_F_NO_TIE_RESOLVE)) {
-        rc = chain_decide(ctx, g, mode, buff);
-        if (rc) return rc;
+        // (decided by the chain replay)
     } else if (!(flags & KGMA_F_NO_TIE_RESOLVE)) {
         rc = kgma_resolve_ties_local(ctx, g);                          // the dips' best windows are final before they are aligned
         if (rc) return rc;
@@ -3906,12 +3909,32 @@ int kgma_scan_aligned(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t
         const int64_t W = ctx->kfv[0].W;
         const int64_t cl = std::min<int64_t>(consensus_len[0], W);
         if (cl < 1) return fail(ctx, KGMA_E_UNSUPPORTED, "consensus 1 is empty and %lld hits are to be aligned against it", (long long)nh);
-        std::vector<int32_t> hc((size_t)nh);
-        std::vector<int64_t> lo((size_t)nh), hi((size_t)nh), first((size_t)nh), last((size_t)nh);
-        for (int64_t i = 0; i < nh; i++) { hc[(size_t)i] = ctx->hits[(size_t)i].contig; lo[(size_t)i] = ctx->hits[(size_t)i].lo; hi[(size_t)i] = ctx->hits[(size_t)i].hi; }
-        rc = kgma_align_hits_device(ctx, g, consensus[0], cl, gap_open_score, gap_extend_score, nh, hc.data(), lo.data(), hi.data(),
-                                    first.data(), last.data(), nullptr);
-        if (rc) return rc;
+        // (segments beyond the device aligner's rows -- windows of more than ~8000 residues -- are aligned by the host restatement)
+        std::vector<int32_t> hc;
+        std::vector<int64_t> lo, hi, which, first((size_t)nh), last((size_t)nh);
+        int64_t n_host = 0;
+        for (int64_t i = 0; i < nh; i++) {
+            const kgma_hit &h = ctx->hits[(size_t)i];
+            const int64_t n = h.hi - h.lo + 1;
+            if (n >= 1 && n <= KGMA_ALIGN_MAX_SEGMENT) { hc.push_back(h.contig); lo.push_back(h.lo); hi.push_back(h.hi); which.push_back(i); continue; }
+            std::vector<uint8_t> seg((size_t)std::max<int64_t>(n, 1));
+            std::vector<char> cig((size_t)(2 * (cl + std::max<int64_t>(n, 0)) + 16));
+            int64_t score = 0, f1 = 1, l1 = n;
+            if (n < 1 || hipMemcpy(seg.data(), g->d_ascii + g->cd[(size_t)h.contig].ascii_off + (h.lo - 1), (size_t)n, hipMemcpyDeviceToHost) != hipSuccess ||
+                kgma_host_semiglobal_cigar(consensus[0], cl, seg.data(), n, gap_open_score, gap_extend_score, cig.data(), (int64_t)cig.size(), &score) != KGMA_OK)
+                return fail(ctx, KGMA_E_HIP, "host fallback alignment of hit %lld failed", (long long)i);
+            cigar_range(cig.data(), &f1, &l1);
+            first[(size_t)i] = f1; last[(size_t)i] = l1;
+            n_host++;
+        }
+        if (!which.empty()) {
+            std::vector<int64_t> f2(which.size()), l2(which.size());
+            rc = kgma_align_hits_device(ctx, g, consensus[0], cl, gap_open_score, gap_extend_score, (int64_t)which.size(), hc.data(), lo.data(), hi.data(),
+                                        f2.data(), l2.data(), nullptr);
+            if (rc) return rc;
+            for (size_t u = 0; u < which.size(); u++) { first[(size_t)which[u]] = f2[u]; last[(size_t)which[u]] = l2[u]; }
+        }
+        ctx->n_align_host = n_host;
         for (int64_t i = 0; i < nh; i++) {
             kgma_hit &h = ctx->hits[(size_t)i];
             const int64_t L = ctx->contig_len[(size_t)h.contig];
@@ -3920,7 +3943,7 @@ int kgma_scan_aligned(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64_t
             h.lo = std::max<int64_t>(1, l0 + first[(size_t)i] - 1);
             h.hi = std::min<int64_t>(l0 + last[(size_t)i] - 1, L);
         }
-        ctx->n_align_device = nh;
+        ctx->n_align_device = nh - n_host;
         return KGMA_OK;
     }
     // cluster engine: speculate every dip's candidate range, one device batch per KFV

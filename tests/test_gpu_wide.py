@@ -334,3 +334,37 @@ def test_float64_kfvs_cluster(ctx, alp_clusters, genes):
             _assert_omn_chain_parity(ctx.hits(), ctx.dips(), ctx.stats(), fo)
         finally:
             gen.free()
+
+
+def test_aligned_scan_with_segments_beyond_the_device_aligner(ctx):
+    """kgma_scan_aligned with windows of 9000 residues: the hits' segments (W + 2 buff residues) exceed the device aligner's 8191
+    rows, so they are aligned by the host restatement -- same ranges as the scan with the host aligner as its callback."""
+    from kmergma_amd import align
+    k, W = 6, 9000
+    rng = np.random.default_rng(123)
+    base, ref = _family(rng, W, k)
+    RV, N = ref["RV"], ref["N"]
+    cons = refprep.gen_ref_ws_cons([Record("c", base)], k)[2]
+    a = bytearray(random_dna(rng, 60_000))
+    a[7000:7000 + W] = mutate(rng, base, 0.03)
+    g2 = bytearray(mutate(rng, base, 0.02)); del g2[4000:4007]; g2[2000:2000] = b"ACGTACG"      # an indel pair
+    a[30_000:30_000 + len(g2)] = g2
+    contigs = [bytes(a)]
+    thr = _thr_for(rng, ref)
+    go, ge = -69, -1
+    ctx.set_refs(k, [RV], [W], [thr], [N])
+    gen = ctx.genome_from_host(contigs)
+    try:
+        def cb(contig, kfv, lo, hi, L):
+            cig, _ = align.semiglobal_cigar(cons[:W], contigs[contig][lo - 1:hi], go, ge)
+            f, l = align.cigar_to_UnitRange(cig)
+            return max(1, lo + f - 1), min(lo + l - 1, L)
+        ctx.scan(gen, _lib.MODE_SINGLE, 50, 0, _lib.F_CHAIN_REPLAY, cb)
+        want = [hit_key(h) for h in ctx.hits()]
+        ctx.scan_aligned(gen, _lib.MODE_SINGLE, 50, 0, _lib.F_CHAIN_REPLAY, [cons], go, ge)
+        got = [hit_key(h) for h in ctx.hits()]
+        al, n_dev, n_host = ctx.alignments()
+        assert len(want) == 2 and got == want
+        assert n_host == 2 and n_dev == 0
+    finally:
+        gen.free()
