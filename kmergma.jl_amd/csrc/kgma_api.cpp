@@ -49,6 +49,8 @@ bool stream8_c16_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16, bool
 int generic_slots_per_cu(int k, bool fp);
 bool generic_counts_in_lds(int k);
 hipError_t launch_generic(const ScanArgs &a, const GenParams &g, hipStream_t st);
+int generic_chain_slots_per_cu(int k);
+hipError_t launch_generic_chain(const ScanArgs &a, const GenParams &g, hipStream_t st);
 hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
 bool chain_applies(int k, int nk, int64_t n_ref, bool s16, bool need_wide);
 int chain_slots_per_cu(int k, bool s16, int nkfv, int nk, bool need_wide);
@@ -921,6 +923,7 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
             if (N == 0) fp = true;
         }
         f.ref.assign(r, r + NB);
+        for (int64_t x = 0; x < NB; x++) f.sumR2 += r[x] * r[x];          // (the Float64 kernels' first-window identity)
         __int128 s2 = 0;
         if (fp) {
             // Float64 form.  The host keeps every distance on an integer lattice D = round(d * 2kN^2) with N a power of two chosen so
@@ -931,7 +934,7 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
             int q = 20;
             while (q > 0 && fmax * std::ldexp(1.0, 2 * q) >= std::ldexp(1.0, 61)) q--;
             if (fmax >= std::ldexp(1.0, 61)) return fail(ctx, KGMA_E_UNSUPPORTED, "KFV %d: entries of magnitude %.3g are outside the device path's range", j + 1, amax);
-            f.fp = true; f.N = (int64_t)1 << q; f.sumR2 = r2;
+            f.fp = true; f.N = (int64_t)1 << q;
             f.S.clear(); f.Smax = INT64_MAX; f.sumS2 = 0;
             f.fits32 = false; f.big_ok = false; f.ref_form = -1;
             f.thr = thr[j];
@@ -979,8 +982,10 @@ int kgma_set_refs(kgma_ctx *ctx, int32_t k, int32_t m, const double *ref, const 
             tab[(size_t)j * (size_t)NB + device_index_of((uint32_t)v, k)] = (int32_t)kv[(size_t)j].S[(size_t)v];
     }
     if (ctx->d_Rtab) { (void)hipFree(ctx->d_Rtab); ctx->d_Rtab = nullptr; }
-    if (any_fp) {
-        // the KFVs as given (Float64), in the kernels' index order: what the Float64 form reads
+    (void)any_fp;
+    {
+        // the KFVs as given (Float64), in the kernels' index order: what the Float64 form of the generic kernel and its chain
+        // kernel read (the chain forms the reference's increments from the caller's own table)
         std::vector<double> rt((size_t)m * (size_t)NB);
         for (int j = 0; j < m; j++)
             for (int64_t v = 0; v < NB; v++)
@@ -2830,21 +2835,33 @@ static bool chain_device_enabled()
 }
 
 static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vector<ChainPair> &pairs, std::vector<size_t> el, std::vector<char> &done,
-                                 ChainDevInfo &info, bool export_only = false, int pin_sel = 0, std::function<int()> *deferred = nullptr);
+                                 ChainDevInfo &info, bool export_only = false, int pin_sel = 0, std::function<int()> *deferred = nullptr, bool generic = false);
+
+// which chain kernel serves a KFV: 1 = stream8_kernel<..., CHAIN> (k = 5, 6, 7, S/N KFVs in one of the two forms), 2 = the generic chain
+// kernel (any k, any window, any KFV: it reads the caller's table), 0 = none (the host chain).  KGMA_CHAIN_GENERIC=0 / 1 (tests):
+// never / always the generic one.
+static int chain_kernel_for(const kgma_ctx *ctx, const KfvInfo &f)
+{
+    const int k = ctx->k, nk = (int)(f.W - k + 1);
+    const char *ge = getenv("KGMA_CHAIN_GENERIC");
+    const bool s8 = !f.fp && (f.fits32 || f.big_ok) && chain_applies(k, nk, f.N, f.Smax <= 32767, !f.fits32) && f.ref_form >= 0 &&
+                    chain_slots_per_cu(k, f.Smax <= 32767, 1, nk, !f.fits32) >= 1;
+    if (s8 && !(ge && atoi(ge) == 1)) return 1;
+    if (ge && atoi(ge) == 0) return 0;
+    return k >= 2 && k <= 10 && nk >= 1 && nk <= KGMA_MAX_NK_WIDE && generic_chain_slots_per_cu(k) >= 1 ? 2 : 0;
+}
 
 static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<ChainPair> &pairs, std::vector<char> &done, ChainDevInfo &info)
 {
-    const int k = ctx->k;
-    std::vector<size_t> el;
+    std::vector<size_t> el8, elg;
     for (size_t i = 0; i < pairs.size(); i++) {
         const ChainPair &p = pairs[i];
-        const KfvInfo &f = ctx->kfv[(size_t)p.j];
-        const int nk = (int)(f.W - k + 1);
-        if (f.fp || !(f.fits32 || f.big_ok) || !chain_applies(k, nk, f.N, f.Smax <= 32767, !f.fits32) || f.ref_form < 0 || p.last < 2) continue;
-        if (chain_slots_per_cu(k, f.Smax <= 32767, 1, nk, !f.fits32) < 1) continue;
-        el.push_back(i);
+        if (p.last < 2) continue;
+        const int which = chain_kernel_for(ctx, ctx->kfv[(size_t)p.j]);
+        if (which == 1) el8.push_back(i);
+        else if (which == 2) elg.push_back(i);
     }
-    if (el.empty()) return KGMA_OK;
+    if (el8.empty() && elg.empty()) return KGMA_OK;
     (void)hipSetDevice(ctx->device);
     // batches of bounded size (2^35 windows: a chunk array of 128 MiB), in record order; the host part of a batch overlaps
     // the device part of the next, so what stays exposed is the LAST batch's host part: smaller batches, shorter tail
@@ -2860,15 +2877,17 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
         ~Worker() { if (th.joinable()) th.join(); }
     } worker;
     int sel = 0;
+    for (int pass = 0; pass < 2; pass++) {
+    const std::vector<size_t> &el = pass == 0 ? el8 : elg;
     for (size_t u0 = 0; u0 < el.size();) {
         size_t u1 = u0;
         int64_t w = 0;
         while (u1 < el.size() && (u1 == u0 || w + pairs[el[u1]].last <= BATCH_WINDOWS)) w += pairs[el[u1++]].last;
         std::function<int()> fin;
-        const bool more = u1 < el.size() || worker.th.joinable();
+        const bool more = u1 < el.size() || worker.th.joinable() || (pass == 0 && !elg.empty());
         const double tb0 = now_ms();
         const int rc = chain_on_device_batch(ctx, g, pairs, std::vector<size_t>(el.begin() + (long)u0, el.begin() + (long)u1), done, info, false, sel,
-                                             more ? &fin : nullptr);
+                                             more ? &fin : nullptr, pass == 1);
         const double tb1 = now_ms();
         const int wrc = worker.join();
         if (getenv("KGMA_CHAIN_DEBUG")) fprintf(stderr, "  chain batch: device part %.2f ms, then %.2f ms waiting for the previous batch's host part\n", tb1 - tb0, now_ms() - tb1);
@@ -2881,6 +2900,7 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
         sel ^= 1;
         u0 = u1;
     }
+    }
     const double tj0 = now_ms();
     const int wrc = worker.join();
     if (getenv("KGMA_CHAIN_DEBUG")) fprintf(stderr, "  chain: %.2f ms waiting for the last batch's host part\n", now_ms() - tj0);
@@ -2889,7 +2909,7 @@ static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<Chai
 }
 
 static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vector<ChainPair> &pairs, std::vector<size_t> el, std::vector<char> &done,
-                                 ChainDevInfo &info, bool export_only, int pin_sel, std::function<int()> *deferred)
+                                 ChainDevInfo &info, bool export_only, int pin_sel, std::function<int()> *deferred, bool generic)
 {
     const int k = ctx->k;
     const double ts0 = now_ms();
@@ -2902,6 +2922,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
     //      KFV per launch; KGMA_CHAIN_GROUP=2..4 keeps the grouped form reachable for tests and for tie-dense inputs.
     int maxg = 1;
     if (const char *e = getenv("KGMA_CHAIN_GROUP")) maxg = std::max(1, std::min(4, atoi(e)));
+    if (generic) maxg = 1;                                             // (the generic chain kernel walks one KFV)
     struct Launch { std::vector<int> kfvs; size_t t0, t1; int64_t T, chunk0, n_chunks; size_t d0_off; bool s16; };
     struct PairStreams { size_t s0, s1; int64_t T; };            // into `streams` (per pair: its slot's chunk and D0 indices)
     std::vector<TileDesc> tiles;
@@ -2926,7 +2947,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
             const KfvInfo &f0 = ctx->kfv[(size_t)kf[i]];
             const bool s16 = f0.Smax <= 32767;
             size_t e = i + 1;
-            while (e < kf.size() && (int)(e - i) < (s16 ? maxg : 1) && ctx->kfv[(size_t)kf[e]].W == f0.W && (ctx->kfv[(size_t)kf[e]].Smax <= 32767) == s16 &&
+            while (!generic && e < kf.size() && (int)(e - i) < (s16 ? maxg : 1) && ctx->kfv[(size_t)kf[e]].W == f0.W && (ctx->kfv[(size_t)kf[e]].Smax <= 32767) == s16 &&
                    f0.fits32 && ctx->kfv[(size_t)kf[e]].fits32 && chain_slots_per_cu(k, s16, (int)(e - i) + 1, (int)(f0.W - k + 1), false) > 0)
                 e++;
             Launch L;
@@ -2958,7 +2979,8 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
         // 2^18 (the drift a stream may add stays far below the guard band)
         int64_t T;
         {
-            const int64_t slots = (int64_t)std::max(1, ctx->n_cus) * chain_slots_per_cu(k, L.s16, nslots, nk, !ctx->kfv[(size_t)L.kfvs[0]].fits32);
+            const int64_t slots = (int64_t)std::max(1, ctx->n_cus) *
+                                  (generic ? generic_chain_slots_per_cu(k) : chain_slots_per_cu(k, L.s16, nslots, nk, !ctx->kfv[(size_t)L.kfvs[0]].fits32));
             T = (windows + slots * 3 - 1) / (slots * 3);
             if (const char *e = getenv("KGMA_CHAIN_STREAM")) T = atoll(e);                     // experiments / tests
             // (a stream's warm-up is its window's n k-mers: streams of at least 4 n transitions)
@@ -3125,13 +3147,13 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
             a.tiles = ctx->d_ctiles + L.t0;
             a.n_tiles = (int32_t)(L.t1 - L.t0);
             a.Stab = ctx->d_Stab;
-            if (k >= 7) {
+            if (!generic && k >= 7) {
                 // k = 7: the kernel gathers S from global memory, one row of int16 slots per k-mer (the scan's compacted layout)
                 const int nv = nslots == 3 ? 4 : nslots;               // row width in int16 slots (the kernel variant's)
                 rc = sinter_tables(ctx, L.kfvs, nv, &a.Sinter, &a.Sbits);
                 if (rc) return rc;
             }
-            if (stream8_state_words(k, nslots) > 0) {
+            if (!generic && stream8_state_words(k, nslots) > 0) {
                 rc = dev_reserve(ctx, ctx->d_wstate, ctx->wstate_cap, (int64_t)(L.t1 - L.t0) * stream8_state_words(k, nslots));
                 if (rc) return rc;
                 a.wave_state = ctx->d_wstate;
@@ -3150,6 +3172,23 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
             a.chain.guard = 1.862645149230957e-09;                  // 2^-29
             a.chain.guard_abs = 9.313225746154785e-10;              // 2^-30 of the stream's first distance
             a.chain.status = ctx->d_cctl + 1;
+            if (generic) {
+                const int j = L.kfvs[0];
+                const KfvInfo &f = ctx->kfv[(size_t)j];
+                GenParams gg;
+                memset(&gg, 0, sizeof gg);
+                gg.k = k; gg.nk = gp.nk; gg.N = (int32_t)f.N; gg.kfv_id = j + 1; gg.fp = 1;
+                gg.n_slots = (int32_t)((int64_t)std::max(1, ctx->n_cus) * generic_chain_slots_per_cu(k));
+                gg.sumR2 = f.sumR2; gg.SF = 1.0 / (double)k;
+                gg.R = ctx->d_Rtab + (size_t)j * (size_t)((int64_t)1 << (2 * k));
+                if (!generic_counts_in_lds(k)) {
+                    rc = dev_reserve(ctx, ctx->d_gctab, ctx->gctab_cap, (int64_t)gg.n_slots * (((int64_t)1 << (2 * k)) / 2));
+                    if (rc) return rc;
+                    gg.ctab = ctx->d_gctab;
+                }
+                HIP_TRY(ctx, launch_generic_chain(a, gg, ctx->stream));
+                continue;
+            }
             HIP_TRY(ctx, launch_chain(a, gp, ctx->stream));
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -3216,6 +3255,17 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
     const double tw0 = now_ms();
     const int64_t *h_D0 = reinterpret_cast<const int64_t *>(pin + off_D0);
     for (size_t t = 0; t < streams.size(); t++) streams[t].D0 = h_D0[stream_d0[t]];
+    if (generic) {
+        // (the generic chain kernel reports each stream's first distance as a double: onto the KFV's integer lattice)
+        for (size_t u = 0; u < el.size(); u++) {
+            const KfvInfo &f = ctx->kfv[(size_t)pairs[el[u]].j];
+            for (size_t t = ps[u].s0; t < ps[u].s1; t++) {
+                double dv;
+                memcpy(&dv, &streams[t].D0, sizeof dv);
+                streams[t].D0 = lattice_of(f, k, dv);
+            }
+        }
+    }
 
     // the chain's value at window 1: kmer_count! + sqeuclidean of the first window (GenomeMiner.jl:42-47), on the host
     std::vector<double> first(el.size(), 0.0);
@@ -3328,6 +3378,7 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64
     // ---- select the pairs ------------------------------------------------------------------
     typedef ChainPair Pair;
     std::vector<Pair> pairs;
+    int64_t why_count[5] = {0, 0, 0, 0, 0};
     // (cluster engine) does the widest candidate range of a dip meet that of another dip of its record?
     std::vector<char> dip_meets_other(ctx->dips.size(), 0);
     if (mode == KGMA_MODE_OMN) {
@@ -3369,10 +3420,11 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64
             while (p.a1 < na && ctx->att[p.a1].contig == c && ctx->att[p.a1].kfv == j) p.a1++;
             di = p.d1; ai = p.a1;
             bool need = p.a1 > p.a0;
+            int why = need ? 1 : 0;                                    // (KGMA_CHAIN_DEBUG: what selected the pair)
             mins.clear();
             mins.push_back(ctx->firstD[(size_t)j * (size_t)nc + (size_t)c]);
             for (size_t u = p.d0; u < p.d1; u++) {
-                if (ctx->dips[u].flags & (KGMA_HIT_TIE | KGMA_HIT_AT_THRESHOLD)) need = true;
+                if (ctx->dips[u].flags & (KGMA_HIT_TIE | KGMA_HIT_AT_THRESHOLD)) { need = true; if (!why) why = (ctx->dips[u].flags & KGMA_HIT_TIE) ? 2 : 3; }
                 mins.push_back(ctx->dips[u].D_min);
             }
             if (!need && mode == KGMA_MODE_SINGLE) {
@@ -3407,9 +3459,14 @@ static int chain_decide(kgma_ctx *ctx, const kgma_genome *g, int32_t mode, int64
                     for (size_t v = u + 1; v < p.d1 && !need; v++) need = near_tie(fj, ctx->dips[v].D_min, ctx->dips[u].D_min);
                 }
             }
-            if (need) pairs.push_back(std::move(p));
+            if (need && !why) why = 4;
+            if (need) { why_count[why]++; pairs.push_back(std::move(p)); }
         }
     }
+    if (getenv("KGMA_CHAIN_DEBUG"))
+        fprintf(stderr, "chain replay: %zu pairs selected: %lld by a window in the threshold band, %lld by a dip with tied minima, %lld by a dip at the threshold, "
+                "%lld by a minimum equal to the running / first / an earlier minimum\n", pairs.size(), (long long)why_count[1], (long long)why_count[2],
+                (long long)why_count[3], (long long)why_count[4]);
     ctx->dip_fmin.assign(ctx->dips.size(), 0.0);
     ctx->dip_fexit.assign(ctx->dips.size(), 0.0);
     ctx->chain_pair.assign((size_t)m * (size_t)nc, 0);
@@ -3761,7 +3818,7 @@ int kgma_chain_values(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int32
     const int rc = chain_on_device(ctx, g, pairs, done, info);
     if (rc) return rc;
     if (!done[0])
-        return fail(ctx, KGMA_E_UNSUPPORTED, "the chain kernel does not serve this KFV (k = 5, 6 or 7, at most 383 k-mers per window, KFV = S * (1/N) or S / N entry by entry, last window >= 2) or a check failed");
+        return fail(ctx, KGMA_E_UNSUPPORTED, "no chain kernel served this request (KGMA_CHAIN / KGMA_CHAIN_GENERIC switched them off, the buffers did not fit, or the walk failed a drift check)");
     memcpy(out, p.val.data(), (size_t)total * sizeof(double));
     ctx->stats.chain_device_pairs = info.pairs; ctx->stats.chain_device_ms = info.kernel_ms;
     ctx->stats.chain_raw_steps = info.raw_steps; ctx->stats.chain_max_drift = info.max_drift;
@@ -4119,14 +4176,12 @@ int kgma_chain_export(kgma_ctx *ctx, const kgma_genome *g, int64_t contig, int32
         const int src = genome_sync(ctx, gm);
         if (src) return src;
     }
-    const int k = ctx->k;
-    if (f.fp || !(f.fits32 || f.big_ok) || !chain_applies(k, (int)(f.W - k + 1), f.N, f.Smax <= 32767, !f.fits32) || f.ref_form < 0 ||
-        chain_slots_per_cu(k, f.Smax <= 32767, 1, (int)(f.W - k + 1), !f.fits32) < 1)
-        return fail(ctx, KGMA_E_UNSUPPORTED, "the chain kernel does not serve this KFV");
+    const int which = chain_kernel_for(ctx, f);
+    if (which == 0) return fail(ctx, KGMA_E_UNSUPPORTED, "no chain kernel serves this KFV");
     std::vector<char> done(1, 0);
     ChainDevInfo info;
     (void)hipSetDevice(ctx->device);
-    const int rc = chain_on_device_batch(ctx, g, pairs, std::vector<size_t>(1, 0), done, info, true);
+    const int rc = chain_on_device_batch(ctx, g, pairs, std::vector<size_t>(1, 0), done, info, true, 0, nullptr, which == 2);
     if (rc) return rc;
     if (!done[0]) return fail(ctx, KGMA_E_NOMEM, "the chain kernel's buffers do not fit");
     *n_streams = (int64_t)ctx->cx_streams.size(); *n_chunks = (int64_t)ctx->cx_chunks.size(); *pool_units = (int64_t)ctx->cx_pool.size();

@@ -361,6 +361,276 @@ __global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// gen_chain_kernel: the reference's running Float64 value (KGMA_F_CHAIN_REPLAY) where stream8_kernel<..., CHAIN> does not
+// apply -- any 2 <= k <= 10, any window, any KFV (the increments are formed from the caller's Float64 table, so they are the
+// reference's bit for bit whatever the table is).  Same contract as the stream8 chain variant (kgma_device.h: ChainArgs,
+// ChainChunk): chain streams of steps of 64 positions and chunks of KGMA_CHAIN_STEPS steps; inside a binade RN(v + inc) is a
+// translation by a number of ulps that depends only on v's parity, so a run of regular steps is (A0, dA); a step that holds a
+// wanted window or whose windows may leave the binade goes out raw (its 64 increments).  The binade test uses the Float64
+// running value d0 + sum(inc) of this kernel's own (tree-shaped) prefix sums, which is within ~1e-13 of the reference's
+// value -- far inside the 2^-29 guard band, which is also what bounds the reference's own drift from it (the host checks the
+// value at every stream start against the first distance the kernel reports).
+// ------------------------------------------------------------------------------------------------------------------
+template <bool CGLOBAL>
+__global__ __launch_bounds__(1024) void gen_chain_kernel(ScanArgs a, GenParams g)
+{
+    typedef Ops<double> O;
+    extern __shared__ uint32_t gsmem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = g_uni((int)(threadIdx.x >> 6));
+    const int nw = (int)(blockDim.x >> 6);
+    const int slot = (int)blockIdx.x * nw + wave;
+    const int k = g.k, nk = g.nk;
+    const int NB = 1 << (2 * k);
+    const uint32_t KM = (uint32_t)NB - 1u;
+    const int CW = NB / 2;
+    uint32_t *C = CGLOBAL ? g.ctab + (size_t)slot * (size_t)CW : gsmem + (size_t)wave * (size_t)CW;
+    const int kid = g.kfv_id;
+    constexpr int CS_SPLIT = 1, CS_DETAIL = 2, CS_FULL = 4;
+
+    for (int tile = slot; tile < a.n_tiles; tile += g.n_slots) {
+        for (int i = lane; i < CW; i += 64) C[i] = 0;
+        if constexpr (CGLOBAL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const TileDesc td = a.tiles[tile];
+        const int n_valid = td.n_valid;
+        const uint32_t *gi = a.inter + 2 * td.word_base;
+        const int n_pos = n_valid + nk - 1;
+        const int n_blocks = (n_pos + 63) >> 6;
+        double wsum = 0.0, d0 = 0.0, carry = 0.0;
+        int64_t pairs = 0;
+        // chain state (wave-uniform except c_acc)
+        int64_t c_acc = 0;                                            // per lane: ulps its windows added in the current run (even-parity a's)
+        int32_t c_corr = 0, c_dA = 0;
+        uint32_t c_P = 0;
+        int c_state = CS_SPLIT;
+        uint32_t c_ent = 0;
+        int c_run_b0 = 0, c_chunk_b0 = 0;
+        int64_t c_gid = 0;
+        uint64_t c_hot = 0;
+        double c_lo = 1.0, c_hi = 0.0;                                // distances that provably stay inside the binade (empty: lo > hi)
+        uint32_t c_XLhi = 0;
+
+        auto pool_alloc = [&](const unsigned int n) -> uint32_t {
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(a.chain.pool_cursor, n);
+            base = (unsigned int)g_uni((int)base);
+            if ((uint64_t)base + (uint64_t)n > (uint64_t)a.chain.pool_cap) {
+                if (lane == 0) atomicOr(a.chain.status, 1u);
+                c_state |= CS_FULL;
+            }
+            return base;
+        };
+        auto run_reset = [&](const int b_next) {
+            c_acc = 0; c_corr = 0; c_dA = 0; c_P = 0;
+            c_state |= CS_SPLIT;
+            c_run_b0 = b_next;
+        };
+        auto close_run = [&](const int b_end, const bool to_detail) {
+            const int n = b_end - c_run_b0;
+            if (!(c_state & CS_DETAIL)) {
+                const int64_t total = Ops<int64_t>::sum(c_acc) + (int64_t)c_corr;
+                uint32_t base = 0;
+                if (to_detail) {
+                    int left = n_blocks - c_chunk_b0;
+                    left = (left > KGMA_CHAIN_STEPS ? KGMA_CHAIN_STEPS : left) - n;
+                    base = pool_alloc((unsigned int)left);
+                    c_ent = base;
+                    c_state |= CS_DETAIL;
+                }
+                if (lane == 0) {
+                    ChainChunk cc;
+                    cc.A0 = total;
+                    cc.info = (uint32_t)(c_dA + 1) | ((uint32_t)n << 2) | (to_detail ? KGMA_CHAIN_DETAIL : 0u);
+                    cc.raw = base;
+                    a.chain.chunks[c_gid] = cc;
+                }
+            } else if (n > 0) {
+                const int64_t total = Ops<int64_t>::sum(c_acc) + (int64_t)c_corr;
+                if (lane == 0 && !(c_state & CS_FULL)) {
+                    ChainChunk cc;
+                    cc.A0 = total;
+                    cc.info = (uint32_t)(c_dA + 1) | ((uint32_t)n << 2);
+                    cc.raw = 0;
+                    a.chain.pool[c_ent] = cc;
+                }
+                c_ent += 1;
+            }
+        };
+        auto raw_step = [&](const int b, const double inc) {
+            close_run(b, true);
+            const uint32_t slot_u = pool_alloc(32);                    // 64 doubles
+            if (!(c_state & CS_FULL)) {
+                if (lane == 0) {
+                    ChainChunk cc;
+                    cc.A0 = 0;
+                    cc.info = 1u | (1u << 2) | KGMA_CHAIN_RAW;
+                    cc.raw = slot_u;
+                    a.chain.pool[c_ent] = cc;
+                }
+                reinterpret_cast<double *>(a.chain.pool)[(size_t)slot_u * 2 + (size_t)lane] = inc;
+            }
+            c_ent += 1;
+            run_reset(b + 1);
+            c_lo = 1.0; c_hi = 0.0;                                   // the binade is looked up again at the next step
+        };
+        // binade of the distance v, with the range in which the reference's value provably shares it: guard bands relative to
+        // the binade's ends and absolute (a fraction of the stream's first distance: kgma_device.h, ChainArgs::guard_abs)
+        auto chain_binade = [&](const double v) {
+            c_lo = 1.0; c_hi = 0.0;
+            if (!(v > 0.0)) return;
+            const int e = ilogb(v);
+            if (e < -900 || e > 900) return;
+            const double blo = ldexp(1.0, e), bhi = ldexp(1.0, e + 1);
+            const double ga = a.chain.guard_abs * d0;
+            const double lo = blo + fmax(blo * a.chain.guard, ga), hi = bhi - fmax(bhi * a.chain.guard, ga);
+            if (!(v > lo && v < hi)) return;
+            c_lo = g_unid(lo); c_hi = g_unid(hi);
+            c_XLhi = (uint32_t)g_uni((int32_t)((uint32_t)(e + 1023) << 20));
+        };
+
+        for (int b = 0; b < n_blocks; b++) {
+            if ((b & (KGMA_CHAIN_STEPS - 1)) == 0) {                  // chunk begin
+                c_chunk_b0 = b;
+                c_state &= CS_FULL;
+                run_reset(b);
+                c_gid = td.dist_base + (b >> KGMA_CHAIN_STEPS_LOG2);
+                const uint32_t hw = (uint32_t)g_uni((int)a.chain.hot[c_gid >> 5]);
+                c_hot = 0;
+                if ((hw >> (c_gid & 31)) & 1u) {
+                    const uint32_t ord = (uint32_t)g_uni((int)a.chain.hot_prefix[c_gid >> 5]) + (uint32_t)__builtin_popcount(hw & ((1u << (c_gid & 31)) - 1u));
+                    c_hot = (uint64_t)g_uni64((int64_t)a.chain.hot_masks[ord]);
+                }
+            }
+            const int p = (b << 6) + lane;
+            uint32_t kp, ks;
+            {
+                const int ie = p >> 4;
+                const uint32_t w0 = gi[ie], w1 = gi[ie + 1];
+                kp = __builtin_amdgcn_alignbit(w1, w0, 2u * (uint32_t)(p & 15)) & KM;
+            }
+            const bool haveL = p >= nk;
+            {
+                const int pl = haveL ? p - nk : 0;
+                const int il = pl >> 4;
+                const uint32_t w0 = gi[il], w1 = gi[il + 1];
+                ks = __builtin_amdgcn_alignbit(w1, w0, 2u * (uint32_t)(pl & 15)) & KM;
+                ks = haveL ? ks : kp;
+            }
+            const bool differ = kp != ks;
+            const bool actE = differ || !haveL, actL = differ && haveL;
+            const uint32_t shp = 16u * (kp & 1u), shs = 16u * (ks & 1u);
+            uint32_t wcp, wcs, wop = 0, wos = 0;
+            if constexpr (CGLOBAL) {
+                wcp = __hip_atomic_load(&C[kp >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wcs = __hip_atomic_load(&C[ks >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wcp), "+v"(wcs) : : "memory");
+                if (actE) wop = __hip_atomic_fetch_add(&C[kp >> 1], 1u << shp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (actL) wos = __hip_atomic_fetch_add(&C[ks >> 1], (uint32_t)(-(int32_t)(1u << shs)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wop), "+v"(wos) : : "memory");
+            } else {
+                wcp = C[kp >> 1];
+                wcs = C[ks >> 1];
+                if (actE) wop = atomicAdd(&C[kp >> 1], 1u << shp);
+                if (actL) wos = atomicSub(&C[ks >> 1], 1u << shs);
+            }
+            int32_t cP, cS;
+            {
+                const uint32_t cp = (wcp >> shp) & 0xFFFFu, cs = (wcs >> shs) & 0xFFFFu;
+                const uint32_t oldp = (wop >> shp) & 0xFFFFu, olds = (wos >> shs) & 0xFFFFu;
+                const bool all = nk < 64;
+                uint64_t pendE = __ballot(actE && (all || oldp != cp)), pendL = __ballot(actL && (all || olds != cs));
+                int32_t corrP = 0, corrS = 0;
+                if (pendE | pendL) {
+                    const uint64_t AE = __ballot(actE), AL = __ballot(actL);
+                    while ((pendE | pendL) != 0) {
+                        uint32_t x0;
+                        if (pendE) x0 = (uint32_t)__builtin_amdgcn_readlane((int)kp, __builtin_ctzll(pendE));
+                        else x0 = (uint32_t)__builtin_amdgcn_readlane((int)ks, __builtin_ctzll(pendL));
+                        const uint64_t eqP = __ballot(kp == x0), eqS = __ballot(ks == x0);
+                        const uint64_t ME = eqP & AE, ML = eqS & AL;
+                        const int32_t ne = (int32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(ME >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ME, 0u));
+                        const int32_t nl = (int32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(ML >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ML, 0u));
+                        corrP = kp == x0 ? ne - nl : corrP;
+                        corrS = ks == x0 ? ne - nl : corrS;
+                        pendE &= ~eqP;
+                        pendL &= ~eqS;
+                    }
+                }
+                cP = (int32_t)cp + corrP;
+                cS = (int32_t)cs + corrS;
+            }
+            // the reference's Float64 update of this lane's window (GenomeMiner.jl:70-72, same operation order)
+            const bool act = actL && p - nk + 1 < n_valid;            // the transition belongs to this stream
+            const uint64_t ACT = __ballot(act);
+            const double rr = g.R[kp], rl = g.R[ks];
+            double inc = 0.0;
+            if (act) {
+                double t = (double)(1 + cP);
+                t = t + rl;
+                t = t - rr;
+                t = t - (double)cS;
+                inc = g.SF * t;
+            }
+            if ((b << 6) < nk) {                                      // warm-up steps: the stream's first distance
+                const bool wu = p < nk;
+                wsum += O::sum(wu ? rr : 0.0);
+                pairs += Ops<int64_t>::sum(wu ? (int64_t)cP : 0);
+                if (nk - 1 < (b << 6) + 64) {
+                    d0 = g_unid(g.SF * 0.5 * ((g.sumR2 - 2.0 * wsum) + (double)((int64_t)nk + 2 * pairs)));
+                    if (lane == 0) a.D0out[(size_t)(kid - 1) * a.n_tiles + tile] = __double_as_longlong(d0);
+                }
+            }
+            const double carry_prev = carry;
+            const double rel = carry_prev + O::scan(inc, lane);       // sum of the increments since the stream's first window
+            const double val = d0 + rel;                              // this lane's distance after its transition (approximate)
+            carry = O::lane_of(rel, 63);
+            bool raw = ((c_hot >> (b & (KGMA_CHAIN_STEPS - 1))) & 1u) != 0;
+            if (!raw && ACT != 0) {
+                if (c_lo > c_hi && (b << 6) >= nk) chain_binade(d0 + carry_prev);
+                const uint64_t inl = __ballot(val >= c_lo && val <= c_hi);
+                raw = (inl | ~ACT) != ~(uint64_t)0;
+            }
+            if (raw) {
+                raw_step(b, inc);
+            } else if (ACT != 0) {
+                // RN(v + inc) for an even and an odd v of this binade, as hardware additions: anchors at the end of the binade the
+                // increment moves away from (2^e, or 2^(e+1) - 2 ulp), so that the sums stay inside
+                const uint64_t ib = (uint64_t)__double_as_longlong(inc);
+                const bool neg = (int32_t)(uint32_t)(ib >> 32) < 0;
+                const uint32_t x0hi = neg ? (c_XLhi | 0xFFFFFu) : c_XLhi;
+                const uint32_t x0lo = neg ? 0xFFFFFFFEu : 0u;
+                const uint64_t x0b = ((uint64_t)x0hi << 32) | x0lo;
+                const double R0 = __longlong_as_double((long long)x0b) + inc;
+                const double R1 = __longlong_as_double((long long)(x0b | 1u)) + inc;
+                const uint64_t r0b = (uint64_t)__double_as_longlong(R0), r1b = (uint64_t)__double_as_longlong(R1);
+                const int64_t av = (int64_t)(r0b - x0b);              // ulps added to an even value
+                const int32_t delta = (int32_t)((uint32_t)r1b - (uint32_t)r0b) - 1;   // ... to an odd value: av + delta (a tie: +-1)
+                c_acc += av;
+                const uint64_t T = __ballot(delta != 0);
+                uint64_t Om = __ballot((av & 1) != 0) & ~T;
+                if (T != 0) {
+                    uint64_t Trem = T;
+                    while (Trem != 0) {
+                        const int u = __builtin_ctzll(Trem);
+                        const uint64_t below = ((uint64_t)1 << u) - 1;
+                        c_P ^= (uint32_t)__builtin_popcountll(Om & below) & 1u;
+                        const int32_t du = __builtin_amdgcn_readlane(delta, u);
+                        const int32_t c0 = c_P ? du : 0;
+                        if (c_state & CS_SPLIT) { c_dA = (c_P ? 0 : du) - c0; c_state &= ~CS_SPLIT; }
+                        c_corr += c0;
+                        c_P = 0;
+                        Om &= ~below;
+                        Trem &= Trem - 1;
+                    }
+                }
+                c_P ^= (uint32_t)__builtin_popcountll(Om) & 1u;
+            }
+            if ((b & (KGMA_CHAIN_STEPS - 1)) == KGMA_CHAIN_STEPS - 1 || b == n_blocks - 1) close_run(b + 1, false);   // chunk end
+        }
+    }
+}
+
 // ---- geometry + launch ----------------------------------------------------------------------------------------------
 bool generic_counts_in_lds(int k) { return k <= 7; }                  // 2 * 4^k bytes per wave: 32 KiB at k = 7
 
@@ -396,6 +666,46 @@ int generic_slots_per_cu(int k, bool fp)
     if (cg) blocks = std::min(blocks, k >= 10 ? 2 : 4);
     if (blocks * nw > 32) blocks = 32 / nw;
     return nw * (blocks < 1 ? 1 : blocks);
+}
+
+static const void *generic_chain_fn(bool cglobal)
+{
+    return cglobal ? reinterpret_cast<const void *>(&gen_chain_kernel<true>) : reinterpret_cast<const void *>(&gen_chain_kernel<false>);
+}
+
+// streams resident per CU of the chain kernel
+int generic_chain_slots_per_cu(int k)
+{
+    const bool cg = !generic_counts_in_lds(k);
+    const int nw = generic_waves(k);
+    const size_t lds = cg ? 0 : (size_t)nw * ((size_t)2 << (2 * k));
+    const void *fn = generic_chain_fn(cg);
+    int blocks = 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64 * nw, lds) != hipSuccess || blocks < 1) {
+        (void)hipGetLastError();
+        blocks = 1;
+    }
+    if (cg) blocks = std::min(blocks, k >= 10 ? 2 : 4);
+    if (blocks * nw > 32) blocks = 32 / nw;
+    return nw * (blocks < 1 ? 1 : blocks);
+}
+
+hipError_t launch_generic_chain(const ScanArgs &a, const GenParams &g, hipStream_t st)
+{
+    if (a.n_tiles <= 0) return hipSuccess;
+    const bool cg = !generic_counts_in_lds(g.k);
+    const int nw = generic_waves(g.k);
+    if (nw < 1 || g.n_slots < nw || g.n_slots % nw != 0 || g.R == nullptr) return hipErrorInvalidConfiguration;
+    if (cg && g.ctab == nullptr) return hipErrorInvalidValue;
+    const size_t lds = cg ? 0 : (size_t)nw * ((size_t)2 << (2 * g.k));
+    const void *fn = generic_chain_fn(cg);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    ScanArgs a_copy = a;
+    GenParams g_copy = g;
+    void *args[2] = {&a_copy, &g_copy};
+    return hipLaunchKernel(fn, dim3((unsigned)(g.n_slots / nw)), dim3(64u * (unsigned)nw), args, lds, st);
 }
 
 hipError_t launch_generic(const ScanArgs &a, const GenParams &g, hipStream_t st)

@@ -328,3 +328,79 @@ def test_chain_values_first_window_only(ctx, alp_ref):
         assert v.tolist() == [orc.kmer_dist_kfv(seq[:alp_ref["ws"]], alp_ref["RV"], 6)]
     finally:
         g.free()
+
+
+@pytest.mark.parametrize("k", [3, 4, 6, 7, 8, 9])
+def test_generic_chain_kernel_every_window(ctx, data_dir, genes, k, monkeypatch):
+    """gen_chain_kernel (kgma_generic.hip): the chain kernel for what stream8_kernel<..., CHAIN> does not serve -- any k, any window,
+    any KFV.  Forced here also at k = 6, 7 (KGMA_CHAIN_GENERIC=1): every window's running value against the reference-order oracle,
+    bit for bit, through homopolymer / N / repeat stretches, several stream lengths."""
+    from kmergma_amd import refprep
+    monkeypatch.setenv("KGMA_CHAIN_GENERIC", "1")
+    tf = os.path.join(data_dir, "Alp_V_ref.fasta")
+    RV, W, cons, (S, N) = refprep.gen_ref_ws_cons(tf, k, return_int=True)
+    rng = np.random.default_rng(400 + k)
+    seqs = [_rich_seq(rng, 70_000, genes), random_dna(rng, 5000), b"A" * 1000 + random_dna(rng, 400)]
+    ctx.set_refs(k, [RV], [W], [30.0], [N])
+    for stream in (None, "1024"):
+        if stream:
+            monkeypatch.setenv("KGMA_CHAIN_STREAM", stream)
+        g = ctx.genome_from_host(seqs)
+        try:
+            for c, seq in enumerate(seqs):
+                chain = _oracle_chain(seq, RV, k, W)
+                v = g.chain_values(c, 1, [(1, len(seq) - W + 1)])
+                assert np.array_equal(v, chain), f"k={k} record {c}: first mismatch at window {int(np.argmax(v != chain)) + 1}"
+                assert ctx.stats()["chain_device_pairs"] == 1
+            # sparse requests: most chunks regular
+            seq = seqs[0]
+            chain = _oracle_chain(seq, RV, k, W)
+            iv = [(5, 9), (20_000, 20_000), (41_234, 41_300), (len(seq) - W + 1, len(seq) - W + 1)]
+            v = g.chain_values(0, 1, iv)
+            want = np.concatenate([chain[a - 1:b] for a, b in iv])
+            assert np.array_equal(v, want)
+        finally:
+            g.free()
+
+
+def test_generic_chain_kernel_float_kfv_and_wide_window(ctx, alp_ref, genes):
+    """A general Float64 KFV (no S/N form for stream8's chain) and a window of 2600 residues at k = 4: both chains run in the generic
+    chain kernel, not on host threads; chain-mode scans report every pair as walked on the device."""
+    from kmergma_amd import refprep
+    from kmergma_amd.fasta import Record
+    rng = np.random.default_rng(77)
+    RV = np.asarray(alp_ref["RV"]) * (1.0 / np.sqrt(2.0)) + np.roll(alp_ref["RV"], 1) * (1.0 - 1.0 / np.sqrt(2.0))
+    W = alp_ref["ws"]
+    seq = _rich_seq(rng, 90_000, genes)
+    ctx.set_refs(6, [RV], [W], [30.0], None)
+    g = ctx.genome_from_host([seq])
+    try:
+        chain = _oracle_chain(seq, RV, 6, W)
+        v = g.chain_values(0, 1, [(1, len(seq) - W + 1)])
+        assert np.array_equal(v, chain), f"first mismatch at window {int(np.argmax(v != chain)) + 1}"
+        thr = float(np.sort(chain[1:])[len(chain) // 100])         # a window's own value: that window sits in the threshold band
+        ctx.set_thresholds([thr])
+        ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_CHAIN_REPLAY, None)
+        st = ctx.stats()
+        ohits, _ = orc.single_scan([seq], RV, 6, W, thr, 50)
+        assert [hit_key(h) for h in ctx.hits()] == [hit_key(h) for h in ohits]
+        assert [h["dist"] for h in ctx.hits()] == [h["dist"] for h in ohits]
+        assert st["n_chain_pairs"] == 1 and st["chain_device_pairs"] == 1
+    finally:
+        g.free()
+    k, L = 4, 2600
+    base = random_dna(rng, L)
+    refs = [Record(f"g{i}", mutate(rng, base, 0.03)) for i in range(6)]
+    RV4, W4, cons, (S, N) = refprep.gen_ref_ws_cons(refs, k, return_int=True)
+    a = bytearray(random_dna(rng, 40_000))
+    a[3000:3000 + L + 200] = b"C" * (L + 200)
+    a[20_000:20_000 + L] = mutate(rng, base, 0.04)
+    seq = bytes(a)
+    ctx.set_refs(k, [RV4], [W4], [30.0], [N])
+    g = ctx.genome_from_host([seq])
+    try:
+        chain = _oracle_chain(seq, RV4, k, W4)
+        v = g.chain_values(0, 1, [(1, len(seq) - W4 + 1)])
+        assert np.array_equal(v, chain), f"first mismatch at window {int(np.argmax(v != chain)) + 1}"
+    finally:
+        g.free()
