@@ -72,9 +72,11 @@ enum {
                                        scan kernel forms every window's increment in the reference's
                                        operation order; the host adds one integer per 4096-window chunk and
                                        the raw increments where the value may change binade or is wanted:
-                                       kgma_device.h) for k = 5 ... 7 (windows of up to 65535 k-mers) and KFVs whose
-                                       entries are S * (1/N) or S / N bit for bit; otherwise on host threads
-                                       (about 1.8 ns per window).  kgma_stats.chain_* report both.  No dip is
+                                       kgma_device.h): stream8_kernel's chain variant for k = 5 ... 7 and KFVs whose entries
+                                       are S * (1/N) or S / N bit for bit, the generic chain kernel (kgma_generic.hip: it
+                                       forms the increments from the caller's own Float64 table) for every other k, window
+                                       and KFV; host threads (about 1.8 ns per window) only when a walk fails a check or
+                                       the device buffers do not fit.  kgma_stats.chain_* report both.  No dip is
                                        left KGMA_HIT_TIE / KGMA_HIT_AT_THRESHOLD.  CONVENTION: the first
                                        window's sqeuclidean is summed left to right; Julia leaves the order of
                                        that @simd reduction to the machine, so "identical to the reference"
@@ -190,7 +192,7 @@ void kgma_destroy(kgma_ctx *ctx);
  *     reference's running value; the decisions rounding noise could take either way in the reference -- a window within a
  *     relative 2^-30 of thr, two minima within 2^-30 of each other -- are flagged exactly like the integer form's exact ties
  *     (KGMA_HIT_AT_THRESHOLD / KGMA_HIT_TIE), and KGMA_F_CHAIN_REPLAY decides them from the reference's own running value
- *     (replayed from the caller's table, bit for bit).  kgma_hit.D / kgma_dip.D_* are then round(d * 2kN^2) with N a power of
+ *     (replayed on the device from the caller's table, bit for bit).  kgma_hit.D / kgma_dip.D_* are then round(d * 2kN^2) with N a power of
  *     two (kgma_kfv_scale), kgma_hit.dist the Float64 distance.
  * Requires 2 <= k <= 10, k < min(windowsizes) (src/API.jl:70,177) and at most 65535 k-mers per window (windowsize - k + 1:
  * the window counts are 16-bit; the reference itself has no bound, src/ReferenceGeneration.jl:35-40); KGMA_E_UNSUPPORTED
@@ -304,8 +306,9 @@ int kgma_host_chain_values(const uint8_t *seq, int64_t len, const double *ref, i
  * (1-based window starts, sorted, disjoint) -- kgma_host_chain_values computed by the chain kernel on the resident genome:
  * what KGMA_F_CHAIN_REPLAY runs for its (record, KFV) pairs.  Window 1's value is the first window's
  * ScaleFactor * 0.5 * sqeuclidean (summed left to right on the host); every later value is bit for bit what a sequential
- * IEEE-754 evaluation of src/GenomeMiner.jl:70-72 gives.  KGMA_E_UNSUPPORTED when the chain kernel does not serve the KFV
- * (k = 5, 6 or 7; KFV bit-identical to S * (1/N) or S / N).  Two-call pattern via cap / *n_out. */
+ * IEEE-754 evaluation of src/GenomeMiner.jl:70-72 gives.  Served for every k, window and KFV (by one of the two chain kernels);
+ * KGMA_E_UNSUPPORTED only when the device chain is switched off (KGMA_CHAIN=host) or its walk failed a check.  Two-call pattern
+ * via cap / *n_out. */
 int kgma_chain_values(kgma_ctx *ctx, const kgma_genome *genome, int64_t contig, int32_t kfv, const int64_t *win_lo,
                       const int64_t *win_hi, int64_t n_intervals, double *out, int64_t cap, int64_t *n_out);
 
