@@ -62,19 +62,19 @@ def pmc_profile(kernel_name, bases):
     of MI355X_MICROARCH.md, + WRITE_SIZE x 1 KiB) and the VALU / LDS figures that actually bind the
     kernel.  Refused (None) unless the summary carries the hash of the current device sources, the same
     kernel and the same number of bases per launch."""
-    path = os.path.join(ROOT, "profiles", "r03_scan_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r04_scan_pmc_summary.json")
     try:
         with open(path) as f:
             prof = json.load(f)
         if prof.get("source_hash") != kernel_source_hash():
-            return None, "stale: profiles/r03_scan_pmc_summary.json was taken on other device sources", None
+            return None, "stale: profiles/r04_scan_pmc_summary.json was taken on other device sources", None
         if kernel_name.split("<")[0] not in prof.get("kernel", "") or int(prof.get("bases_per_launch", -1)) != int(bases):
-            return None, "profiles/r03_scan_pmc_summary.json is for another kernel / workload", None
+            return None, "profiles/r04_scan_pmc_summary.json is for another kernel / workload", None
         d = prof["derived"]
         extra = {k: d[k] for k in ("valu_instructions_per_cycle_per_simd", "valu_wave_instructions_per_64_windows",
                                    "lds_instructions_per_64_windows", "lds_active_fraction_of_kernel",
                                    "lds_bank_conflict_fraction_of_lds_cycles", "wait_any_fraction_of_wave_cycles") if k in d}
-        return round(d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]), "profiles/r03_scan_pmc_summary.json", extra
+        return round(d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]), "profiles/r04_scan_pmc_summary.json", extra
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None, None, None
 

@@ -46,6 +46,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mb", type=float, default=400.0)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--out", default="")
     args = ap.parse_args()
     n = int(args.mb * 1e6)
     ctx = _lib.Context(0)
@@ -80,18 +81,21 @@ def main():
         run("stream8 C16 / 64-bit carries", 6, W, chain=True)
     run("stream8 C16 / 64-bit carries", 5, 3000, chain=True)
     run("stream8 C16 / 64-bit carries", 7, 3000, chain=True)
-    run("generic int (forced)", 6, 289, env={"KGMA_KERNEL": "generic"})
-    run("generic Float64", 6, 289, fp=True)
-    run("generic Float64", 6, 3000, fp=True)
-    run("generic Float64", 7, 289, fp=True)
-    run("generic int", 4, 3000)
-    run("bit-sliced", 8, 289)
+    run("generic int (forced)", 6, 289, env={"KGMA_KERNEL": "generic", "KGMA_CHAIN_GENERIC": "1"}, chain=True)
+    run("generic Float64", 6, 289, fp=True, chain=True)
+    run("generic Float64", 6, 3000, fp=True, chain=True)
+    run("generic Float64", 7, 289, fp=True, chain=True)
+    run("generic int", 4, 3000, chain=True)
+    run("bit-sliced (scan) / generic chain", 8, 289, chain=True)
     run("generic int (forced)", 8, 289, env={"KGMA_KERNEL": "generic"})
-    run("generic int", 8, 3000)
+    run("generic int", 8, 3000, chain=True)
     run("generic Float64", 8, 289, fp=True)
     run("generic int", 10, 3000)
     g.free()
     ctx.close()
+    if args.out:
+        with open(args.out, "w") as fh:
+            json.dump({"tool": "tools/wide_time.py", "bases": n, "rows": rows}, fh, indent=1)
 
 
 if __name__ == "__main__":
