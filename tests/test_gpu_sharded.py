@@ -133,6 +133,96 @@ def test_scan_sharded_ranks(world):
         assert p.exitcode == 0
 
 
+def _worker_new_paths(rank, world, port, q):
+    """The round-4 paths through the sharded scan: (1) windows of 2600 residues (16-bit counter form with 64-bit carries, its chain
+    variant exported per slice), (2) a general Float64 KFV (generic kernel, generic chain kernel exported per slice)."""
+    try:
+        for p in (ROOT, os.path.join(ROOT, "kmergma.jl_amd")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import torch.distributed as dist
+        from kmergma_amd import _lib, parallel, refprep, workloads
+        from kmergma_amd.fasta import Record
+        from oracle import oracle as orc
+        from tests.helpers import hit_key, make_genome, mutate, random_dna
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        ctx = _lib.Context(0)
+        ok, n_hits = True, 0
+        rng = np.random.default_rng(11)                     # same inputs on every rank
+        # ---- (1) wide windows
+        k, W = 6, 2600
+        base = random_dna(rng, W)
+        refs = [Record(f"g{i}", mutate(rng, base, 0.03)) for i in range(7)]
+        RV, ws, cons, (S, N) = refprep.gen_ref_ws_cons(refs, k, return_int=True)
+        a = bytearray(random_dna(rng, 300_000))
+        for pos in (20_000, 20_000 + W + 40, 150_000, 230_000):        # two copies side by side (a suppressed dip), copies near the cuts
+            a[pos:pos + W] = mutate(rng, base, 0.02)
+        contigs = [bytes(a), random_dna(rng, W - 1), mutate(rng, base, 0.05) + random_dna(rng, 9000)]
+        thr = float(np.round(0.5 * orc.kmer_dist_kfv(random_dna(rng, W), RV, k)))      # an integer threshold: on the distance lattice
+        ctx.set_refs(k, [RV], [ws], [thr], [N])
+        for flags in (_lib.F_NO_TIE_RESOLVE, _lib.F_CHAIN_REPLAY):
+            hits = parallel.scan_sharded(ctx, contigs, _lib.MODE_SINGLE, buff=50, genome_pos=0, flags=flags, min_windows=2048)
+            if rank == 0:
+                g = ctx.genome_from_host(contigs)
+                ctx.scan(g, _lib.MODE_SINGLE, 50, 0, flags, None)
+                ref = ctx.hits()
+                g.free()
+                same = [hit_key(h) for h in hits] == [hit_key(h) for h in ref] and [h["D"] for h in hits] == [h["D"] for h in ref] and len(ref) >= 2
+                if flags == _lib.F_CHAIN_REPLAY:
+                    ohits, _ = orc.single_scan(contigs, RV, k, ws, thr, 50)
+                    same = same and [hit_key(h) for h in hits] == [hit_key(h) for h in ohits] and [h["dist"] for h in hits] == [h["dist"] for h in ref]
+                if not same:
+                    print("sharded scan, wide windows, flags", flags, ": differs", len(hits), len(ref), file=sys.stderr, flush=True)
+                ok = ok and same
+                n_hits += len(hits)
+        # ---- (2) a general Float64 KFV
+        fx = workloads.fixture_refs(os.path.join(ROOT, "tests", "data"), 6)
+        RVf = np.asarray(fx["RV"]) * (1.0 / np.sqrt(2.0)) + np.roll(fx["RV"], 1) * (1.0 - 1.0 / np.sqrt(2.0))
+        contigs, _ = make_genome(rng, [400_000, 100, 90_000], fx["genes"], n_plants_per_mb=150)
+        _, od = orc.single_scan(contigs, RVf, 6, fx["ws"], 1.0, 50, return_dists=True)
+        thr = float(np.sort(od)[len(od) // 100])                        # a window's own value: in the threshold band
+        ctx.set_refs(6, [RVf], [fx["ws"]], [thr], None)
+        hits = parallel.scan_sharded(ctx, contigs, _lib.MODE_SINGLE, buff=50, genome_pos=0, flags=_lib.F_CHAIN_REPLAY, min_windows=2048)
+        if rank == 0:
+            ohits, _ = orc.single_scan(contigs, RVf, 6, fx["ws"], thr, 50)
+            same = [hit_key(h) for h in hits] == [hit_key(h) for h in ohits] and len(ohits) > 10
+            same = same and all(a["dist"] == b["dist"] for a, b in zip(hits, ohits) if a["flags"] & _lib.HIT_CHAIN)
+            same = same and any(a["flags"] & _lib.HIT_CHAIN for a in hits)
+            if not same:
+                print("sharded scan, Float64 KFV, chain mode: differs", len(hits), len(ohits), file=sys.stderr, flush=True)
+            ok = ok and same
+            n_hits += len(hits)
+            q.put((bool(ok), n_hits))
+        dist.barrier()
+        ctx.close()
+        dist.destroy_process_group()
+    except BaseException:
+        if rank == 0:
+            q.put((False, -1))
+        raise
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_scan_sharded_wide_windows_and_float_kfv(world):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_new_paths, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    same, n = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    assert same and n > 10
+    for p in procs:
+        assert p.exitcode == 0
+
+
 def _worker_rccl(port, q):
     """One rank, backend "nccl" (= RCCL): the device-side path of HitGatherer (pinned staging, its own
     stream, all_gather_into_tensor, start/finish pipelining) on the box's single GPU."""
