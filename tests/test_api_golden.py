@@ -163,3 +163,19 @@ def test_cluster_mode_alignment_on_device_zero_host_calls(golden, paths):
         assert nh == 0 and nd > 0
         assert [r.description for r in a[0]] == [r.description for r in b[0]] and len(a[0]) > 5
         assert a[1] == b[1] and [tuple(x) for x in a[2]] == [tuple(x) for x in b[2]]
+
+
+def test_ac_gma_testing_general_float64_refvec(paths, alp_ref):
+    """refVec::Vector{Float64} may be any vector (src/GenomeMiner.jl:6): a smoothed profile through the operator mirror -- the
+    records' headers (distance rounded to two digits, MatchPos, GenomePos, Len) equal the ones the reference-order oracle gives."""
+    import numpy as np
+    from kmergma_amd import headers
+    from oracle import oracle as orc
+    RV = (np.asarray(alp_ref["RV"]) + 0.01 / np.pi) / (1.0 + 0.01 / np.pi)
+    recs = fasta.read_fasta(paths["genome"])
+    res = []
+    api.ac_gma_testing(genome_path=paths["genome"], refVec=RV, consensus_refseq=alp_ref["cons"], windowsize=alp_ref["ws"], thr=30,
+                       do_align=False, resultVec=res)
+    ohits, _ = orc.single_scan([r.sequence for r in recs], RV, 6, alp_ref["ws"], 30.0, 50)
+    want = [headers.single_header(recs[h["contig"]].identifier, h["dist"], h["lo"], h["hi"], h["genome_pos"]) for h in ohits]
+    assert [r.description for r in res] == want and len(want) >= 5
