@@ -28,7 +28,7 @@ EXPORTS = [
     "kgma_genome_fetch", "kgma_genome_fetch_batch", "kgma_genome_num_contigs", "kgma_genome_contig_len", "kgma_genome_total_bases",
     "kgma_genome_free", "kgma_genome_repack", "kgma_genome_poke", "kgma_scan", "kgma_scan_device", "kgma_get_hits",
     "kgma_get_dips", "kgma_get_first_window", "kgma_get_dists", "kgma_get_stats", "kgma_stream",
-    "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_header", "kgma_scan_kernel_name",
+    "kgma_host_semiglobal_cigar", "kgma_genome_from_fasta", "kgma_genome_from_fasta_file", "kgma_genome_header", "kgma_scan_kernel_name",
     "kgma_resolve_ties_local", "kgma_get_dip_last_min", "kgma_replay_dips", "kgma_align_hits_device", "kgma_repack_scan_hits",
     "kgma_kmer_count_batch", "kgma_kmer_dist_batch", "kgma_step_begin", "kgma_step_end", "kgma_set_reserved_cus",
     "kgma_scan_aligned", "kgma_get_alignments", "kgma_set_residue_source", "kgma_host_chain_values",
@@ -119,6 +119,7 @@ def load():
     L.kgma_set_thresholds.argtypes = [vp, P(dbl)]
     L.kgma_genome_from_host.argtypes = [vp, P(C.c_char_p), P(i64), i64, P(vp)]
     L.kgma_genome_from_fasta.argtypes = [vp, vp, i64, P(vp)]
+    L.kgma_genome_from_fasta_file.argtypes = [vp, C.c_char_p, P(vp)]
     L.kgma_genome_header.argtypes = [vp, i64, P(C.c_char_p), P(i64)]
     L.kgma_genome_synthetic.argtypes = [vp, P(i64), i64, u64, C.c_char_p, i64, P(i64), P(i64), i64, P(vp)]
     L.kgma_genome_fetch.argtypes = [vp, vp, i64, i64, i64, C.c_char_p]
@@ -370,12 +371,13 @@ class Context:
         return Genome(self, h)
 
     def genome_from_fasta(self, source) -> Genome:
-        """Device-side FASTA ingest. `source` is a path (memory-mapped) or a bytes object."""
-        if isinstance(source, (bytes, bytearray)):
-            buf = np.frombuffer(bytes(source), dtype=np.uint8)
-        else:
-            buf = np.memmap(source, dtype=np.uint8, mode="r") if os.path.getsize(source) else np.zeros(0, np.uint8)
+        """Device-side FASTA ingest. `source` is a path (kgma_genome_from_fasta_file: read straight into the pinned staging
+        buffers) or a bytes object."""
         h = C.c_void_p()
+        if not isinstance(source, (bytes, bytearray)):
+            self._check(load().kgma_genome_from_fasta_file(self._h, os.fsencode(source), C.byref(h)))
+            return Genome(self, h)
+        buf = np.frombuffer(bytes(source), dtype=np.uint8)
         ptr = buf.ctypes.data_as(C.c_void_p) if buf.size else None
         self._check(load().kgma_genome_from_fasta(self._h, ptr, int(buf.size), C.byref(h)))
         return Genome(self, h)

@@ -44,9 +44,9 @@ def main():
     try:
         for name, fn, kw in (("findGenes", api.findGenes, dict(KmerDistThr=30)),
                              ("findGenes_cluster_mode", api.findGenes_cluster_mode, dict(KmerDistThrs=[37, 33, 38, 34, 28, 30]))):
-            for rep in range(2):
+            for rep in range(5):
                 t0 = time.perf_counter()
-                if args.profile and rep == 1:
+                if args.profile and rep == 4:
                     pr = cProfile.Profile()
                     out = pr.runcall(fn, genome_path=path, ref_path=ref_path, verbose=False, **kw)
                 else:
@@ -55,7 +55,7 @@ def main():
                 st = api.default_context().stats()
                 print("%s: %d Mb file -> %d hit records in %.1f ms (scan kernels %.2f ms, chain %.1f ms, replay %.2f ms)" % (
                     name, args.mb, len(out[0]), dt * 1e3, st["scan_ms"], st["chain_ms"], st["replay_ms"]), flush=True)
-                if args.profile and rep == 1:
+                if args.profile and rep == 4:
                     pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
     finally:
         os.unlink(path)
