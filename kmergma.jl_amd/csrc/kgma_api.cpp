@@ -475,7 +475,7 @@ std::vector<Group> make_groups(const kgma_ctx *ctx, int mode, bool s8 = false)
         }
         if (!placed) gs.push_back(Group{W, {j}});
     }
-    // Two neighbouring launches with FIVE KFVs between them (k = 7: EIGHT), windows within two k-mers of each other (k <= 6: every
+    // Two neighbouring launches with FIVE KFVs between them (k = 6: also SIX; k = 7: EIGHT), windows within two k-mers of each other (k <= 6: every
     // S below 256): one launch of the five- / eight-KFV variant (stream8_wide_applies; BASELINE configs[3] is {288, 288, 288, 289} +
     // {290}, configs[4] {288 x 4} + {289 x 3, 290})
     if (s8)
@@ -483,7 +483,7 @@ std::vector<Group> make_groups(const kgma_ctx *ctx, int mode, bool s8 = false)
             Group &g0 = gs[i];
             const Group &g1 = gs[i + 1];
             const size_t total = g0.kfvs.size() + g1.kfvs.size();
-            if (total != (ctx->k >= 7 ? 8u : 5u)) continue;
+            if (!(ctx->k >= 7 ? total == 8u : (total == 5u || (total == 6u && ctx->k == 6)))) continue;
             bool all32 = true;
             for (const Group *gp : {static_cast<const Group *>(&g0), &g1})
                 for (int u : gp->kfvs) all32 = all32 && ctx->kfv[(size_t)u].fits32;

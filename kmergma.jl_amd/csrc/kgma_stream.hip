@@ -533,7 +533,7 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 #endif
 
 template <int K, bool S16, int NKFV, int ND = 0, bool CHAIN = false, int ND2 = 0, bool C16 = false>
-__global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN_WAVES : 8) : (CHAIN ? 4 : (NKFV <= 5 ? 6 : 4))))) void stream8_kernel(ScanArgs a, GroupParams gp)
+__global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ? KGMA_CHAIN_WAVES : 8) : (CHAIN ? 4 : (NKFV <= 5 ? 6 : (NKFV == 6 ? 5 : 4)))))) void stream8_kernel(ScanArgs a, GroupParams gp)
 {
     // C16: 16-BIT counters (two per dword) for windows of 384 ... 2031 k-mers -- k <= 6, up to four KFVs of one window size; a
     // wave's table is 2 * 4^k bytes (16 waves per CU at k = 6 with one KFV), no count can leave its field, so the heavy-k-mer
@@ -567,12 +567,14 @@ __global__ __launch_bounds__(1024, K >= 7 ? 2 : (C16 ? 4 : (NKFV == 1 ? (CHAIN ?
     // The KFVs of a launch are sorted by window size: NKFV - ND - ND2 of n k-mers (the count table's), then ND of n + 1,
     // then ND2 of n + 2 (five-KFV variant only).
     constexpr bool DERIVE = ND + ND2 > 0;
-    static_assert(!DERIVE || (((NKFV >= 2 && NKFV <= 5) || (NKFV == 8 && K >= 7)) && ND + ND2 < NKFV && S16),
-                  "derived windows: 2-5 KFVs (k = 7: also 8, launched full) with 16-bit (or 8-bit) S tables");
-    static_assert(ND2 == 0 || NKFV == 5 || NKFV == 8, "windows two k-mers longer: the five- and eight-KFV variants");
-    // NKFV = 5: S rows of eight BYTES (every S of the launch < 256, checked on the host): the rows of five KFVs take the
-    // 32 KiB that four int16 KFVs take, so the launch keeps the residency of a four-KFV launch
-    constexpr bool SBYTE = NKFV == 5;
+    static_assert(!DERIVE || (((NKFV >= 2 && NKFV <= 6) || (NKFV == 8 && K >= 7)) && ND + ND2 < NKFV && S16),
+                  "derived windows: 2-6 KFVs (k = 7: also 8, launched full) with 16-bit (or 8-bit) S tables");
+    static_assert(ND2 == 0 || NKFV == 5 || NKFV == 6 || NKFV == 8, "windows two k-mers longer: the five-, six- and eight-KFV variants");
+    // NKFV = 5, 6: S rows of eight BYTES (every S of the launch < 256, checked on the host): the rows of five or six KFVs take the
+    // 32 KiB that four int16 KFVs take, so the launch keeps (nearly) the residency of a four-KFV launch.  Six KFVs (round 4): the
+    // shape findGenes_cluster_mode produces by default -- cluster_ref_API's five clusters plus the average KFV
+    // (src/ReferenceGeneration.jl:80,127-132) -- in ONE pass over the genome instead of two launches of four and two.
+    constexpr bool SBYTE = NKFV == 5 || NKFV == 6;
     static_assert(!SBYTE || (S16 && K <= 6), "byte rows: k <= 6");
     // k = 7: a wave's table is 16 KiB, so the LDS holds 10 of them and nothing else; the S tables stay in global memory,
     // interleaved per k-mer ([k-mer][NKFV] int16: ONE gather per k-mer serves every KFV of the launch; 32-256 KiB, L2-resident)
@@ -1560,7 +1562,7 @@ static size_t stream8_lds(int k, bool s16, int nkfv, int nw, bool c16 = false)
         return (nkfv == 1 ? NB * (s16 ? 2 : 4) : NB * 2 * slots16) + (size_t)nw * (NB * 2 + (nkfv > 1 ? (size_t)nkfv * ST_WORDS * 4 : 0));
     }
     const size_t slots = s16 && nkfv >= 2 ? (nkfv >= 5 ? 8 : nkfv >= 3 ? 4 : 2) : (size_t)nkfv;   // int16 tables of several KFVs: rows of 2 / 4 / 8 slots
-    const size_t tabs = k >= 7 ? 0 : nkfv == 5 ? NB * 8 : NB * (s16 ? 2 : 4) * slots;   // k = 7: the S tables stay in global memory; 5: rows of 8 bytes
+    const size_t tabs = k >= 7 ? 0 : (nkfv == 5 || nkfv == 6) ? NB * 8 : NB * (s16 ? 2 : 4) * slots;   // k = 7: the S tables stay in global memory; 5, 6: rows of 8 bytes
     return tabs + (size_t)nw * (NB + (nkfv > 1 && k < 7 ? (size_t)nkfv * ST_WORDS * 4 : 0));   // (k = 7: the per-KFV state is in global memory)
 }
 
@@ -1597,6 +1599,8 @@ bool stream8_wide_applies(int k, int nk_min, int nk_max, int n_kfv, int64_t n_re
     if (nk_max != nk_min && !stream8_derive_env_on()) return false;
     if ((k == 5 || k == 6) && n_kfv == 5 && u8)
         return stream8_applies(k, nk_max, n_kfv, n_ref, true) && stream8_fn_of(k, true, 5, n_plus1, n_plus2) != nullptr;
+    if (k == 6 && n_kfv == 6 && u8)                                    // (six KFVs: k = 6 only)
+        return stream8_applies(k, nk_max, n_kfv, n_ref, true) && stream8_fn_of(k, true, 6, n_plus1, n_plus2) != nullptr;
     if (k == 7 && n_kfv == 8 && s16 && n_plus1 + n_plus2 > 0)         // (one window size: the plain eight-KFV variant)
         return stream8_applies(k, nk_max, n_kfv, n_ref, true) && stream8_fn_of(k, true, 8, n_plus1, n_plus2) != nullptr;
     return false;
@@ -1610,6 +1614,18 @@ static const void *stream8_fn_wide(int nd, int nd2)
     KGMA_WIDE(0, 0) KGMA_WIDE(1, 0) KGMA_WIDE(2, 0) KGMA_WIDE(3, 0) KGMA_WIDE(4, 0)
     KGMA_WIDE(0, 1) KGMA_WIDE(1, 1) KGMA_WIDE(2, 1) KGMA_WIDE(3, 1)
     KGMA_WIDE(0, 2) KGMA_WIDE(1, 2) KGMA_WIDE(2, 2)
+    default: return nullptr;
+    }
+#undef KGMA_WIDE
+}
+
+static const void *stream8_fn_wide6(int nd, int nd2)                  // k = 6, six KFVs (the patterns that are instantiated; others keep two launches)
+{
+#define KGMA_WIDE(D1, D2) case (D2) * 8 + (D1): return reinterpret_cast<const void *>(&stream8_kernel<6, true, 6, D1, false, D2>);
+    switch (nd2 * 8 + nd) {
+    KGMA_WIDE(0, 0) KGMA_WIDE(1, 0) KGMA_WIDE(2, 0) KGMA_WIDE(3, 0)
+    KGMA_WIDE(1, 1) KGMA_WIDE(2, 1) KGMA_WIDE(3, 1)
+    KGMA_WIDE(2, 2)
     default: return nullptr;
     }
 #undef KGMA_WIDE
@@ -1688,6 +1704,7 @@ static const void *stream8_fn_c16(int k, bool s16, bool chain, int nkfv = 1)
 static const void *stream8_fn_of(int k, bool s16, int nkfv, int nd = 0, int nd2 = 0)       // nd / nd2: KFVs with a window one / two k-mers longer
 {
     if (nkfv == 5) return k == 5 ? stream8_fn_wide<5>(nd, nd2) : k == 6 ? stream8_fn_wide<6>(nd, nd2) : nullptr;
+    if (nkfv == 6) return k == 6 ? stream8_fn_wide6(nd, nd2) : nullptr;   // (six KFVs only arrive here for the one-launch variant)
     if (nkfv == 8 && nd + nd2 > 0) return k == 7 ? stream8_fn_wide8(nd, nd2) : nullptr;
     if (nd > 0) return k == 5 ? stream8_fn_derive<5>(nkfv, nd) : k == 7 ? stream8_fn_derive<7>(nkfv, nd) : stream8_fn_derive<6>(nkfv, nd);
     if (k == 5) return s16 ? stream8_fn_k<5, true>(nkfv) : stream8_fn_k<5, false>(nkfv);

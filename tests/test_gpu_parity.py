@@ -879,6 +879,9 @@ def test_stream8_derived_windows(ctx, k, lens, monkeypatch):
     (7, [288, 288, 288, 288, 289, 289, 289, 290]),   # BASELINE configs[4]: eight KFVs at k = 7, one launch instead of {288 x 4} + {289 x 3, 290}
     (7, [134, 134, 134, 135, 135, 135, 135, 136]), (7, [133, 133, 133, 133, 133, 133, 133, 135]), (7, [200, 200, 200, 200, 200, 200, 201, 201]),
     (7, [261, 261, 261, 261, 262, 262, 262, 262]),   # 255 k-mers
+    # six KFVs at k = 6 (round 4): the shape findGenes_cluster_mode produces by default (five clusters + the average KFV)
+    (6, [288, 288, 288, 289, 289, 290]), (6, [288] * 6), (6, [288, 288, 289, 289, 290, 290]), (6, [260, 260, 260, 260, 261, 262]),
+    (6, [261, 261, 261, 262, 262, 262]), (6, [100, 100, 100, 100, 101, 102]),
 ])
 def test_stream8_five_kfv_launch(ctx, k, lens, monkeypatch):
     """Five KFVs (k = 7: eight) whose windows are within two k-mers of each other (k <= 6: every S below 256): ONE launch of

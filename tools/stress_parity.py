@@ -52,7 +52,7 @@ def one_case(ctx, rng, case):
     if WIDE and rng.random() < 0.6:
         base_len = int(rng.choice([rng.integers(2031 + k, 2100), rng.integers(2100, 9000)]))
     as_float = FLOAT > 0 and rng.random() < FLOAT
-    m = int(rng.choice([1, 1, 2, 3, 5, 8]))
+    m = int(rng.choice([1, 1, 2, 3, 5, 6, 8]))
     # reference sets: m clusters of mutated copies of related genes, lengths spread by up to +-6
     root = rdna(rng, base_len + 8)
     KFVs, ws, Ss, Ns, genes = [], [], [], [], []
