@@ -69,15 +69,12 @@ mutable struct DeviceGenome
     h::Ptr{Cvoid}
 end
 
-# FASTA file -> device (replaces `open(FASTA.Reader, genome_path)` + getSeq, src/GenomeMiner.jl:31-35): the mapped
-# file is handed to the library, which strips the line breaks and encodes the residues on the GPU
+# FASTA file -> device (replaces `open(FASTA.Reader, genome_path)` + getSeq, src/GenomeMiner.jl:31-35): the library reads
+# the file straight into its pinned staging buffers (kgma_genome_from_fasta_file), strips the line breaks and encodes the
+# residues on the GPU
 function genome_from_fasta(ctx::Context, genome_path::String)
-    text = filesize(genome_path) == 0 ? UInt8[] : Mmap.mmap(genome_path)
     g = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve text begin
-        check(ctx, ccall((:kgma_genome_from_fasta, libkgma), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int64, Ref{Ptr{Cvoid}}),
-                         ctx.h, text, length(text), g))
-    end
+    check(ctx, ccall((:kgma_genome_from_fasta_file, libkgma), Cint, (Ptr{Cvoid}, Cstring, Ref{Ptr{Cvoid}}), ctx.h, genome_path, g))
     return DeviceGenome(ctx, g[])
 end
 
