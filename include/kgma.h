@@ -355,6 +355,10 @@ int kgma_set_chain_source(kgma_ctx *ctx, kgma_chain_fn fn, void *user);
 /* 2 k N^2 of KFV `kfv` (1-based): exact distance = D / scale (what kgma_host_chain_walk checks the chain against); N as given
  * to or inferred by kgma_set_refs. */
 int kgma_kfv_scale(kgma_ctx *ctx, int32_t kfv, double *scale, int64_t *n_refs);
+/* 1 if KFV `kfv` (1-based) is scanned as a general Float64 vector (kgma_set_refs: not S/n_refs), 0 for the exact-integer form.
+ * Callers that join dips themselves (parallel.merge_payloads across slice boundaries) compare the D values of a Float64 KFV
+ * with the library's near-tie tolerance |a - b| <= max(|a|, |b|) * 2^-30 + 2 instead of ==. */
+int kgma_kfv_is_float(kgma_ctx *ctx, int32_t kfv, int32_t *is_float);
 /* The tested windows inside the threshold guard band found by the last scan (0-based record, 1-based KFV, window start):
  * they travel with the dips, because the chain replay samples the running value at them.  kgma_set_att hands the merged
  * list to the NEXT kgma_replay_dips. */

@@ -4175,6 +4175,14 @@ int kgma_kfv_scale(kgma_ctx *ctx, int32_t kfv, double *scale, int64_t *n_refs)
     return KGMA_OK;
 }
 
+int kgma_kfv_is_float(kgma_ctx *ctx, int32_t kfv, int32_t *is_float)
+{
+    if (!ctx || !is_float) return KGMA_E_ARG;
+    if (kfv < 1 || kfv > ctx->m) return fail(ctx, KGMA_E_ARG, "no such KFV");
+    *is_float = ctx->kfv[(size_t)(kfv - 1)].fp ? 1 : 0;
+    return KGMA_OK;
+}
+
 int kgma_set_chain_source(kgma_ctx *ctx, kgma_chain_fn fn, void *user)
 {
     if (!ctx) return KGMA_E_ARG;

@@ -33,7 +33,7 @@ EXPORTS = [
     "kgma_kmer_count_batch", "kgma_kmer_dist_batch", "kgma_step_begin", "kgma_step_end", "kgma_set_reserved_cus",
     "kgma_scan_aligned", "kgma_get_alignments", "kgma_set_residue_source", "kgma_host_chain_values",
     "kgma_chain_values", "kgma_host_chain_walk", "kgma_chain_chunk_steps", "kgma_set_chain_source", "kgma_get_att", "kgma_set_att",
-    "kgma_chain_export", "kgma_chain_export_copy", "kgma_kfv_scale",
+    "kgma_chain_export", "kgma_chain_export_copy", "kgma_kfv_scale", "kgma_kfv_is_float",
 ]
 
 
@@ -157,6 +157,7 @@ def load():
     L.kgma_set_residue_source.argtypes = [vp, FETCH_FN, vp]
     L.kgma_set_chain_source.argtypes = [vp, CHAIN_FN, vp]
     L.kgma_kfv_scale.argtypes = [vp, i32, P(dbl), P(i64)]
+    L.kgma_kfv_is_float.argtypes = [vp, i32, P(i32)]
     L.kgma_get_att.argtypes = [vp, P(i32), P(i32), P(i64), i64, P(i64)]
     L.kgma_set_att.argtypes = [vp, P(i32), P(i32), P(i64), i64]
     L.kgma_chain_export.argtypes = [vp, vp, i64, i32, i64, P(i64), P(i64), i64, P(i64), P(i64), P(i64), P(dbl)]
@@ -536,6 +537,12 @@ class Context:
         sc = C.c_double(0)
         self._check(load().kgma_kfv_scale(self._h, int(kfv), C.byref(sc), None))
         return sc.value
+
+    def kfv_is_float(self, kfv: int) -> bool:
+        """True if KFV `kfv` (1-based) is scanned as a general Float64 vector (not S/N)."""
+        v = C.c_int32(0)
+        self._check(load().kgma_kfv_is_float(self._h, int(kfv), C.byref(v)))
+        return bool(v.value)
 
     def att(self) -> np.ndarray:
         """kgma_get_att: tested windows inside the threshold guard band, as an (n, 3) int64 array (record, 1-based KFV, window)."""

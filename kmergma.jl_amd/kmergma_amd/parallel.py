@@ -563,9 +563,14 @@ def walk_chain_pieces(ctx, pairs, pieces: List[dict], ws: Sequence[int]) -> List
     return out
 
 
-def merge_payloads(payloads: Sequence[dict], n_records: int, m: int):
+def merge_payloads(payloads: Sequence[dict], n_records: int, m: int, float_kfv: Optional[Sequence[bool]] = None):
     """Join the ranks' dips: sort by (record, KFV, start), merge a dip that reaches the end of its slice
-    with the dip that starts the next slice at the shared window.  Returns (dips, last_min, first_D)."""
+    with the dip that starts the next slice at the shared window.  Returns (dips, last_min, first_D).
+
+    `float_kfv[j]` (Context.kfv_is_float): KFV j + 1 is a general Float64 vector.  Its D values are anchored per stream, so two
+    ranks report the shared window (and any two windows whose distances differ by rounding noise) a few units apart: minima within
+    the library's near-tie tolerance max(|a|, |b|) * 2^-30 + 2 (kgma_kfv_is_float, kgma.h) count as tied, as they do between
+    the streams of one rank."""
     from . import _lib
     TIE, RESOLVED = _lib.HIT_TIE, _lib.HIT_TIE_RESOLVED
     dips = np.concatenate([p["dips"] for p in payloads]) if payloads else np.zeros(0, dtype=_lib.DIP_DTYPE)
@@ -585,14 +590,21 @@ def merge_payloads(payloads: Sequence[dict], n_records: int, m: int):
         if (cur is not None and cur["contig"] == d["contig"] and cur["kfv"] == d["kfv"] and cur["exit_pos"] == 0
                 and cur["end"] == d["start"]):
             # the shared window is under the threshold in both slices: one dip
-            if d["D_min"] < cur["D_min"]:
+            a, b = int(cur["D_min"]), int(d["D_min"])
+            tol = 0
+            if float_kfv is not None and float_kfv[int(d["kfv"]) - 1]:
+                tol = int(max(abs(a), abs(b)) * 2.0 ** -30) + 2
+            if b < a - tol:
                 cur["D_min"], cur["argmin"], cur_last = d["D_min"], d["argmin"], lm
                 cur["flags"] = (cur["flags"] & ~np.uint32(TIE | RESOLVED)) | (d["flags"] & np.uint32(TIE | RESOLVED))
-            elif d["D_min"] == cur["D_min"]:
+            elif b <= a + tol:
                 single = cur["argmin"] == cur_last == d["argmin"] == lm           # the minimum IS the shared window
+                if b < a:
+                    cur["D_min"], cur["argmin"] = d["D_min"], d["argmin"]
                 cur_last = lm
                 if not single:
                     cur["flags"] = (cur["flags"] & ~np.uint32(RESOLVED)) | np.uint32(TIE)   # tie across a slice boundary
+                cur["flags"] |= d["flags"] & np.uint32(TIE)
             cur["flags"] |= d["flags"] & np.uint32(_lib.HIT_AT_THRESHOLD)
             cur["end"], cur["exit_pos"], cur["D_exit"] = d["end"], d["exit_pos"], d["D_exit"]
             continue
@@ -677,7 +689,7 @@ def scan_sharded(ctx, records, mode: int, buff: int = 50, genome_pos: int = 0, f
         # From here on the other ranks sit in their serve loop (chain mode): whatever happens on rank 0 -- also before the replay
         # starts -- the release broadcast in the finally below must go out, or they block in the collective for ever.
         try:
-            dips, last_min, first_D = merge_payloads(gathered, len(lengths), m)
+            dips, last_min, first_D = merge_payloads(gathered, len(lengths), m, [ctx.kfv_is_float(j + 1) for j in range(m)])
             ctx.set_residue_source(lambda c, pos, n: src.fetch(c, pos - 1, pos - 1 + n))
             if chain:
                 att = np.concatenate([p["att"] for p in gathered]) if gathered else np.zeros((0, 3), dtype=np.int64)

@@ -263,6 +263,45 @@ def test_dip_exchange_world4_gloo():
     assert keys == sorted(keys)
 
 
+def test_merge_payloads_float_kfv_near_ties():
+    """A dip cut by a slice boundary, Float64 KFV (KFV 2; KFV 1 is the exact-integer form): the two ranks report D values
+    anchored on different streams, so minima within max(|a|, |b|) * 2^-30 + 2 are a tie (flagged unless both minima ARE the
+    shared window); the integer KFV keeps exact comparison."""
+    from kmergma_amd import _lib
+
+    def dip(kfv, start, end, argmin, dmin, exit_pos=0, dexit=0):
+        d = np.zeros(1, dtype=_lib.DIP_DTYPE)
+        d["contig"], d["kfv"], d["start"], d["end"], d["argmin"] = 0, kfv, start, end, argmin
+        d["D_min"], d["exit_pos"], d["D_exit"] = dmin, exit_pos, dexit
+        return d
+
+    big = 3 << 40                                            # tolerance = big * 2^-30 + 2 = 3074
+    def merged(kfv, a_min, a_arg, b_min, b_arg, flt):
+        pa = dict(dips=dip(kfv, 90, 100, a_arg, a_min), last_min=np.array([a_arg]), first_D={0: [1, 1]})
+        pb = dict(dips=dip(kfv, 100, 110, b_arg, b_min, 111, big * 2), last_min=np.array([b_arg]), first_D={})
+        out, last, _ = parallel.merge_payloads([pa, pb], 1, 2, flt)
+        assert len(out) == 1 and out[0]["start"] == 90 and out[0]["end"] == 110 and out[0]["exit_pos"] == 111
+        return out[0], int(last[0])
+
+    flt = [False, True]
+    d, last = merged(2, big, 95, big + 3000, 105, flt)        # within the tolerance: a tie across the cut, the smaller value kept
+    assert d["flags"] & _lib.HIT_TIE and d["D_min"] == big and d["argmin"] == 95 and last == 105
+    d, last = merged(2, big + 3000, 95, big, 105, flt)
+    assert d["flags"] & _lib.HIT_TIE and d["D_min"] == big and d["argmin"] == 105 and last == 105
+    d, last = merged(2, big, 95, big + 4000, 105, flt)        # beyond it: the earlier minimum stands, no flag
+    assert not (d["flags"] & _lib.HIT_TIE) and d["D_min"] == big and d["argmin"] == 95 and last == 95
+    d, last = merged(2, big + 4000, 95, big, 105, flt)
+    assert not (d["flags"] & _lib.HIT_TIE) and d["D_min"] == big and d["argmin"] == 105 and last == 105
+    d, last = merged(2, big + 7, 100, big, 100, flt)          # the minimum IS the shared window, reported a few units apart: one minimum
+    assert not (d["flags"] & _lib.HIT_TIE) and d["D_min"] == big and d["argmin"] == 100 and last == 100
+    d, last = merged(1, big, 95, big + 1, 105, flt)           # exact-integer KFV: == only
+    assert not (d["flags"] & _lib.HIT_TIE) and d["argmin"] == 95
+    d, last = merged(1, big, 95, big, 105, flt)
+    assert d["flags"] & _lib.HIT_TIE and d["argmin"] == 95 and last == 105
+    d, last = merged(2, big, 95, big + 3000, 105, None)       # no float information: exact comparison (as before)
+    assert not (d["flags"] & _lib.HIT_TIE)
+
+
 def test_chain_request_and_piece_blocks_round_trip():
     """The int64 blocks of the sharded chain replay (parallel.scan_sharded with KGMA_F_CHAIN_REPLAY): requests rank 0
     broadcasts, guard-band windows in the dip payload, and the pieces the ranks send back (streams, chunk records, pool)."""

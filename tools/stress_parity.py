@@ -210,6 +210,29 @@ def float_case(ctx, gen, rng, contigs, KFVs, ws, thr, k, m, mode_single, buff, g
     if [key(h) for h in hits_f] != [key(h) for h in ohf]:
         assert any(d["flags"] & 3 for d in dips_f) or st_f["n_at_threshold"] > 0, "float KFV: difference with nothing flagged"
         nflag = 1
+    # the same scan sharded INSIDE records (the ranks' parts run one after the other), ties left flagged: the joined dips give
+    # the oracle's hits unless something is flagged (near ties across a cut are compared with the library's tolerance)
+    world = int(rng.integers(2, 5))
+    minw = int(rng.choice([2, 7, 64, 1000]))
+    mm = 1 if mode_single else m
+    plan = parallel.plan_slices([len(c) for c in contigs], world, mode_single, ws if not mode_single else ws[:1], k, minw)
+    payloads = [parallel.local_scan(ctx, contigs, plan[r], mode, _lib.F_NO_TIE_RESOLVE) for r in range(world)]
+    sd, slm, sfd = parallel.merge_payloads(payloads, len(contigs), mm, [ctx.kfv_is_float(j + 1) for j in range(mm)])
+    ctx.replay_dips(mode, buff, g0, _lib.F_NO_TIE_RESOLVE, [len(c) for c in contigs], sfd, sd, slm, None)
+    sh = ctx.hits()
+    sd = ctx.dips()                                          # (with the flags the hit state machine added: minima equal to the running minimum)
+    assert [key(h) for h in sh] == [key(h) for h in hits_f] or any(d["flags"] & 3 for d in sd) or any(p["att"].shape[0] for p in payloads), \
+        "float KFV, sharded: differs from the one-process scan with nothing flagged"
+    if [key(h) for h in sh] != [key(h) for h in ohf]:
+        if os.environ.get("KGMA_STRESS_DEBUG") and not (any(d["flags"] & 3 for d in sd) or any(p["att"].shape[0] for p in payloads)):
+            print("k", k, "ws", ws, "thr", thr, "single", mode_single, "buff", buff, "lens", [len(c) for c in contigs], "plan", plan)
+            print("sharded:", [key(h) + (h["D"], h["dist"]) for h in sh])
+            print("oracle: ", [key(h) + (h["dist"],) for h in ohf])
+            print("one process:", [key(h) + (h["D"], h["dist"]) for h in hits_f])
+            print("merged dips after replay:", [tuple(int(d[f]) for f in ("contig", "kfv", "start", "end", "argmin", "D_min", "exit_pos", "D_exit", "flags")) for d in sd])
+            print("one-process dips:", [tuple(int(d[f]) for f in ("contig", "kfv", "start", "end", "argmin", "D_min", "exit_pos", "D_exit", "flags")) for d in dips_f])
+        assert any(d["flags"] & 3 for d in sd) or any(p["att"].shape[0] for p in payloads), "float KFV, sharded: difference with nothing flagged"
+        nflag = 1
     return dict(k=k, m=m, ws=ws, single=mode_single, hits=len(hits_f), amb=nflag)
 
 
@@ -220,6 +243,7 @@ def main():
     ap.add_argument("--k", default="", help="comma-separated k-mer lengths to draw from (default: 2 ... 10)")
     ap.add_argument("--wide", action="store_true", help="windows of 2040 ... 9000 residues as well")
     ap.add_argument("--float", type=float, default=0.0, dest="float_p", help="probability of a general Float64 KFV set")
+    ap.add_argument("--case", type=int, default=-1, help="run this one case of the seed only (to reproduce a failure)")
     args = ap.parse_args()
     global KSET, WIDE, FLOAT
     KSET = [int(x) for x in args.k.split(",")] if args.k else None
@@ -227,9 +251,9 @@ def main():
     ctx = _lib.Context(0)
     t0 = time.time()
     n = skipped = total_hits = amb = 0
-    case = 0
+    case = max(args.case, 0)
     last_print = t0
-    while time.time() - t0 < args.seconds:
+    while time.time() - t0 < args.seconds and (args.case < 0 or case == args.case):
         rng = np.random.default_rng([args.seed, case])
         try:
             r = one_case(ctx, rng, case)

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--mb", type=float, default=400.0)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--out", default="")
+    ap.add_argument("--only", default="", help="comma-separated case numbers (0-based, in the order below): profile runs")
     args = ap.parse_args()
     n = int(args.mb * 1e6)
     ctx = _lib.Context(0)
@@ -54,7 +55,13 @@ def main():
     rng = np.random.default_rng(1)
     rows = []
 
+    only = {int(x) for x in args.only.split(",") if x != ""}
+    case_no = [0]
+
     def run(label, k, W, fp=False, env=None, chain=False):
+        case_no[0] += 1
+        if only and case_no[0] - 1 not in only:
+            return
         RV, ws, N = family(rng, W, k)
         if fp:
             RV = RV * (1.0 / np.sqrt(2.0)) + np.roll(RV, 1) * (1.0 - 1.0 / np.sqrt(2.0))
