@@ -1453,6 +1453,7 @@ int kgma_genome_from_fasta_file(kgma_ctx *ctx, const char *path, kgma_genome **o
     if (fd < 0) return fail(ctx, KGMA_E_ARG, "cannot open %s", path);
     struct stat sb;
     if (fstat(fd, &sb) != 0 || sb.st_size < 0) { close(fd); return fail(ctx, KGMA_E_ARG, "cannot stat %s", path); }
+    if (!S_ISREG(sb.st_mode)) { close(fd); return fail(ctx, KGMA_E_ARG, "%s is not a regular file (pipes are not read: pass the text to kgma_genome_from_fasta)", path); }
     const int64_t n = (int64_t)sb.st_size;
     if (n == 0) { close(fd); return genome_from_fasta_impl(ctx, nullptr, 0, -1, out); }
     void *map = mmap(nullptr, (size_t)n, PROT_READ, MAP_PRIVATE, fd, 0);

@@ -31,6 +31,8 @@ namespace kgma {
 
 namespace {
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ int g_uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ int64_t g_uni64(int64_t v)
 {
@@ -38,11 +40,6 @@ __device__ __forceinline__ int64_t g_uni64(int64_t v)
 }
 __device__ __forceinline__ double g_unid(double v) { return __longlong_as_double(g_uni64(__double_as_longlong(v))); }
 
-__device__ __forceinline__ int64_t g_shfl_up64(int64_t v, int d)
-{
-    const int lo = __shfl_up((int)(uint32_t)v, d), hi = __shfl_up((int)(uint32_t)((uint64_t)v >> 32), d);
-    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-}
 __device__ __forceinline__ int64_t g_shfl_xor64(int64_t v, int d)
 {
     const int lo = __shfl_xor((int)(uint32_t)v, d), hi = __shfl_xor((int)(uint32_t)((uint64_t)v >> 32), d);
@@ -54,12 +51,27 @@ __device__ __forceinline__ int64_t g_readlane64(int64_t v, int l)
     return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
+// One stage of the wave-wide inclusive prefix sum on the DPP network (no LDS round trip): the 64-bit value of the lane the control
+// selects, 0 where the control selects none (row_shr past the row's start) or the row mask disables the lane.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int64_t g_dpp64(int64_t v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROWS, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((uint64_t)v >> 32), CTRL, ROWS, 0xF, false);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
 template <class V> struct Ops;
 template <> struct Ops<int64_t> {
     static __device__ __forceinline__ int64_t scan(int64_t v, int lane)
     {
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int64_t o = g_shfl_up64(v, d); v += lane >= d ? o : 0; }
+        (void)lane;
+        v += g_dpp64<0x111, 0xF>(v);      // row_shr:1
+        v += g_dpp64<0x112, 0xF>(v);      // row_shr:2
+        v += g_dpp64<0x114, 0xF>(v);      // row_shr:4
+        v += g_dpp64<0x118, 0xF>(v);      // row_shr:8
+        v += g_dpp64<0x142, 0xA>(v);      // row_bcast:15 -> rows 1, 3
+        v += g_dpp64<0x143, 0xC>(v);      // row_bcast:31 -> rows 2, 3
         return v;
     }
     static __device__ __forceinline__ int64_t sum(int64_t v)
@@ -81,8 +93,15 @@ template <> struct Ops<int64_t> {
 template <> struct Ops<double> {
     static __device__ __forceinline__ double scan(double v, int lane)
     {
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const double o = __longlong_as_double(g_shfl_up64(__double_as_longlong(v), d)); v += lane >= d ? o : 0.0; }
+        // (a lane the stage does not feed adds the bit pattern 0 = +0.0; any summation order serves: the value is an approximation
+        //  of the reference's running sum either way, and its bitwise plateaus are restored by the caller)
+        (void)lane;
+        v += __longlong_as_double(g_dpp64<0x111, 0xF>(__double_as_longlong(v)));
+        v += __longlong_as_double(g_dpp64<0x112, 0xF>(__double_as_longlong(v)));
+        v += __longlong_as_double(g_dpp64<0x114, 0xF>(__double_as_longlong(v)));
+        v += __longlong_as_double(g_dpp64<0x118, 0xF>(__double_as_longlong(v)));
+        v += __longlong_as_double(g_dpp64<0x142, 0xA>(__double_as_longlong(v)));
+        v += __longlong_as_double(g_dpp64<0x143, 0xC>(__double_as_longlong(v)));
         return v;
     }
     static __device__ __forceinline__ double sum(double v)
@@ -104,9 +123,12 @@ template <> struct Ops<double> {
 
 }  // namespace
 
-template <bool FP, bool CGLOBAL>
+// TLDS (k <= 6): the KFV's table (S as int32, or the Float64 vector: 16 / 32 KiB at k = 6) is copied to the front of the
+// workgroup's LDS once -- two of the step's four dependent reads then stay in the LDS instead of going to L1 / L2.
+template <bool FP, bool CGLOBAL, bool TLDS>
 __global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
 {
+    static_assert(!(CGLOBAL && TLDS), "global count tables: k >= 8, the table stays in global memory as well");
     typedef std::conditional_t<FP, double, int64_t> V;
     typedef Ops<V> O;
     extern __shared__ uint32_t gsmem[];
@@ -118,7 +140,16 @@ __global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
     const int NB = 1 << (2 * k);
     const uint32_t KM = (uint32_t)NB - 1u;
     const int CW = NB / 2;                                            // dwords of a count table (two 16-bit counters each)
-    uint32_t *C = CGLOBAL ? g.ctab + (size_t)slot * (size_t)CW : gsmem + (size_t)wave * (size_t)CW;
+    const int TW = TLDS ? (FP ? 2 * NB : NB) : 0;                     // dwords of the table in front of the count tables
+    uint32_t *C = CGLOBAL ? g.ctab + (size_t)slot * (size_t)CW : gsmem + (size_t)TW + (size_t)wave * (size_t)CW;
+    if constexpr (TLDS) {
+        if constexpr (FP) { for (int i = threadIdx.x; i < NB; i += blockDim.x) reinterpret_cast<double *>(gsmem)[i] = g.R[i]; }
+        else { for (int i = threadIdx.x; i < NB; i += blockDim.x) reinterpret_cast<int32_t *>(gsmem)[i] = g.S[i]; }
+        __syncthreads();                                              // (the only workgroup barrier: every wave reaches it)
+    }
+    const double *Rt = TLDS ? reinterpret_cast<const double *>(gsmem) : g.R;
+    const int32_t *St = TLDS ? reinterpret_cast<const int32_t *>(gsmem) : g.S;
+    (void)Rt; (void)St;
     const int kid = g.kfv_id;
     const int64_t Nn = g.N, twoN = 2 * (int64_t)g.N;
     double *dist = a.dist[0];
@@ -142,22 +173,32 @@ __global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
         int in_run = 0, run_start = 0, argf = 0, argl = 0, nmin = 0;
         V minV = 0;
 
+        // genome words of a step: the dword pair holding the entering k-mer of position 64 b + lane and the pair holding the
+        // leaving one (n positions back; none yet in the warm-up).  Reads run up to a step past the stream's end: the genome
+        // buffer is padded by more than that (TAIL_PAD_WORDS).
+        auto load_words = [&](const int bb) -> u32x4_t {
+            const int pp = (bb << 6) + lane;
+            const int ie = pp >> 4, il = (pp >= nk ? pp - nk : 0) >> 4;
+            u32x4_t w;
+            w.x = gi[ie]; w.y = gi[ie + 1]; w.z = gi[il]; w.w = gi[il + 1];
+            return w;
+        };
+        u32x4_t pw = load_words(0);
         for (int b = 0; b < n_blocks; b++) {
             const int p = (b << 6) + lane;
-            uint32_t kp, ks;
-            {
-                const int ie = p >> 4;
-                const uint32_t w0 = gi[ie], w1 = gi[ie + 1];
-                kp = __builtin_amdgcn_alignbit(w1, w0, 2u * (uint32_t)(p & 15)) & KM;
-            }
             const bool haveL = p >= nk;
+            uint32_t kp = __builtin_amdgcn_alignbit(pw.y, pw.x, 2u * (uint32_t)(p & 15)) & KM, ks;
             {
                 const int pl = haveL ? p - nk : 0;
-                const int il = pl >> 4;
-                const uint32_t w0 = gi[il], w1 = gi[il + 1];
-                ks = __builtin_amdgcn_alignbit(w1, w0, 2u * (uint32_t)(pl & 15)) & KM;
+                ks = __builtin_amdgcn_alignbit(pw.w, pw.z, 2u * (uint32_t)(pl & 15)) & KM;
                 ks = haveL ? ks : kp;
             }
+            // S[kp], S[ks] / ref[kp], ref[ks] -- and then the NEXT step's genome words, one step ahead (issued after the table
+            // reads: a wait for those must not wait for these)
+            V tab_p, tab_l;
+            if constexpr (FP) { tab_p = Rt[kp]; tab_l = Rt[ks]; }
+            else { tab_p = St[kp]; tab_l = St[ks]; }
+            pw = load_words(b + 1);
             const bool differ = kp != ks;                             // GenomeMiner.jl:66: nothing happens if left == right
             const bool actE = differ || !haveL, actL = differ && haveL;
             const uint32_t shp = 16u * (kp & 1u), shs = 16u * (ks & 1u);
@@ -208,10 +249,8 @@ __global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
             }
             // ---- this lane's transition ------------------------------------------------------------------------------
             V e = 0;
-            V tab_p = 0;                                              // S[kp] / ref[kp] (warm-up sum)
             if constexpr (FP) {
-                const double rr = g.R[kp], rl = g.R[ks];
-                tab_p = rr;
+                const double rr = tab_p, rl = tab_l;
                 if (actL) {
                     double t = (double)(1 + cP);                      // 1 + curr_kmer_freq[right]: an Int addition in the reference
                     t = t + rl;                                       // + refVec[left]
@@ -220,9 +259,7 @@ __global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
                     e = g.SF * t;
                 }
             } else {
-                const int64_t Sr = g.S[kp], Sl = g.S[ks];
-                tab_p = Sr;
-                if (actL) e = Sl - Sr - Nn * (int64_t)(cS - 1 - cP);
+                if (actL) e = tab_l - tab_p - Nn * (int64_t)(cS - 1 - cP);
             }
             if ((b << 6) < nk) {                                      // warm-up steps: the stream's first window
                 const bool wu = p < nk;
@@ -254,10 +291,12 @@ __global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
                 // rounded along different paths), so every such lane takes the value of the head of its run of zero increments:
                 // plateaus are bitwise plateaus, and the strict running minimum picks their first window like the reference.
                 const uint64_t H = ~__ballot(e == 0.0) | 1ull;        // (lane 0 heads a run: with e = 0 its value is the carry itself)
-                const int head = 63 - __builtin_clzll(H & (~(uint64_t)0 >> (63 - lane)));
-                const int64_t vb = __double_as_longlong(val);
-                const int lo = __shfl((int)(uint32_t)vb, head), hi = __shfl((int)(uint32_t)((uint64_t)vb >> 32), head);
-                val = __longlong_as_double((int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
+                if (H != ~(uint64_t)0) {                              // (random sequence: a lane in 4^k has left == right)
+                    const int head = 63 - __builtin_clzll(H & (~(uint64_t)0 >> (63 - lane)));
+                    const int64_t vb = __double_as_longlong(val);
+                    const int lo = __shfl((int)(uint32_t)vb, head), hi = __shfl((int)(uint32_t)((uint64_t)vb >> 32), head);
+                    val = __longlong_as_double((int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
+                }
             }
             carry = O::lane_of(val, 63);
             if constexpr (FP) val = d0 + val;
@@ -372,9 +411,10 @@ __global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
 // value -- far inside the 2^-29 guard band, which is also what bounds the reference's own drift from it (the host checks the
 // value at every stream start against the first distance the kernel reports).
 // ------------------------------------------------------------------------------------------------------------------
-template <bool CGLOBAL>
+template <bool CGLOBAL, bool TLDS>
 __global__ __launch_bounds__(1024) void gen_chain_kernel(ScanArgs a, GenParams g)
 {
+    static_assert(!(CGLOBAL && TLDS), "global count tables: the table stays in global memory as well");
     typedef Ops<double> O;
     extern __shared__ uint32_t gsmem[];
     const int lane = threadIdx.x & 63;
@@ -385,7 +425,13 @@ __global__ __launch_bounds__(1024) void gen_chain_kernel(ScanArgs a, GenParams g
     const int NB = 1 << (2 * k);
     const uint32_t KM = (uint32_t)NB - 1u;
     const int CW = NB / 2;
-    uint32_t *C = CGLOBAL ? g.ctab + (size_t)slot * (size_t)CW : gsmem + (size_t)wave * (size_t)CW;
+    const int TW = TLDS ? 2 * NB : 0;                                 // (TLDS: the Float64 table in front of the count tables, as in gen_kernel)
+    uint32_t *C = CGLOBAL ? g.ctab + (size_t)slot * (size_t)CW : gsmem + (size_t)TW + (size_t)wave * (size_t)CW;
+    if constexpr (TLDS) {
+        for (int i = threadIdx.x; i < NB; i += blockDim.x) reinterpret_cast<double *>(gsmem)[i] = g.R[i];
+        __syncthreads();
+    }
+    const double *Rt = TLDS ? reinterpret_cast<const double *>(gsmem) : g.R;
     const int kid = g.kfv_id;
     constexpr int CS_SPLIT = 1, CS_DETAIL = 2, CS_FULL = 4;
 
@@ -489,6 +535,17 @@ __global__ __launch_bounds__(1024) void gen_chain_kernel(ScanArgs a, GenParams g
             c_XLhi = (uint32_t)g_uni((int32_t)((uint32_t)(e + 1023) << 20));
         };
 
+        // genome words of a step: the dword pair holding the entering k-mer of position 64 b + lane and the pair holding the
+        // leaving one (n positions back; none yet in the warm-up).  Reads run up to a step past the stream's end: the genome
+        // buffer is padded by more than that (TAIL_PAD_WORDS).
+        auto load_words = [&](const int bb) -> u32x4_t {
+            const int pp = (bb << 6) + lane;
+            const int ie = pp >> 4, il = (pp >= nk ? pp - nk : 0) >> 4;
+            u32x4_t w;
+            w.x = gi[ie]; w.y = gi[ie + 1]; w.z = gi[il]; w.w = gi[il + 1];
+            return w;
+        };
+        u32x4_t pw = load_words(0);
         for (int b = 0; b < n_blocks; b++) {
             if ((b & (KGMA_CHAIN_STEPS - 1)) == 0) {                  // chunk begin
                 c_chunk_b0 = b;
@@ -503,20 +560,15 @@ __global__ __launch_bounds__(1024) void gen_chain_kernel(ScanArgs a, GenParams g
                 }
             }
             const int p = (b << 6) + lane;
-            uint32_t kp, ks;
-            {
-                const int ie = p >> 4;
-                const uint32_t w0 = gi[ie], w1 = gi[ie + 1];
-                kp = __builtin_amdgcn_alignbit(w1, w0, 2u * (uint32_t)(p & 15)) & KM;
-            }
             const bool haveL = p >= nk;
+            uint32_t kp = __builtin_amdgcn_alignbit(pw.y, pw.x, 2u * (uint32_t)(p & 15)) & KM, ks;
             {
                 const int pl = haveL ? p - nk : 0;
-                const int il = pl >> 4;
-                const uint32_t w0 = gi[il], w1 = gi[il + 1];
-                ks = __builtin_amdgcn_alignbit(w1, w0, 2u * (uint32_t)(pl & 15)) & KM;
+                ks = __builtin_amdgcn_alignbit(pw.w, pw.z, 2u * (uint32_t)(pl & 15)) & KM;
                 ks = haveL ? ks : kp;
             }
+            const double rr = Rt[kp], rl = Rt[ks];
+            pw = load_words(b + 1);                                   // the next step's genome words, one step ahead
             const bool differ = kp != ks;
             const bool actE = differ || !haveL, actL = differ && haveL;
             const uint32_t shp = 16u * (kp & 1u), shs = 16u * (ks & 1u);
@@ -563,7 +615,6 @@ __global__ __launch_bounds__(1024) void gen_chain_kernel(ScanArgs a, GenParams g
             // the reference's Float64 update of this lane's window (GenomeMiner.jl:70-72, same operation order)
             const bool act = actL && p - nk + 1 < n_valid;            // the transition belongs to this stream
             const uint64_t ACT = __ballot(act);
-            const double rr = g.R[kp], rl = g.R[ks];
             double inc = 0.0;
             if (act) {
                 double t = (double)(1 + cP);
@@ -633,96 +684,108 @@ __global__ __launch_bounds__(1024) void gen_chain_kernel(ScanArgs a, GenParams g
 
 // ---- geometry + launch ----------------------------------------------------------------------------------------------
 bool generic_counts_in_lds(int k) { return k <= 7; }                  // 2 * 4^k bytes per wave: 32 KiB at k = 7
+static bool generic_table_in_lds(int k) { return k <= 6; }            // 4 (S) or 8 (Float64) bytes per k-mer: at most 32 KiB
 
-static int generic_waves(int k)                                       // waves (= streams) per workgroup
+namespace {
+struct GenGeom { bool cglobal, tlds; int nw; size_t lds; };
+}
+
+// waves (= streams) per workgroup and its LDS: [table (TLDS) | nw count tables] out of 160 KiB less `reserve`
+static GenGeom generic_geom_of(int k, bool fp, size_t reserve)
 {
-    if (!generic_counts_in_lds(k)) return 4;
+    GenGeom q;
+    q.cglobal = !generic_counts_in_lds(k);
+    q.tlds = !q.cglobal && generic_table_in_lds(k);
+    if (q.cglobal) { q.nw = 4; q.lds = 0; return q; }
     const size_t per = (size_t)2 << (2 * k);
-    const size_t w = (((size_t)160 << 10) - 1024) / per;
-    return (int)(w > 16 ? 16 : w);
+    const size_t tab = q.tlds ? ((size_t)(fp ? 8 : 4) << (2 * k)) : 0;
+    const size_t w = (((size_t)160 << 10) - reserve - tab) / per;
+    q.nw = (int)(w > 16 ? 16 : w);
+    q.lds = tab + (size_t)q.nw * per;
+    return q;
 }
 
-static const void *generic_fn(bool fp, bool cglobal)
+static const void *generic_fn(bool fp, const GenGeom &q)
 {
-    if (fp) return cglobal ? reinterpret_cast<const void *>(&gen_kernel<true, true>) : reinterpret_cast<const void *>(&gen_kernel<true, false>);
-    return cglobal ? reinterpret_cast<const void *>(&gen_kernel<false, true>) : reinterpret_cast<const void *>(&gen_kernel<false, false>);
+    if (fp) return q.cglobal ? reinterpret_cast<const void *>(&gen_kernel<true, true, false>)
+                             : (q.tlds ? reinterpret_cast<const void *>(&gen_kernel<true, false, true>) : reinterpret_cast<const void *>(&gen_kernel<true, false, false>));
+    return q.cglobal ? reinterpret_cast<const void *>(&gen_kernel<false, true, false>)
+                     : (q.tlds ? reinterpret_cast<const void *>(&gen_kernel<false, false, true>) : reinterpret_cast<const void *>(&gen_kernel<false, false, false>));
 }
 
-// streams resident per CU (what the host sizes the stream table and the global count tables for)
-int generic_slots_per_cu(int k, bool fp)
+static const void *generic_chain_fn(const GenGeom &q)
 {
-    const bool cg = !generic_counts_in_lds(k);
-    const int nw = generic_waves(k);
-    const size_t lds = cg ? 0 : (size_t)nw * ((size_t)2 << (2 * k));
-    const void *fn = generic_fn(fp, cg);
+    return q.cglobal ? reinterpret_cast<const void *>(&gen_chain_kernel<true, false>)
+                     : (q.tlds ? reinterpret_cast<const void *>(&gen_chain_kernel<false, true>) : reinterpret_cast<const void *>(&gen_chain_kernel<false, false>));
+}
+
+// The whole LDS of a CU where the runtime grants it to one workgroup (k = 7: five 32 KiB count tables; k = 6, Float64: the 32 KiB
+// table and sixteen 8 KiB count tables), else with 1 KiB left over.
+static GenGeom generic_geom(int k, bool fp, bool chain)
+{
+    GenGeom q = generic_geom_of(k, fp, 0);
+    if (q.cglobal) return q;
+    const void *fn = chain ? generic_chain_fn(q) : generic_fn(fp, q);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds) == hipSuccess) return q;
+    (void)hipGetLastError();
+    return generic_geom_of(k, fp, 1024);
+}
+
+static int generic_resident(const void *fn, const GenGeom &q, int k)
+{
     int blocks = 0;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64 * nw, lds) != hipSuccess || blocks < 1) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64 * q.nw, q.lds) != hipSuccess || blocks < 1) {
         (void)hipGetLastError();
         blocks = 1;
     }
     // (global count tables: 2 * 4^k bytes per slot; a step is two dependent round trips to L2, so the walk is latency-bound and
     //  wants waves: 16 per CU at k = 8, 9 (128 / 512 KiB per slot), 8 at k = 10 (2 MiB per slot: 4 GiB of tables))
-    if (cg) blocks = std::min(blocks, k >= 10 ? 2 : 4);
-    if (blocks * nw > 32) blocks = 32 / nw;
-    return nw * (blocks < 1 ? 1 : blocks);
+    if (q.cglobal) blocks = std::min(blocks, k >= 10 ? 2 : 4);
+    if (blocks * q.nw > 32) blocks = 32 / q.nw;
+    return q.nw * (blocks < 1 ? 1 : blocks);
 }
 
-static const void *generic_chain_fn(bool cglobal)
+// streams resident per CU (what the host sizes the stream table and the global count tables for)
+int generic_slots_per_cu(int k, bool fp)
 {
-    return cglobal ? reinterpret_cast<const void *>(&gen_chain_kernel<true>) : reinterpret_cast<const void *>(&gen_chain_kernel<false>);
+    const GenGeom q = generic_geom(k, fp, false);
+    return generic_resident(generic_fn(fp, q), q, k);
 }
 
-// streams resident per CU of the chain kernel
+// streams resident per CU of the chain kernel (it reads the Float64 table whatever the KFV's form)
 int generic_chain_slots_per_cu(int k)
 {
-    const bool cg = !generic_counts_in_lds(k);
-    const int nw = generic_waves(k);
-    const size_t lds = cg ? 0 : (size_t)nw * ((size_t)2 << (2 * k));
-    const void *fn = generic_chain_fn(cg);
-    int blocks = 0;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64 * nw, lds) != hipSuccess || blocks < 1) {
-        (void)hipGetLastError();
-        blocks = 1;
-    }
-    if (cg) blocks = std::min(blocks, k >= 10 ? 2 : 4);
-    if (blocks * nw > 32) blocks = 32 / nw;
-    return nw * (blocks < 1 ? 1 : blocks);
+    const GenGeom q = generic_geom(k, true, true);
+    return generic_resident(generic_chain_fn(q), q, k);
+}
+
+static hipError_t launch_gen(const void *fn, const GenGeom &q, const ScanArgs &a, const GenParams &g, hipStream_t st)
+{
+    if (q.nw < 1 || g.n_slots < q.nw || g.n_slots % q.nw != 0) return hipErrorInvalidConfiguration;
+    if (q.cglobal && g.ctab == nullptr) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds);
+    if (e != hipSuccess) return e;
+    ScanArgs a_copy = a;
+    GenParams g_copy = g;
+    void *args[2] = {&a_copy, &g_copy};
+    return hipLaunchKernel(fn, dim3((unsigned)(g.n_slots / q.nw)), dim3(64u * (unsigned)q.nw), args, q.lds, st);
 }
 
 hipError_t launch_generic_chain(const ScanArgs &a, const GenParams &g, hipStream_t st)
 {
     if (a.n_tiles <= 0) return hipSuccess;
-    const bool cg = !generic_counts_in_lds(g.k);
-    const int nw = generic_waves(g.k);
-    if (nw < 1 || g.n_slots < nw || g.n_slots % nw != 0 || g.R == nullptr) return hipErrorInvalidConfiguration;
-    if (cg && g.ctab == nullptr) return hipErrorInvalidValue;
-    const size_t lds = cg ? 0 : (size_t)nw * ((size_t)2 << (2 * g.k));
-    const void *fn = generic_chain_fn(cg);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    ScanArgs a_copy = a;
-    GenParams g_copy = g;
-    void *args[2] = {&a_copy, &g_copy};
-    return hipLaunchKernel(fn, dim3((unsigned)(g.n_slots / nw)), dim3(64u * (unsigned)nw), args, lds, st);
+    if (g.R == nullptr) return hipErrorInvalidConfiguration;
+    const GenGeom q = generic_geom(g.k, true, true);
+    return launch_gen(generic_chain_fn(q), q, a, g, st);
 }
 
 hipError_t launch_generic(const ScanArgs &a, const GenParams &g, hipStream_t st)
 {
     if (a.n_tiles <= 0) return hipSuccess;
-    const bool cg = !generic_counts_in_lds(g.k);
-    const int nw = generic_waves(g.k);
-    if (nw < 1 || g.n_slots < nw || g.n_slots % nw != 0) return hipErrorInvalidConfiguration;
-    if (cg && g.ctab == nullptr) return hipErrorInvalidValue;
-    const size_t lds = cg ? 0 : (size_t)nw * ((size_t)2 << (2 * g.k));
-    const void *fn = generic_fn(g.fp != 0, cg);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    ScanArgs a_copy = a;
-    GenParams g_copy = g;
-    void *args[2] = {&a_copy, &g_copy};
-    return hipLaunchKernel(fn, dim3((unsigned)(g.n_slots / nw)), dim3(64u * (unsigned)nw), args, lds, st);
+    if (g.fp ? g.R == nullptr : g.S == nullptr) return hipErrorInvalidConfiguration;
+    const GenGeom q = generic_geom(g.k, g.fp != 0, false);
+    return launch_gen(generic_fn(g.fp != 0, q), q, a, g, st);
 }
 
 }  // namespace kgma

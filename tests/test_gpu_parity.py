@@ -460,6 +460,22 @@ def test_fasta_ingest_on_device(ctx, data_dir, tmp_path):
     g = ctx.genome_from_fasta(b"")
     assert g.n_contigs == 0
     g.free()
+    # the file entry: an empty file is an empty genome; a missing path, a directory and a pipe are argument errors
+    empty = tmp_path / "empty.fasta"
+    empty.write_bytes(b"")
+    g = ctx.genome_from_fasta(str(empty))
+    assert g.n_contigs == 0
+    g.free()
+    fifo = tmp_path / "pipe.fasta"
+    os.mkfifo(fifo)
+    for bad in (tmp_path / "no_such_file.fasta", tmp_path, fifo):
+        if bad == fifo:
+            wfd = os.open(fifo, os.O_RDWR)                 # (so that the library's open() of the read end does not block)
+        with pytest.raises(_lib.KgmaError) as ei:
+            ctx.genome_from_fasta(str(bad))
+        assert ei.value.status == _lib.KGMA_E_ARG
+        if bad == fifo:
+            os.close(wfd)
 
 
 def test_empty_and_tiny_inputs(ctx, alp_ref):
