@@ -50,10 +50,11 @@ bool stream8_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16);
 int stream8_variant(int n_kfv);
 int stream8_state_words(int k, int n_kfv);
 bool stream8_c16_applies(int k, int nk, int n_kfv, int64_t n_ref, bool s16, bool need_wide);
-int generic_slots_per_cu(int k, bool fp);
-bool generic_counts_in_lds(int k);
+int generic_slots_per_cu(int k, bool fp, int nk_max);
+int generic_count_mode(int k, int nk_max);               // 0: counters in LDS, 1: in global memory (GenParams::ctab), 2: hash table in LDS
+void generic_set_mode(GenParams &g, int nk_max);
 hipError_t launch_generic(const ScanArgs &a, const GenParams &g, hipStream_t st);
-int generic_chain_slots_per_cu(int k);
+int generic_chain_slots_per_cu(int k, int nk);
 hipError_t launch_generic_chain(const ScanArgs &a, const GenParams &g, hipStream_t st);
 hipError_t launch_pos(const ScanArgs &a, const GroupParams &gp, int j0, int nj, hipStream_t st);
 bool chain_applies(int k, int nk, int64_t n_ref, bool s16, bool need_wide);
@@ -1606,6 +1607,7 @@ int stitch_dips(kgma_ctx *ctx, const std::vector<DevRecord> &recs)
         const int64_t twoN = 2 * kf.N;
         Frag f;
         f.contig = td.contig; f.kfv = kfv; f.kind = r.kind_kfv & REC_KIND_MASK;
+        if (f.kind == REC_FAULT) return fail(ctx, KGMA_E_HIP, "internal: the scan kernel gave up on stream %d (hash table of the window's k-mers)", r.tile);
         f.start = td.win0 + r.start; f.end = td.win0 + r.end;
         if (r.kind_kfv & REC_WIDE) {
             // 64-bit values: an int64 prefix E, or (Float64 KFV) the distance itself
@@ -1961,7 +1963,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
     std::vector<int> launch_slots;
     std::vector<double> launch_weight;
     if (generic_all) {
-        stream_nw = generic_slots_per_cu(k, generic_fp);
+        stream_nw = generic_slots_per_cu(k, generic_fp, (int)(maxws - k + 1));
         if (stream_nw < 1) return fail(ctx, KGMA_E_HIP, "the generic kernel cannot be launched (k = %d)", k);
     }
     if (use_stream && !generic_all)
@@ -2080,7 +2082,7 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
             // stream stays long against its warm-up (n k-mers) and the S-table staging of its workgroup.
             {
                 int64_t want = 3, min_windows = std::max<int64_t>(8192, 8 * (maxws - k + 1));   // (a stream's warm-up is its window's n k-mers)
-                if (generic_all && !generic_counts_in_lds(k)) min_windows = std::max<int64_t>(min_windows, (int64_t)1 << (2 * k - 2));   // (and zeroing its global count table)
+                if (generic_all && generic_count_mode(k, (int)(maxws - k + 1)) == 1) min_windows = std::max<int64_t>(min_windows, (int64_t)1 << (2 * k - 2));   // (and zeroing its global count table)
                 if (const char *re = getenv("KGMA_STREAM_ROUNDS")) want = std::max(1, atoi(re));               // experiments
                 if (const char *re = getenv("KGMA_STREAM_ROUND_WINDOWS")) min_windows = std::max(64, atoi(re));
                 rounds = std::max(rounds, std::min<int64_t>(want, total_nwin / (slots * min_windows)));
@@ -2291,7 +2293,8 @@ int kgma_scan_device(kgma_ctx *ctx, const kgma_genome *gc, int32_t mode, uint32_
                 gg.S = ctx->d_Stab + (size_t)j * (size_t)NBk;
                 gg.R = ctx->d_Rtab ? ctx->d_Rtab + (size_t)j * (size_t)NBk : nullptr;
                 if (f.fp && !gg.R) return fail(ctx, KGMA_E_STATE, "internal: no Float64 table for KFV %d", j + 1);
-                if (!generic_counts_in_lds(k)) {
+                generic_set_mode(gg, (int)(maxws - k + 1));           // (one geometry for every launch of the scan: its longest window decides)
+                if (gg.cmode == 1) {
                     rc = dev_reserve(ctx, ctx->d_gctab, ctx->gctab_cap, (int64_t)gg.n_slots * (NBk / 2));
                     if (rc) return rc;
                     gg.ctab = ctx->d_gctab;
@@ -2902,7 +2905,7 @@ static int chain_kernel_for(const kgma_ctx *ctx, const KfvInfo &f)
                     chain_slots_per_cu(k, f.Smax <= 32767, 1, nk, !f.fits32) >= 1;
     if (s8 && !(ge && atoi(ge) == 1)) return 1;
     if (ge && atoi(ge) == 0) return 0;
-    return k >= 2 && k <= 10 && nk >= 1 && nk <= KGMA_MAX_NK_WIDE && generic_chain_slots_per_cu(k) >= 1 ? 2 : 0;
+    return k >= 2 && k <= 10 && nk >= 1 && nk <= KGMA_MAX_NK_WIDE && generic_chain_slots_per_cu(k, nk) >= 1 ? 2 : 0;
 }
 
 static int chain_on_device(kgma_ctx *ctx, const kgma_genome *g, std::vector<ChainPair> &pairs, std::vector<char> &done, ChainDevInfo &info)
@@ -3034,7 +3037,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
         int64_t T;
         {
             const int64_t slots = (int64_t)std::max(1, ctx->n_cus) *
-                                  (generic ? generic_chain_slots_per_cu(k) : chain_slots_per_cu(k, L.s16, nslots, nk, !ctx->kfv[(size_t)L.kfvs[0]].fits32));
+                                  (generic ? generic_chain_slots_per_cu(k, nk) : chain_slots_per_cu(k, L.s16, nslots, nk, !ctx->kfv[(size_t)L.kfvs[0]].fits32));
             T = (windows + slots * 3 - 1) / (slots * 3);
             if (const char *e = getenv("KGMA_CHAIN_STREAM")) T = atoll(e);                     // experiments / tests
             // (a stream's warm-up is its window's n k-mers: streams of at least 4 n transitions)
@@ -3232,10 +3235,11 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
                 GenParams gg;
                 memset(&gg, 0, sizeof gg);
                 gg.k = k; gg.nk = gp.nk; gg.N = (int32_t)f.N; gg.kfv_id = j + 1; gg.fp = 1;
-                gg.n_slots = (int32_t)((int64_t)std::max(1, ctx->n_cus) * generic_chain_slots_per_cu(k));
+                gg.n_slots = (int32_t)((int64_t)std::max(1, ctx->n_cus) * generic_chain_slots_per_cu(k, gp.nk));
                 gg.sumR2 = f.sumR2; gg.SF = 1.0 / (double)k;
                 gg.R = ctx->d_Rtab + (size_t)j * (size_t)((int64_t)1 << (2 * k));
-                if (!generic_counts_in_lds(k)) {
+                generic_set_mode(gg, gp.nk);
+                if (gg.cmode == 1) {
                     rc = dev_reserve(ctx, ctx->d_gctab, ctx->gctab_cap, (int64_t)gg.n_slots * (((int64_t)1 << (2 * k)) / 2));
                     if (rc) return rc;
                     gg.ctab = ctx->d_gctab;
@@ -3255,6 +3259,7 @@ static int chain_on_device_batch(kgma_ctx *ctx, const kgma_genome *g, std::vecto
         if (getenv("KGMA_CHAIN_DEBUG"))
             fprintf(stderr, "  chain batch: %zu pairs, %lld steps, %lld hot units, pool of %lld units, %u asked for%s, attempt %d, kernels %.2f ms\n", el.size(),
                     (long long)total_steps, (long long)hot_units, (long long)pool_units, ctl[0], (ctl[1] & 1u) ? " (ran out)" : "", attempt, ms);
+        if (ctl[1] & 2u) return fail(ctx, KGMA_E_HIP, "internal: the chain kernel gave up on a stream (hash table of the window's k-mers)");
         if (!(ctl[1] & 1u)) {
             pool_units = std::min<int64_t>(pool_units, (int64_t)ctl[0]);
             // (the densest batch this context has seen: a launch that runs out of pool is a launch repeated)

@@ -67,7 +67,7 @@ struct GroupParams {
 // quantities kept in (minE_hi : minE) and (exitE_hi : exitE) -- an int64 prefix E from the kernels that carry the prefix in
 // 64 bits (windows of more than 2031 k-mers, large N), or the bits of a Float64 distance from the Float64 KFV path.  Records
 // without the flag hold int32 E values and leave the two high words unwritten.
-enum : int32_t { REC_RUN = 0, REC_EXIT = 1, REC_ATT = 2, REC_KIND_MASK = 0x3F, REC_WIDE = 0x40 };
+enum : int32_t { REC_RUN = 0, REC_EXIT = 1, REC_ATT = 2, REC_FAULT = 3 /* the kernel gave up on a stream (internal error) */, REC_KIND_MASK = 0x3F, REC_WIDE = 0x40 };
 
 // One record emitted by the scan kernel (positions are local to the tile; E is the integer
 // prefix (D - D0[tile]) / (2N)).
@@ -178,7 +178,12 @@ struct GenParams {
     const int32_t *S;                    // integer form: the KFV's S table, 2-bit interleaved index order (first base least significant)
     const double *R;                     // Float64 form: the KFV as given, same index order
     uint32_t *ctab;                      // k >= 8: 4^k / 2 dwords of counters per wave slot (global memory)
+    // where the wave keeps its counts (generic_set_mode): 0 = 4^k 16-bit counters in LDS (k <= 7), 1 = the same in global memory,
+    // 2 = a hash table of the window's distinct k-mers in LDS (k >= 8, windows of at most KGMA_HASH_MAX_NK k-mers): 2^hash_log2m
+    // dwords per wave, rebuilt from the window every hash_rebuild steps
+    int32_t cmode, hash_log2m, hash_rebuild;
 };
+constexpr int KGMA_HASH_MAX_NK = 1983;                         // count field of 11 bits: n + 64 <= 2047
 
 // Count-table stream kernel (kgma_stream.hip): one wave per stream of consecutive window starts.
 constexpr int KGMA_STREAM_MIN_WINDOWS = 2048;                  // shorter streams waste their warm-up (n k-mers)

@@ -5,10 +5,11 @@
 // Float64 KFV.  One KFV per launch (the cluster engine's KFVs are launched one after the other over the same stream table).
 //
 // Same quantity, same records as stream8_kernel (kgma_stream.hip: the per-record body of src/GenomeMiner.jl:32-107 and
-// src/OmnGenomeMiner.jl:55-160): ONE WAVE owns a stream (a run of consecutive window starts of one record) and a table of 4^k
-// 16-bit counters -- in LDS while 2 * 4^k bytes fit a wave's share (k <= 7), else in global memory (k = 8 ... 10: 128 KiB ... 2 MiB
-// per wave, L2 traffic) --, advances 64 windows per step (lane = window), and corrects the counts of the k-mers that several lanes
-// of a step touch with ballots of the lower lanes' transitions.  The waves are persistent (a grid-stride loop over the streams:
+// src/OmnGenomeMiner.jl:55-160): ONE WAVE owns a stream (a run of consecutive window starts of one record) and the counts of its
+// window's k-mers -- 4^k 16-bit counters in LDS while 2 * 4^k bytes fit a wave's share (k <= 7); at k = 8 ... 10 a hash table of the
+// window's distinct k-mers in LDS (windows of at most 1983 k-mers) or the 4^k counters in global memory (128 KiB ... 2 MiB per wave,
+// HBM traffic; see Counts below) --, advances 64 windows per step (lane = window), and corrects the counts of the k-mers that several
+// lanes of a step touch with ballots of the lower lanes' transitions.  The waves are persistent (a grid-stride loop over the streams:
 // the global count tables belong to the wave slots, not to the streams) and every wave reaches the loop's end.
 //   integer form:  e = S[l] - S[r] - N (c[l] - 1 - c[r]),  E = (D - D0) / 2N as an int64 prefix, compared with (T - D0) / 2N;
 //   Float64 form:  inc = SF * (1 + c[r] + ref[l] - ref[r] - c[l]) in the reference's operation order (GenomeMiner.jl:70-72:
@@ -123,15 +124,167 @@ template <> struct Ops<double> {
 
 }  // namespace
 
+// ---- where a wave keeps the counts of its window's k-mers ---------------------------------------------------------------
+//   CM 0: 4^k 16-bit counters (two per dword) in LDS (k <= 7);   CM 1: the same table in global memory (k >= 8: 128 KiB ... 2 MiB per
+//   wave -- every operation is an L2 miss, profiles/r04_gen8_hbm.txt);   CM 2 (k >= 8, windows of at most KGMA_HASH_MAX_NK k-mers): a hash
+//   table of the window's DISTINCT k-mers in LDS -- at most n + 64 of the 4^k k-mers are present at any time.
+// The hash table: 2^log2m dwords in buckets of four (one ds_read_b128 per probe), linear probing over buckets.  An entry is
+//   0 (never used), 1 (tombstone: was used, is free) or LIVE | k-mer << 11 | count.  Within a bucket the never-used entries form
+//   a suffix; a k-mer lives in a bucket of its probe path before or in the first bucket that holds a never-used entry.  A step:
+//   (A) every acting lane finds its entering and its leaving k-mer -- an absent entering k-mer claims the first tombstone of
+//   its path, else the first never-used entry, by compare-and-swap (the loser of a race rescans: either it finds its own k-mer,
+//   claimed by a lane with the same one, or the next free entry); counts do not change in this phase, so the counts read are the
+//   start-of-step counts; (B) the returning add / subtract of the direct tables; (C) a leaving lane whose entry went to 0 leaves a
+//   tombstone.  Every insertion may consume a never-used entry, so the table is rebuilt from the window (clear + re-insert its n
+//   k-mers) every `rebuild` steps, chosen by the host so that an eighth of the table is never-used at all times: probes stay
+//   short and every search ends.  A search that does not end in 8 x buckets iterations reports a fault instead of hanging.
+constexpr uint32_t H_LIVE = 0x80000000u, H_TOMB = 1u, H_CNT = 0x7FFu, H_NONE = 0xFFFFFFFFu;
+
+template <int CM>
+struct Counts {
+    uint32_t *C;
+    int lane, CW;                                                     // CW: dwords of the table
+    uint32_t bmask;                                                   // CM 2: buckets - 1
+    int hshift;                                                       //       32 - log2(buckets)
+    bool fault;
+
+    __device__ __forceinline__ void clear()
+    {
+        if constexpr (CM == 2) {
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            for (int i = lane; i < CW / 4; i += 64) reinterpret_cast<u32x4_t *>(C)[i] = z;
+        } else {
+            for (int i = lane; i < CW; i += 64) C[i] = 0;
+        }
+        if constexpr (CM == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
+
+    struct Probe { uint32_t key, b, tomb, slot, val; bool done; };
+    __device__ __forceinline__ uint32_t home(const uint32_t key) const { return (key * 2654435761u) >> hshift; }
+    __device__ __forceinline__ Probe probe_of(const uint32_t key, const bool on) const
+    {
+        Probe s;
+        s.key = key; s.b = home(key) & bmask; s.tomb = H_NONE; s.slot = 0; s.val = 0; s.done = !on;
+        return s;
+    }
+    // One probe of one search: the bucket's four entries in one read.  INSERT = false: the k-mer is known to be present (a
+    // leaving k-mer), so tombstones and never-used entries are only walked past.
+    template <bool INSERT>
+    __device__ __forceinline__ void probe_step(Probe &s)
+    {
+        if (s.done) return;
+        const u32x4_t v = *reinterpret_cast<const u32x4_t *>(C + 4u * s.b);
+        const uint32_t tag = H_LIVE | (s.key << 11);
+        // (entry ^ tag < 2^11: same k-mer, live -- a tombstone or a never-used entry has the LIVE bit of the tag left)
+        const uint32_t x0 = v.x ^ tag, x1 = v.y ^ tag, x2 = v.z ^ tag, x3 = v.w ^ tag;
+        const uint32_t xm = x0 < x1 ? x0 : x1, xn = x2 < x3 ? x2 : x3;
+        const uint32_t xx = xm < xn ? xm : xn;
+        if (xx <= H_CNT) {
+            const uint32_t j = x0 <= H_CNT ? 0u : (x1 <= H_CNT ? 1u : (x2 <= H_CNT ? 2u : 3u));
+            s.slot = 4u * s.b + j;
+            s.val = tag | xx;                                         // (the matching entry: tag | count)
+            s.done = true;
+            return;
+        }
+        if constexpr (!INSERT) {
+            s.b = (s.b + 1u) & bmask;                                 // (present by construction; the iteration limit guards the walk)
+        } else {
+            if (s.tomb == H_NONE) {
+                const int jt = v.x == H_TOMB ? 0 : (v.y == H_TOMB ? 1 : (v.z == H_TOMB ? 2 : (v.w == H_TOMB ? 3 : -1)));
+                if (jt >= 0) s.tomb = 4u * s.b + (uint32_t)jt;
+            }
+            if (v.w != 0u) { s.b = (s.b + 1u) & bmask; return; }      // (the never-used entries of a bucket are a suffix)
+            // the k-mer is absent: claim the first tombstone of the path, else this bucket's first never-used entry
+            const uint32_t je = v.x == 0u ? 0u : (v.y == 0u ? 1u : (v.z == 0u ? 2u : 3u));
+            const uint32_t target = s.tomb != H_NONE ? s.tomb : 4u * s.b + je;
+            const uint32_t expect = s.tomb != H_NONE ? H_TOMB : 0u;
+            const uint32_t old = atomicCAS(&C[target], expect, tag);
+            if (old == expect) { s.slot = target; s.val = tag; s.done = true; }
+            else if ((old ^ tag) <= H_CNT) { s.slot = target; s.val = old; s.done = true; }   // a lane with the same k-mer was first
+            else { s.b = home(s.key) & bmask; s.tomb = H_NONE; }                              // lost to another k-mer: rescan
+        }
+    }
+    // the searches of a step: the entering k-mers (inserted when absent), then the leaving ones (present)
+    __device__ __forceinline__ void probe2(Probe &e, Probe &l)
+    {
+        const int limit = 8 * (int)(bmask + 1u);
+        int it = 0;
+        while (__ballot(!e.done || !l.done) != 0) {
+            probe_step<true>(e);
+            probe_step<false>(l);
+            if (++it > limit) { fault = true; break; }
+        }
+    }
+    // the window in front of step b (k-mer positions 64 b - nk ... 64 b - 1) re-inserted into a cleared table
+    __device__ __forceinline__ void rebuild(const uint32_t *gi, const int b, const int nk, const uint32_t KM)
+    {
+        clear();
+        const int q1 = b << 6;
+        const int q0 = q1 - nk < 0 ? 0 : q1 - nk;
+        for (int base = q0; base < q1 && !fault; base += 64) {
+            const int q = base + lane;
+            const bool on = q < q1;
+            const int qq = on ? q : q0;
+            const uint32_t w0 = gi[qq >> 4], w1 = gi[(qq >> 4) + 1];
+            const uint32_t key = __builtin_amdgcn_alignbit(w1, w0, 2u * (uint32_t)(qq & 15)) & KM;
+            Probe s = probe_of(key, on), d = probe_of(0u, false);
+            probe2(s, d);
+            if (on && !fault) atomicAdd(&C[s.slot], 1u);
+        }
+    }
+
+    // One step: the start-of-step counts of the lane's entering / leaving k-mer (cp, cs), its transition applied, and the counts
+    // the returning operations saw (oldp, olds: different from cp / cs iff another lane of the step touched the k-mer first).
+    __device__ __forceinline__ void step(const uint32_t kp, const uint32_t ks, const bool actE, const bool actL,
+                                         uint32_t &cp, uint32_t &cs, uint32_t &oldp, uint32_t &olds)
+    {
+        if constexpr (CM == 2) {
+            Probe e = probe_of(kp, actE), l = probe_of(ks, actL);
+            probe2(e, l);
+            cp = e.val & H_CNT; cs = l.val & H_CNT;
+            uint32_t wop = 0, wos = 0;
+            if (!fault) {
+                if (actE) wop = atomicAdd(&C[e.slot], 1u);
+                if (actL) wos = atomicSub(&C[l.slot], 1u);
+                if (actL) {                                           // (after every lane's add and subtract: the count of the next step's start)
+                    const uint32_t v = C[l.slot];
+                    if ((v & H_CNT) == 0u) C[l.slot] = H_TOMB;
+                }
+            }
+            oldp = wop & H_CNT; olds = wos & H_CNT;
+        } else {
+            const uint32_t shp = 16u * (kp & 1u), shs = 16u * (ks & 1u);
+            uint32_t wcp, wcs, wop = 0, wos = 0;
+            if constexpr (CM == 1) {
+                // counts at the start of the step, read past the vector L1 (the atomics below work in L2), and complete before them
+                wcp = __hip_atomic_load(&C[kp >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wcs = __hip_atomic_load(&C[ks >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wcp), "+v"(wcs) : : "memory");
+                if (actE) wop = __hip_atomic_fetch_add(&C[kp >> 1], 1u << shp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (actL) wos = __hip_atomic_fetch_add(&C[ks >> 1], (uint32_t)(-(int32_t)(1u << shs)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wop), "+v"(wos) : : "memory");
+            } else {
+                wcp = C[kp >> 1];                                     // (LDS operations of a wave complete in order)
+                wcs = C[ks >> 1];
+                if (actE) wop = atomicAdd(&C[kp >> 1], 1u << shp);
+                if (actL) wos = atomicSub(&C[ks >> 1], 1u << shs);
+            }
+            cp = (wcp >> shp) & 0xFFFFu; cs = (wcs >> shs) & 0xFFFFu;
+            oldp = (wop >> shp) & 0xFFFFu; olds = (wos >> shs) & 0xFFFFu;
+        }
+    }
+};
+
 // TLDS (k <= 6): the KFV's table (S as int32, or the Float64 vector: 16 / 32 KiB at k = 6) is copied to the front of the
 // workgroup's LDS once -- two of the step's four dependent reads then stay in the LDS instead of going to L1 / L2.
-template <bool FP, bool CGLOBAL, bool TLDS>
+template <bool FP, int CM, bool TLDS>
 __global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
 {
-    static_assert(!(CGLOBAL && TLDS), "global count tables: k >= 8, the table stays in global memory as well");
+    static_assert(!(CM != 0 && TLDS), "k >= 8: the KFV's table stays in global memory");
+    constexpr bool CGLOBAL = CM == 1;
     typedef std::conditional_t<FP, double, int64_t> V;
     typedef Ops<V> O;
-    extern __shared__ uint32_t gsmem[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t gsmem[];
     const int lane = threadIdx.x & 63;
     const int wave = g_uni((int)(threadIdx.x >> 6));
     const int nw = (int)(blockDim.x >> 6);
@@ -139,9 +292,12 @@ __global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
     const int k = g.k, nk = g.nk;
     const int NB = 1 << (2 * k);
     const uint32_t KM = (uint32_t)NB - 1u;
-    const int CW = NB / 2;                                            // dwords of a count table (two 16-bit counters each)
+    const int CW = CM == 2 ? 1 << g.hash_log2m : NB / 2;              // dwords of a count table (two 16-bit counters each; CM 2: the hash table)
     const int TW = TLDS ? (FP ? 2 * NB : NB) : 0;                     // dwords of the table in front of the count tables
-    uint32_t *C = CGLOBAL ? g.ctab + (size_t)slot * (size_t)CW : gsmem + (size_t)TW + (size_t)wave * (size_t)CW;
+    Counts<CM> cnt;
+    cnt.C = CGLOBAL ? g.ctab + (size_t)slot * (size_t)CW : gsmem + (size_t)TW + (size_t)wave * (size_t)CW;
+    cnt.lane = lane; cnt.CW = CW; cnt.fault = false;
+    cnt.bmask = CM == 2 ? (uint32_t)(CW / 4 - 1) : 0u; cnt.hshift = CM == 2 ? 32 - (g.hash_log2m - 2) : 0;
     if constexpr (TLDS) {
         if constexpr (FP) { for (int i = threadIdx.x; i < NB; i += blockDim.x) reinterpret_cast<double *>(gsmem)[i] = g.R[i]; }
         else { for (int i = threadIdx.x; i < NB; i += blockDim.x) reinterpret_cast<int32_t *>(gsmem)[i] = g.S[i]; }
@@ -155,8 +311,7 @@ __global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
     double *dist = a.dist[0];
 
     for (int tile = slot; tile < a.n_tiles; tile += g.n_slots) {
-        for (int i = lane; i < CW; i += 64) C[i] = 0;
-        if constexpr (CGLOBAL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        cnt.clear();
         const TileDesc td = a.tiles[tile];
         const int n_valid = td.n_valid, first_test = td.first_test;
         const uint32_t *gi = a.inter + 2 * td.word_base;              // 2-bit codes, 16 residues per dword, first residue = bits 0-1
@@ -201,21 +356,23 @@ __global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
             pw = load_words(b + 1);
             const bool differ = kp != ks;                             // GenomeMiner.jl:66: nothing happens if left == right
             const bool actE = differ || !haveL, actL = differ && haveL;
-            const uint32_t shp = 16u * (kp & 1u), shs = 16u * (ks & 1u);
-            uint32_t wcp, wcs, wop = 0, wos = 0;
-            if constexpr (CGLOBAL) {
-                // counts at the start of the step, read past the vector L1 (the atomics below work in L2), and complete before them
-                wcp = __hip_atomic_load(&C[kp >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                wcs = __hip_atomic_load(&C[ks >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wcp), "+v"(wcs) : : "memory");
-                if (actE) wop = __hip_atomic_fetch_add(&C[kp >> 1], 1u << shp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (actL) wos = __hip_atomic_fetch_add(&C[ks >> 1], (uint32_t)(-(int32_t)(1u << shs)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wop), "+v"(wos) : : "memory");
-            } else {
-                wcp = C[kp >> 1];                                     // (LDS operations of a wave complete in order)
-                wcs = C[ks >> 1];
-                if (actE) wop = atomicAdd(&C[kp >> 1], 1u << shp);
-                if (actL) wos = atomicSub(&C[ks >> 1], 1u << shs);
+            if constexpr (CM == 2) {
+                if (b > 0 && b % g.hash_rebuild == 0) cnt.rebuild(gi, b, nk, KM);
+            }
+            uint32_t cp, cs, oldp, olds;
+            cnt.step(kp, ks, actE, actL, cp, cs, oldp, olds);
+            if constexpr (CM == 2) {
+                if (cnt.fault) {                                      // (wave-uniform; cannot happen: the host's rebuild period keeps never-used entries)
+                    if (lane == 0) {
+                        DevRecord rec;
+                        rec.tile = tile; rec.kind_kfv = REC_FAULT | REC_WIDE | (kid << 8);
+                        rec.start = rec.end = rec.argf = rec.argl = 0; rec.nmin = 0; rec.has_exit = 0;
+                        rec.minE = rec.exitE = rec.minE_hi = rec.exitE_hi = 0;
+                        const unsigned int idx = atomicAdd(a.rec_count, 1u);
+                        if (idx < a.rec_cap) a.recs[idx] = rec;
+                    }
+                    break;
+                }
             }
             // exact counts of the entering / leaving k-mer in THIS lane's window: the value read, corrected by the transitions of
             // the lower lanes wherever another lane of the step touched the k-mer (its returned old value then differs from the
@@ -223,8 +380,6 @@ __global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
             // hide that -- there every acting lane takes the correction rounds)
             int32_t cP, cS;
             {
-                const uint32_t cp = (wcp >> shp) & 0xFFFFu, cs = (wcs >> shs) & 0xFFFFu;
-                const uint32_t oldp = (wop >> shp) & 0xFFFFu, olds = (wos >> shs) & 0xFFFFu;
                 const bool all = nk < 64;
                 uint64_t pendE = __ballot(actE && (all || oldp != cp)), pendL = __ballot(actL && (all || olds != cs));
                 int32_t corrP = 0, corrS = 0;
@@ -411,12 +566,13 @@ __global__ __launch_bounds__(1024) void gen_kernel(ScanArgs a, GenParams g)
 // value -- far inside the 2^-29 guard band, which is also what bounds the reference's own drift from it (the host checks the
 // value at every stream start against the first distance the kernel reports).
 // ------------------------------------------------------------------------------------------------------------------
-template <bool CGLOBAL, bool TLDS>
+template <int CM, bool TLDS>
 __global__ __launch_bounds__(1024) void gen_chain_kernel(ScanArgs a, GenParams g)
 {
-    static_assert(!(CGLOBAL && TLDS), "global count tables: the table stays in global memory as well");
+    static_assert(!(CM != 0 && TLDS), "k >= 8: the KFV's table stays in global memory");
+    constexpr bool CGLOBAL = CM == 1;
     typedef Ops<double> O;
-    extern __shared__ uint32_t gsmem[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t gsmem[];
     const int lane = threadIdx.x & 63;
     const int wave = g_uni((int)(threadIdx.x >> 6));
     const int nw = (int)(blockDim.x >> 6);
@@ -424,9 +580,12 @@ __global__ __launch_bounds__(1024) void gen_chain_kernel(ScanArgs a, GenParams g
     const int k = g.k, nk = g.nk;
     const int NB = 1 << (2 * k);
     const uint32_t KM = (uint32_t)NB - 1u;
-    const int CW = NB / 2;
+    const int CW = CM == 2 ? 1 << g.hash_log2m : NB / 2;
     const int TW = TLDS ? 2 * NB : 0;                                 // (TLDS: the Float64 table in front of the count tables, as in gen_kernel)
-    uint32_t *C = CGLOBAL ? g.ctab + (size_t)slot * (size_t)CW : gsmem + (size_t)TW + (size_t)wave * (size_t)CW;
+    Counts<CM> cnt;
+    cnt.C = CGLOBAL ? g.ctab + (size_t)slot * (size_t)CW : gsmem + (size_t)TW + (size_t)wave * (size_t)CW;
+    cnt.lane = lane; cnt.CW = CW; cnt.fault = false;
+    cnt.bmask = CM == 2 ? (uint32_t)(CW / 4 - 1) : 0u; cnt.hshift = CM == 2 ? 32 - (g.hash_log2m - 2) : 0;
     if constexpr (TLDS) {
         for (int i = threadIdx.x; i < NB; i += blockDim.x) reinterpret_cast<double *>(gsmem)[i] = g.R[i];
         __syncthreads();
@@ -436,8 +595,7 @@ __global__ __launch_bounds__(1024) void gen_chain_kernel(ScanArgs a, GenParams g
     constexpr int CS_SPLIT = 1, CS_DETAIL = 2, CS_FULL = 4;
 
     for (int tile = slot; tile < a.n_tiles; tile += g.n_slots) {
-        for (int i = lane; i < CW; i += 64) C[i] = 0;
-        if constexpr (CGLOBAL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        cnt.clear();
         const TileDesc td = a.tiles[tile];
         const int n_valid = td.n_valid;
         const uint32_t *gi = a.inter + 2 * td.word_base;
@@ -571,25 +729,19 @@ __global__ __launch_bounds__(1024) void gen_chain_kernel(ScanArgs a, GenParams g
             pw = load_words(b + 1);                                   // the next step's genome words, one step ahead
             const bool differ = kp != ks;
             const bool actE = differ || !haveL, actL = differ && haveL;
-            const uint32_t shp = 16u * (kp & 1u), shs = 16u * (ks & 1u);
-            uint32_t wcp, wcs, wop = 0, wos = 0;
-            if constexpr (CGLOBAL) {
-                wcp = __hip_atomic_load(&C[kp >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                wcs = __hip_atomic_load(&C[ks >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wcp), "+v"(wcs) : : "memory");
-                if (actE) wop = __hip_atomic_fetch_add(&C[kp >> 1], 1u << shp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (actL) wos = __hip_atomic_fetch_add(&C[ks >> 1], (uint32_t)(-(int32_t)(1u << shs)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wop), "+v"(wos) : : "memory");
-            } else {
-                wcp = C[kp >> 1];
-                wcs = C[ks >> 1];
-                if (actE) wop = atomicAdd(&C[kp >> 1], 1u << shp);
-                if (actL) wos = atomicSub(&C[ks >> 1], 1u << shs);
+            if constexpr (CM == 2) {
+                if (b > 0 && b % g.hash_rebuild == 0) cnt.rebuild(gi, b, nk, KM);
+            }
+            uint32_t cp, cs, oldp, olds;
+            cnt.step(kp, ks, actE, actL, cp, cs, oldp, olds);
+            if constexpr (CM == 2) {
+                if (cnt.fault) {                                      // (wave-uniform; cannot happen, see Counts)
+                    if (lane == 0) atomicOr(a.chain.status, 2u);
+                    break;
+                }
             }
             int32_t cP, cS;
             {
-                const uint32_t cp = (wcp >> shp) & 0xFFFFu, cs = (wcs >> shs) & 0xFFFFu;
-                const uint32_t oldp = (wop >> shp) & 0xFFFFu, olds = (wos >> shs) & 0xFFFFu;
                 const bool all = nk < 64;
                 uint64_t pendE = __ballot(actE && (all || oldp != cp)), pendL = __ballot(actL && (all || olds != cs));
                 int32_t corrP = 0, corrS = 0;
@@ -683,22 +835,51 @@ __global__ __launch_bounds__(1024) void gen_chain_kernel(ScanArgs a, GenParams g
 }
 
 // ---- geometry + launch ----------------------------------------------------------------------------------------------
-bool generic_counts_in_lds(int k) { return k <= 7; }                  // 2 * 4^k bytes per wave: 32 KiB at k = 7
 static bool generic_table_in_lds(int k) { return k <= 6; }            // 4 (S) or 8 (Float64) bytes per k-mer: at most 32 KiB
 
+// Where the counts of a launch live (GenParams::cmode) for windows of at most nk_max k-mers, and the hash table's size and
+// rebuild period: 2048 entries (8 KiB per wave) up to 448 k-mers per window, 4096 up to 1400, 8192 beyond; an insertion consumes
+// at most one never-used entry, 64 insertions per step, and an eighth of the table stays never-used:
+// rebuild = (M - n - 64 - M / 8) / 64 >= 20 steps (a rebuild costs about 2.5 steps).
+void generic_set_mode(GenParams &g, int nk_max)
+{
+    g.cmode = g.k <= 7 ? 0 : 1;
+    g.hash_log2m = 0; g.hash_rebuild = 0;
+    const char *e = getenv("KGMA_GENERIC_HASH");                      // (0: the global count tables, for comparison and tests)
+    if (g.k >= 8 && nk_max <= KGMA_HASH_MAX_NK && !(e && atoi(e) == 0)) {
+        g.cmode = 2;
+        // (measured at k = 8, n = 282, 400 Mb: 2048 entries -- 16 waves per CU -- 94 Gbp/s, 4096 -- 10 waves -- 79, 8192 -- 5 waves -- 49)
+        g.hash_log2m = nk_max <= 448 ? 11 : (nk_max <= 1400 ? 12 : 13);
+        if (const char *r = getenv("KGMA_HASH_LOG2M")) g.hash_log2m = std::max(g.hash_log2m, std::min(13, atoi(r)));   // experiments: larger only
+        const int M = 1 << g.hash_log2m;
+        g.hash_rebuild = std::max(1, (M - nk_max - 64 - M / 8) / 64);
+        if (const char *r = getenv("KGMA_HASH_REBUILD")) g.hash_rebuild = std::max(1, std::min(g.hash_rebuild, atoi(r)));   // experiments
+    }
+}
+
+int generic_count_mode(int k, int nk_max)
+{
+    GenParams g;
+    g.k = k;
+    generic_set_mode(g, nk_max);
+    return g.cmode;
+}
+
 namespace {
-struct GenGeom { bool cglobal, tlds; int nw; size_t lds; };
+struct GenGeom { int cmode; bool tlds; int nw; size_t lds; };
 }
 
 // waves (= streams) per workgroup and its LDS: [table (TLDS) | nw count tables] out of 160 KiB less `reserve`
-static GenGeom generic_geom_of(int k, bool fp, size_t reserve)
+static GenGeom generic_geom_of(const GenParams &g, bool fp, size_t reserve)
 {
     GenGeom q;
-    q.cglobal = !generic_counts_in_lds(k);
-    q.tlds = !q.cglobal && generic_table_in_lds(k);
-    if (q.cglobal) { q.nw = 4; q.lds = 0; return q; }
-    const size_t per = (size_t)2 << (2 * k);
-    const size_t tab = q.tlds ? ((size_t)(fp ? 8 : 4) << (2 * k)) : 0;
+    q.cmode = g.cmode;
+    q.tlds = q.cmode == 0 && generic_table_in_lds(g.k);
+    if (q.cmode == 1) { q.nw = 4; q.lds = 0; return q; }
+    const size_t per = q.cmode == 2 ? (size_t)4 << g.hash_log2m : (size_t)2 << (2 * g.k);
+    const size_t tab = q.tlds ? ((size_t)(fp ? 8 : 4) << (2 * g.k)) : 0;
+    // (ten-wave workgroups of 8 KiB hash tables, two per CU = 20 waves, measured against sixteen-wave ones: scan 89.5 against 93.8 Gbp/s,
+    //  chain 83.6 against 81.6 -- no gain, the larger workgroup stays)
     const size_t w = (((size_t)160 << 10) - reserve - tab) / per;
     q.nw = (int)(w > 16 ? 16 : w);
     q.lds = tab + (size_t)q.nw * per;
@@ -707,28 +888,33 @@ static GenGeom generic_geom_of(int k, bool fp, size_t reserve)
 
 static const void *generic_fn(bool fp, const GenGeom &q)
 {
-    if (fp) return q.cglobal ? reinterpret_cast<const void *>(&gen_kernel<true, true, false>)
-                             : (q.tlds ? reinterpret_cast<const void *>(&gen_kernel<true, false, true>) : reinterpret_cast<const void *>(&gen_kernel<true, false, false>));
-    return q.cglobal ? reinterpret_cast<const void *>(&gen_kernel<false, true, false>)
-                     : (q.tlds ? reinterpret_cast<const void *>(&gen_kernel<false, false, true>) : reinterpret_cast<const void *>(&gen_kernel<false, false, false>));
+    if (fp) {
+        if (q.cmode == 1) return reinterpret_cast<const void *>(&gen_kernel<true, 1, false>);
+        if (q.cmode == 2) return reinterpret_cast<const void *>(&gen_kernel<true, 2, false>);
+        return q.tlds ? reinterpret_cast<const void *>(&gen_kernel<true, 0, true>) : reinterpret_cast<const void *>(&gen_kernel<true, 0, false>);
+    }
+    if (q.cmode == 1) return reinterpret_cast<const void *>(&gen_kernel<false, 1, false>);
+    if (q.cmode == 2) return reinterpret_cast<const void *>(&gen_kernel<false, 2, false>);
+    return q.tlds ? reinterpret_cast<const void *>(&gen_kernel<false, 0, true>) : reinterpret_cast<const void *>(&gen_kernel<false, 0, false>);
 }
 
 static const void *generic_chain_fn(const GenGeom &q)
 {
-    return q.cglobal ? reinterpret_cast<const void *>(&gen_chain_kernel<true, false>)
-                     : (q.tlds ? reinterpret_cast<const void *>(&gen_chain_kernel<false, true>) : reinterpret_cast<const void *>(&gen_chain_kernel<false, false>));
+    if (q.cmode == 1) return reinterpret_cast<const void *>(&gen_chain_kernel<1, false>);
+    if (q.cmode == 2) return reinterpret_cast<const void *>(&gen_chain_kernel<2, false>);
+    return q.tlds ? reinterpret_cast<const void *>(&gen_chain_kernel<0, true>) : reinterpret_cast<const void *>(&gen_chain_kernel<0, false>);
 }
 
 // The whole LDS of a CU where the runtime grants it to one workgroup (k = 7: five 32 KiB count tables; k = 6, Float64: the 32 KiB
-// table and sixteen 8 KiB count tables), else with 1 KiB left over.
-static GenGeom generic_geom(int k, bool fp, bool chain)
+// table and sixteen 8 KiB count tables; ten 16 KiB hash tables), else with 1 KiB left over.
+static GenGeom generic_geom(const GenParams &g, bool fp, bool chain)
 {
-    GenGeom q = generic_geom_of(k, fp, 0);
-    if (q.cglobal) return q;
+    GenGeom q = generic_geom_of(g, fp, 0);
+    if (q.cmode == 1) return q;
     const void *fn = chain ? generic_chain_fn(q) : generic_fn(fp, q);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds) == hipSuccess) return q;
     (void)hipGetLastError();
-    return generic_geom_of(k, fp, 1024);
+    return generic_geom_of(g, fp, 1024);
 }
 
 static int generic_resident(const void *fn, const GenGeom &q, int k)
@@ -739,31 +925,40 @@ static int generic_resident(const void *fn, const GenGeom &q, int k)
         (void)hipGetLastError();
         blocks = 1;
     }
-    // (global count tables: 2 * 4^k bytes per slot; a step is two dependent round trips to L2, so the walk is latency-bound and
-    //  wants waves: 16 per CU at k = 8, 9 (128 / 512 KiB per slot), 8 at k = 10 (2 MiB per slot: 4 GiB of tables))
-    if (q.cglobal) blocks = std::min(blocks, k >= 10 ? 2 : 4);
+    // (global count tables: 2 * 4^k bytes per slot; 16 waves per CU at k = 8, 9 (128 / 512 KiB per slot), 8 at k = 10 (2 MiB per
+    //  slot: 4 GiB of tables))
+    if (q.cmode == 1) blocks = std::min(blocks, k >= 10 ? 2 : 4);
     if (blocks * q.nw > 32) blocks = 32 / q.nw;
     return q.nw * (blocks < 1 ? 1 : blocks);
 }
 
-// streams resident per CU (what the host sizes the stream table and the global count tables for)
-int generic_slots_per_cu(int k, bool fp)
+// streams resident per CU (what the host sizes the stream table and the global count tables for); nk_max: the longest window
+// (in k-mers) of the scan's KFVs -- every launch of a scan runs in the same geometry over one stream table
+int generic_slots_per_cu(int k, bool fp, int nk_max)
 {
-    const GenGeom q = generic_geom(k, fp, false);
+    GenParams g;
+    g.k = k;
+    generic_set_mode(g, nk_max);
+    const GenGeom q = generic_geom(g, fp, false);
     return generic_resident(generic_fn(fp, q), q, k);
 }
 
 // streams resident per CU of the chain kernel (it reads the Float64 table whatever the KFV's form)
-int generic_chain_slots_per_cu(int k)
+int generic_chain_slots_per_cu(int k, int nk)
 {
-    const GenGeom q = generic_geom(k, true, true);
+    GenParams g;
+    g.k = k;
+    generic_set_mode(g, nk);
+    const GenGeom q = generic_geom(g, true, true);
     return generic_resident(generic_chain_fn(q), q, k);
 }
 
 static hipError_t launch_gen(const void *fn, const GenGeom &q, const ScanArgs &a, const GenParams &g, hipStream_t st)
 {
     if (q.nw < 1 || g.n_slots < q.nw || g.n_slots % q.nw != 0) return hipErrorInvalidConfiguration;
-    if (q.cglobal && g.ctab == nullptr) return hipErrorInvalidValue;
+    if (q.cmode == 1 && g.ctab == nullptr) return hipErrorInvalidValue;
+    if (q.cmode == 2 && (g.hash_log2m < 8 || g.hash_log2m > 13 || g.hash_rebuild < 1 || g.nk > KGMA_HASH_MAX_NK ||
+                         (1 << g.hash_log2m) - g.nk - 64 * (g.hash_rebuild + 1) < 4)) return hipErrorInvalidConfiguration;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds);
     if (e != hipSuccess) return e;
     ScanArgs a_copy = a;
@@ -772,11 +967,12 @@ static hipError_t launch_gen(const void *fn, const GenGeom &q, const ScanArgs &a
     return hipLaunchKernel(fn, dim3((unsigned)(g.n_slots / q.nw)), dim3(64u * (unsigned)q.nw), args, q.lds, st);
 }
 
+// (g.cmode / hash_log2m / hash_rebuild as set by generic_set_mode for the scan's longest window)
 hipError_t launch_generic_chain(const ScanArgs &a, const GenParams &g, hipStream_t st)
 {
     if (a.n_tiles <= 0) return hipSuccess;
     if (g.R == nullptr) return hipErrorInvalidConfiguration;
-    const GenGeom q = generic_geom(g.k, true, true);
+    const GenGeom q = generic_geom(g, true, true);
     return launch_gen(generic_chain_fn(q), q, a, g, st);
 }
 
@@ -784,7 +980,7 @@ hipError_t launch_generic(const ScanArgs &a, const GenParams &g, hipStream_t st)
 {
     if (a.n_tiles <= 0) return hipSuccess;
     if (g.fp ? g.R == nullptr : g.S == nullptr) return hipErrorInvalidConfiguration;
-    const GenGeom q = generic_geom(g.k, g.fp != 0, false);
+    const GenGeom q = generic_geom(g, g.fp != 0, false);
     return launch_gen(generic_fn(g.fp != 0, q), q, a, g, st);
 }
 

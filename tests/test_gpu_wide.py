@@ -188,6 +188,51 @@ def test_generic_kernel_forced(ctx, data_dir, genes, k, monkeypatch):
     assert ctx.kernel_name().startswith("gen_kernel"), ctx.kernel_name()
 
 
+@pytest.mark.parametrize("k,W", [(8, 70), (8, 289), (8, 455), (8, 457), (9, 1408), (9, 1410), (10, 1992), (10, 1994), (8, 300)])
+def test_generic_kernel_hash_counts(ctx, k, W, monkeypatch):
+    """k >= 8: the generic kernel keeps the window's distinct k-mers in a hash table in LDS (2048 / 4096 / 8192 entries by window
+    length, rebuilt every few dozen steps) up to 1983 k-mers per window, 4^k counters in global memory beyond -- on both sides of
+    every size boundary, with stretches that put all 64 lanes of a step on one k-mer (homopolymer, N run) or on two / four (short
+    repeats), records around the window length, streams long enough for many rebuilds.  All three modes against both oracles, the
+    chain kernel at every window, and every result identical to the global-table form's (KGMA_GENERIC_HASH=0)."""
+    monkeypatch.setenv("KGMA_KERNEL", "generic")
+    monkeypatch.setenv("KGMA_CHAIN_GENERIC", "1")
+    rng = np.random.default_rng(1000 * k + W)
+    base, ref = _family(rng, W, k)
+    contigs = _wide_genome(rng, W, [base])
+    contigs[0] = contigs[0][:40_000] + b"C" * 5000 + b"GT" * 1200 + contigs[0][40_000:]
+    thr = _thr_for(rng, ref)
+    hits, d = _assert_single_parity(ctx, contigs, ref, thr)
+    assert ctx.kernel_name().startswith("gen_kernel"), ctx.kernel_name()
+    assert len(hits) >= 1
+    # the running Float64 value of the reference at every window of a record (the chain kernel, hash form)
+    seq = contigs[0][:30_000] + contigs[0][-9000:]
+    nwin = len(seq) - W + 1
+    g = ctx.genome_from_host([seq])
+    try:
+        got = g.chain_values(0, 1, [(1, nwin)])
+        assert ctx.stats()["chain_device_pairs"] == 1
+        _, od = orc.single_scan([seq], ref["RV"], k, W, thr, 50, return_dists=True)
+        want = np.concatenate([[orc.kmer_dist_kfv(seq[:W], ref["RV"], k)], od])
+        assert np.array_equal(got, want), f"first mismatch at window {int(np.argmax(got != want)) + 1}"
+    finally:
+        g.free()
+    # ... and the same scan with the 4^k counters in global memory: identical dips and distances
+    dips = ctx_dips_of(ctx, contigs, ref, thr)
+    monkeypatch.setenv("KGMA_GENERIC_HASH", "0")
+    assert ctx_dips_of(ctx, contigs, ref, thr) == dips
+
+
+def ctx_dips_of(ctx, contigs, ref, thr):
+    ctx.set_refs(ref["k"], [ref["RV"]], [ref["ws"]], [thr], [ref["N"]])
+    g = ctx.genome_from_host(contigs)
+    try:
+        ctx.scan(g, _lib.MODE_SINGLE, 50, 0, _lib.F_RETURN_DISTS | _lib.F_NO_TIE_RESOLVE, None)
+        return [tuple(sorted(d.items())) for d in ctx.dips()], ctx.dists(1).tobytes()
+    finally:
+        g.free()
+
+
 def test_generic_kernel_forced_cluster(ctx, alp_clusters, genes, monkeypatch):
     monkeypatch.setenv("KGMA_KERNEL", "generic")
     rng = np.random.default_rng(77)
