@@ -98,6 +98,9 @@ def main():
     run("generic int", 8, 3000, chain=True)
     run("generic Float64", 8, 289, fp=True)
     run("generic int", 10, 3000)
+    run("generic int (forced)", 8, 1000, env={"KGMA_KERNEL": "generic", "KGMA_CHAIN_GENERIC": "1"}, chain=True)
+    run("generic int (forced)", 8, 1990, env={"KGMA_KERNEL": "generic", "KGMA_CHAIN_GENERIC": "1"}, chain=True)
+    run("generic Float64", 10, 289, fp=True, chain=True)
     g.free()
     ctx.close()
     if args.out:
