@@ -478,6 +478,29 @@ def test_fasta_ingest_on_device(ctx, data_dir, tmp_path):
             os.close(wfd)
 
 
+def test_ingest_leaves_the_callers_affinity_alone(ctx, tmp_path):
+    """The ingest binds itself to the GPU's NUMA node for the duration of the call (NumaBind): the calling thread's CPU affinity is
+    what it was afterwards, also when the caller had restricted it, and on the error path."""
+    rng = np.random.default_rng(5)
+    seqs = [random_dna(rng, 300_000), random_dna(rng, 1000)]
+    p = tmp_path / "g.fasta"
+    p.write_bytes(b"".join(b">r%d\n" % i + s + b"\n" for i, s in enumerate(seqs)))
+    before = os.sched_getaffinity(0)
+    for mask in (before, set(sorted(before)[:max(1, len(before) // 2)]), set(sorted(before)[-1:])):
+        os.sched_setaffinity(0, mask)
+        try:
+            for make in (lambda: ctx.genome_from_host(seqs), lambda: ctx.genome_from_fasta(str(p))):
+                g = make()
+                assert os.sched_getaffinity(0) == mask
+                assert g.fetch(0, 1, 50) == seqs[0][:50] and g.fetch(1, 1, 1000) == seqs[1]
+                g.free()
+            with pytest.raises(_lib.KgmaError):
+                ctx.genome_from_fasta(b"ACGT\n>late header\nACGT\n")
+            assert os.sched_getaffinity(0) == mask
+        finally:
+            os.sched_setaffinity(0, before)
+
+
 def test_empty_and_tiny_inputs(ctx, alp_ref):
     ctx.set_refs(6, [alp_ref["RV"]], [alp_ref["ws"]], [30.0], [alp_ref["N"]])
     g = ctx.genome_from_host([])
